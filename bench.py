@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s of the 800x800 NeRF inference render (BASELINE.json configs[1]).
+
+One "step" = one full 800x800 frame (640,000 rays) of the hot path
+  trace(count) -> scan -> trace(write) -> sampler+encode+MLP -> composite
+on synthetic, HBM-resident inputs: 128^3 procedural "Lego stand-in" occupancy,
+the reference's 8x128 ReLU MLP with Composite-Frequency encoding (main.cu:35-69),
+seeded random fp16 weights, 32 samples per crossed occupied cell
+(sampler/sampler.h:4), poses on the NeRF-synthetic hemisphere.
+
+Multi-GPU (--gpus N, launched by torch.distributed.run, one rank per GPU): the
+frame's image rows are dealt round-robin to the ranks (ray sharding, no
+data-path collective), each rank renders its rows, and the rendered rows are
+gathered on rank 0 with one RCCL gather per frame (0.96 MB per rank at N=8).
+Total work per step is fixed, so this is strong scaling.
+
+Prints ONE JSON line on rank 0; see DESIGN.md for the roofline arithmetic.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=800)
+    ap.add_argument("--height", type=int, default=800)
+    ap.add_argument("--grid", type=int, default=128)
+    ap.add_argument("--neurons", type=int, default=128)
+    ap.add_argument("--layers", type=int, default=8)
+    ap.add_argument("--poses", type=int, default=4)
+    ap.add_argument("--cpu-rays", type=int, default=1536, help="rays of the cpu_baseline / PSNR sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--kernel-steps", type=int, default=5, help="extra frames with HIP events around the MLP kernel")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run "
+                  f"--nproc-per-node {args.gpus}", file=sys.stderr)
+        sys.exit(2)
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from rtx_nerf_amd import api, render, scenes
+
+    W, H, R = args.width, args.height, args.grid
+    dense = scenes.lego_standin_density(R, seed=0)
+    words = scenes.pack_occupancy(dense)
+    occ = torch.from_numpy(words.view(np.int32).copy()).cuda()
+    net = api.Network(n_neurons=args.neurons, n_hidden_layers=args.layers)
+    params = scenes.xavier_params_fp16(args.neurons, args.layers, net.encoded_width(), seed=1337)
+    net.set_params(torch.from_numpy(params).cuda())
+    focal = scenes.lego_focal_length(True)
+    poses = [scenes.pose_spherical(360.0 * i / args.poses + 15.0, -30.0, origin_scale=10.0) for i in range(args.poses)]
+
+    # ray shard of this rank: image rows rank, rank+world, ... (chunk = one row)
+    rows = list(range(rank, H, world))
+    n_local = len(rows) * W
+    window = (W, world * W) if world > 1 else (0, 0)
+    pipe = render.RenderPipeline(net, R, W, H, focal, occupancy=occ, max_rays=n_local, max_segments=1024,
+                                 window=window)
+    ray_begin = rank * W if world > 1 else 0
+    worst = pipe.calibrate(poses, ray_begin=ray_begin, ray_count=n_local)
+    poses_d = [torch.from_numpy(p.reshape(16)).cuda() for p in poses]
+
+    # gather plumbing: equal shards only when H % world == 0; otherwise pad to the largest shard
+    n_max = ((H + world - 1) // world) * W
+    pix_bufs = [torch.zeros((n_max, 3), device="cuda") for _ in range(2)]
+    gather_bufs = [[torch.empty((n_max, 3), device="cuda") for _ in range(world)] for _ in range(2)] \
+        if (world > 1 and rank == 0) else None
+    pending = [None, None]
+
+    def step(i):
+        b = i & 1
+        if pending[b] is not None:
+            pending[b].wait()           # frame i-2's gather is done with this buffer
+            pending[b] = None
+        pipe.look_at.copy_(poses_d[i % len(poses_d)], non_blocking=True)
+        pipe.render(ray_begin=ray_begin, ray_count=n_local, out=pix_bufs[b][:n_local])
+        if world > 1:
+            pending[b] = dist.gather(pix_bufs[b], gather_bufs[b] if rank == 0 else None, dst=0, async_op=True)
+
+    def drain():
+        for b in range(2):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    drain()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    drain()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert not pipe.overflowed(), "segment capacity overflow: calibrate() margin too small"
+
+    # ---- dominant kernel (fused sampler+encode+MLP), HIP events on the launch stream ----
+    kern_ms, kern_samples = [], []
+    for i in range(args.kernel_steps):
+        pipe.look_at.copy_(poses_d[i % len(poses_d)], non_blocking=True)
+        nh, idx = pipe.num_hits[:n_local], pipe.indices[:n_local]
+        pipe._trace(ray_begin, n_local, write=False)
+        api.scan_hits(nh, idx, pipe.total, pipe.scan_ws)
+        pipe._trace(ray_begin, n_local, write=True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        net.forward_segments(pipe.start, pipe.end, pipe.view_dirs, pipe.seg_ray, pipe.total, pipe.max_segments,
+                             pipe.radiance, pipe.t_vals)
+        e1.record()
+        torch.cuda.synchronize()
+        kern_ms.append(e0.elapsed_time(e1))
+        kern_samples.append(int(pipe.total.item()) * api.NUM_SAMPLES_PER_SEGMENT)
+
+    rays_per_step = W * H
+    value = rays_per_step * args.steps / elapsed / 1e6
+    out = {
+        "metric": "Mrays/sec rendered (NeRF inference render, traverse->sample->MLP->composite)",
+        "value": round(value, 4),
+        "unit": "Mrays/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f16",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{W}x{H} inference render, {R}^3 grid (procedural Lego stand-in occupancy, "
+                        f"{100.0 * dense.mean():.1f}% cells), {args.layers}x{args.neurons} ReLU MLP + Composite-Frequency "
+                        f"encoding, 32 samples/segment, {args.poses} hemisphere poses, seeded random fp16 weights",
+            "rays_per_step": rays_per_step,
+            "parallelism": f"ray-shard x{world} (rows round-robin) + RCCL gather" if world > 1 else "single GPU",
+            "trace_mode": "dda+mip",
+        },
+    }
+    if rank == 0:
+        flops = net.flops_per_sample()
+        ms = float(np.mean(kern_ms)) if kern_ms else None
+        smp = float(np.mean(kern_samples)) if kern_samples else 0.0
+        if ms:
+            ach = flops * smp / (ms * 1e-3) / 1e12
+            out["roofline"] = {
+                "kernel": "mlp_fwd_kernel<128,...,segments,radiance>" if args.neurons == 128 else "mlp_fwd_kernel",
+                "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                "flop_per_sample": flops, "samples_per_launch": smp, "kernel_ms": round(ms, 4),
+            }
+        out["config"]["segments_per_frame_local_max"] = worst
+        out["config"]["mean_samples_per_ray"] = round(smp / max(n_local, 1), 2)
+
+    # ---- cpu_baseline + PSNR vs oracle on a bounded ray sample (rank 0, N=1 only) ----
+    if rank == 0 and world == 1 and not args.no_cpu:
+        import oracle as O   # checker / baseline only
+        stride = max(1, (W * H) // args.cpu_rays)
+        ray_ids = (np.arange(args.cpu_rays, dtype=np.int64) * stride + (stride // 2) * 0).astype(np.uint32)
+        # centre-weighted sample so that it is not dominated by empty rays: every `stride`-th ray of the frame
+        cfg = O.mlp_cfg(n_neurons=args.neurons, n_hidden_layers=args.layers)
+        pose = poses[0]
+        pipe.look_at.copy_(poses_d[0])
+        gpu_pix = pipe.render(ray_begin=0, ray_count=n_local).cpu().numpy()
+        t1 = time.perf_counter()
+        cpu_pix, cpu_samples = O.render(pose, focal, W / H, W, H, R, words, 1, cfg, params, ray_ids)
+        cpu_s = time.perf_counter() - t1
+        mse = float(((gpu_pix[ray_ids] - cpu_pix) ** 2).mean())
+        out["psnr_vs_oracle_db"] = round(10.0 * np.log10(1.0 / max(mse, 1e-20)), 2)
+        out["max_abs_err_vs_oracle"] = float(np.abs(gpu_pix[ray_ids] - cpu_pix).max())
+        out["cpu_baseline"] = {
+            "value": round(args.cpu_rays / cpu_s / 1e6, 6), "unit": "Mrays/s", "cores": O.num_threads(),
+            "kind": "port",
+            "sample": f"{args.cpu_rays} rays (every {stride}th ray of pose 0's frame, {cpu_samples} samples), "
+                      f"oracle/rtxn_oracle.c orc_render, OpenMP over rays, {cpu_s:.1f} s",
+        }
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

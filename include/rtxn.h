@@ -1,0 +1,215 @@
+/*
+ * rtxn.h -- C ABI of librtxn.so, the MI355X (gfx950) implementation of the
+ * owensgroup/rtx_nerf hot path: ray generation + ray/grid traversal, CSR
+ * compaction, per-segment sampling, frequency-encoded fully-fused MLP and
+ * alpha-compositing volume rendering (forward and backward).
+ *
+ * The reference has no FFI layer; its "operator API" is a handful of C++ free
+ * functions and PODs called from main.cu.  Each entry point below names the
+ * reference interface it replaces (paths relative to the reference root).  The
+ * C++ drop-in headers in include/rtxn/ (sampler.h, vol_render.h, params.h,
+ * data_loader.h) keep the reference's own names and argument order and forward
+ * to these symbols.  INTEGRATION.md shows the binding a maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the comment says "host";
+ *   - the caller owns every buffer; the library allocates nothing per call
+ *     (rtxn_mlp_create owns its packed-weight buffer until rtxn_mlp_destroy);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all
+ *     work is enqueued asynchronously on it, nothing synchronises the host, so
+ *     every call is hipGraph-capturable;
+ *   - return value: RTXN_OK or an error code; rtxn_last_error() (host,
+ *     thread-local) describes the last failure.  The reference's functions
+ *     return void and print-and-continue (common/common.h:38-50).
+ *   - there is no CPU fallback: without a HIP device every compute entry
+ *     point fails with RTXN_ERR_HIP.
+ */
+#ifndef RTXN_H
+#define RTXN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTXN_VERSION 100
+
+typedef void* rtxn_stream_t;
+
+enum rtxn_status {
+  RTXN_OK = 0,
+  RTXN_ERR_INVALID = 1,     /* bad argument (null pointer, negative size, unsupported width) */
+  RTXN_ERR_HIP = 2,         /* a HIP runtime call or kernel launch failed */
+  RTXN_ERR_UNSUPPORTED = 3  /* valid request this build does not implement */
+};
+
+int rtxn_version(void);
+const char* rtxn_last_error(void);
+
+/* ---- sampler/sampler.h:4-9 ------------------------------------------------ */
+#define RTXN_NUM_SAMPLES_PER_SEGMENT 32
+enum rtxn_sampling_type {
+  RTXN_SAMPLING_REGULAR = 0,
+  RTXN_SAMPLING_STRATIFIED_JITTERING = 1,
+  RTXN_SAMPLING_UNIFORM = 2
+};
+
+/* ---- traversal ------------------------------------------------------------ */
+/* Replaces struct Params (rtx/include/params.h:14-42), the RTXDataHolder
+ * lifecycle (rtx/include/rtxFunctions.h:56-100: initContext .. buildSBT,
+ * initAccelerationStructure) and optixLaunch(pipeline_ray_march, ..., W, H, 1)
+ * (main.cu:506-508).  There is no acceleration structure to build: the grid of
+ * make_grid (main.cu:154-174), R^3 cells over [-1,1]^3, is walked analytically;
+ * `handle`, `aabb` and `num_primitives` have no counterpart. */
+enum rtxn_trace_mode {
+  RTXN_TRACE_COMPAT = 0, /* reference arithmetic: re-launch from each exit point (optixPrograms.cu:99-115,180-248) */
+  RTXN_TRACE_DDA = 1     /* global-t 3D-DDA with hierarchical empty-space skipping; same cells, points within 1e-5 */
+};
+
+typedef struct rtxn_trace_params {
+  /* rays: either a pinhole camera (look_at != NULL; params.h:17,33-34,41) ... */
+  const float* look_at;      /* 16 floats, row-major 4x4, translation at [3],[7],[11] */
+  float focal_length;        /* params.h:33 */
+  float aspect_ratio;        /* params.h:34 */
+  uint32_t width, height;    /* params.h:41 */
+  /* ... or explicit rays (look_at == NULL): float3[width*height] each, d normalised */
+  const float* rays_o;
+  const float* rays_d;
+  /* window of the launch handled by this call: rays [ray_begin, ray_begin+ray_count)
+   * of the width*height launch (row-major, ray = x + y*width, optixPrograms.cu:45).
+   * Outputs are indexed by the LOCAL ray number (ray - ray_begin).  This is how
+   * a launch is sharded across GPUs. */
+  uint32_t ray_begin, ray_count;
+  /* optional interleave: local ray i maps to launch ray
+   * ray_begin + (i / window_chunk) * window_stride + (i % window_chunk); 0,0 = contiguous.
+   * (chunk = width, stride = n_gpus*width gives GPU g every n_gpus-th image row.) */
+  uint32_t window_chunk, window_stride;
+  /* grid */
+  int grid_res;              /* R; cell = 2/R (main.cu:156,482) */
+  const uint32_t* occupancy; /* R^3 bits, bit ((x*R+y)*R+z); NULL = dense (reference) */
+  const uint32_t* occupancy_coarse; /* (R/4)^3 bits, OR of 4^3 blocks; NULL = none (from rtxn_build_occupancy_mip) */
+  int mode;                  /* enum rtxn_trace_mode */
+  /* outputs */
+  float* ray_origins;        /* float3[ray_count]  (params.h:25), may be NULL */
+  float* viewing_direction;  /* float2[ray_count]  (params.h:32), may be NULL */
+  int* num_hits;             /* int[ray_count]     (params.h:31) */
+  /* segment outputs; any may be NULL.  Layout: strided (reference) when
+   * indices == NULL: slot = local_ray*intersection_arr_size + k
+   * (optixPrograms.cu:184, main.cu:486); packed CSR when indices != NULL:
+   * slot = indices[local_ray] + k (the layout main.cu:646-673 builds on the
+   * host for the sampler). */
+  int intersection_arr_size; /* S (params.h:19); segments beyond S are counted, not stored */
+  const int* indices;
+  float* start_points;       /* float3 per slot (params.h:23) */
+  float* end_points;         /* float3 per slot (params.h:24) */
+  float* t_start;            /* float per slot  (params.h:28) */
+  float* t_end;              /* float per slot  (params.h:29) */
+  int* seg_ray;              /* int per slot: local ray of the segment (packed layout; new) */
+  long segment_capacity;     /* packed layout: slots >= capacity are not written (0 = unbounded) */
+} rtxn_trace_params;
+
+/* One launch: ray generation + grid march.  With every segment pointer NULL it
+ * is the counting pass of the two-pass packed pipeline (count -> rtxn_scan_hits
+ * -> write). */
+int rtxn_trace_grid(const rtxn_trace_params* p, rtxn_stream_t stream);
+
+/* Coarse occupancy mip for RTXN_TRACE_DDA: bit of coarse cell (X,Y,Z) of a
+ * (R/4)^3 grid = OR over its 4^3 fine cells.  R must be a multiple of 4.
+ * coarse: (R/4)^3 bits rounded up to whole uint32 words. */
+int rtxn_build_occupancy_mip(const uint32_t* occupancy, int grid_res, uint32_t* coarse, rtxn_stream_t stream);
+
+/* ---- CSR compaction -------------------------------------------------------- */
+/* Replaces thrust::reduce + thrust::exclusive_scan over num_hits
+ * (main.cu:631-637).  indices[i] = sum_{j<i} num_hits[j]; *total = sum of all.
+ * `total` is a device int: nothing is copied to the host.  workspace: at least
+ * rtxn_scan_workspace_bytes(n) bytes of device scratch. */
+size_t rtxn_scan_workspace_bytes(int n);
+int rtxn_scan_hits(const int* num_hits, int* indices, int* total, int n, void* workspace,
+                   size_t workspace_bytes, rtxn_stream_t stream);
+
+/* ---- sampler ---------------------------------------------------------------- */
+/* Replaces launchSampler (sampler/sampler.h:19-30, sampler/sampler.cu:105-131).
+ * start/end: float3[P] packed; view_dirs: float2[B]; t_vals: float[P*32];
+ * sampled_points: float[P*32*5] AoS (x,y,z,theta,phi); num_hits, indices:
+ * int[B].  grid_res is accepted and ignored, as in the reference. */
+int rtxn_sample(const float* start_points, const float* end_points, const float* view_dirs,
+                float* t_vals, float* sampled_points, int batch_size, int grid_res,
+                const int* num_hits, const int* indices, int sample_type, rtxn_stream_t stream);
+
+/* ---- volume rendering --------------------------------------------------------- */
+enum rtxn_volrender_mode {
+  RTXN_VR_COMPAT = 0,   /* reference arithmetic, vol_render.cu:19-143, quirks included */
+  RTXN_VR_NERF = 1      /* canonical NeRF quadrature: exclusive transmittance, exact analytic backward */
+};
+
+/* Replaces launch_volrender_cuda (vol_render/vol_render.h:5-13,
+ * vol_render.cu:144-164).  network_inputs is accepted and ignored (the
+ * reference never reads it).  network_outputs: float[P*K*4] AoS (r,g,b,sigma);
+ * ray_hit: float[P*K] (the sampler's t_vals); pixels: float[B*3]. */
+int rtxn_volrender_fwd(const float* network_inputs, const float* network_outputs, const int* num_hits,
+                       const int* indices, const float* ray_hit, int batch_size,
+                       int num_samples_per_hit, float* pixels, int mode, rtxn_stream_t stream);
+
+/* Replaces launch_volrender_backward_cuda (vol_render/vol_render.h:15-25,
+ * vol_render.cu:166-190).  loss_values is accepted and ignored.  loss_gradients:
+ * half[B*3]; radiance_gradients: half[P*K*4] (stride 4, as the reference
+ * writes them, vol_render.cu:108,136-139). */
+int rtxn_volrender_bwd(const float* loss_values, const void* loss_gradients,
+                       const float* sampled_points_radiance, const float* t_hit, const int* num_hits,
+                       const int* indices, int batch_size, int num_samples_per_hit,
+                       void* radiance_gradients, int mode, rtxn_stream_t stream);
+
+/* ---- MLP (tiny-cuda-nn surface used by main.cu) ------------------------------- */
+/* Replaces tcnn::create_from_config(5, 4, config) (main.cu:35-69,325),
+ * network->n_params / set_params / initialize_params (main.cu:327-349),
+ * network->forward (main.cu:721) and the convertHalfToFloat glue
+ * (main.cu:203-208,723-728).  Model: Composite(Frequency(n_pos_dims,
+ * n_pos_freqs), Frequency(n_dir_dims, n_dir_freqs)) -> n_hidden_layers x
+ * n_neurons ReLU -> 16 (n_output_dims used), fp16 weights, no biases. */
+enum rtxn_activation { RTXN_ACT_NONE = 0, RTXN_ACT_SIGMOID = 1 };
+
+typedef struct rtxn_mlp_config {
+  int n_pos_dims, n_pos_freqs;   /* 3, 10 (main.cu:52-54) */
+  int n_dir_dims, n_dir_freqs;   /* 2, 12 (main.cu:57-59: "n_bins" is not a Frequency key -> default 12) */
+  int n_neurons;                 /* 64 or 128 (main.cu:66) */
+  int n_hidden_layers;           /* >= 1 (main.cu:67) */
+  int n_output_dims;             /* <= 16 (main.cu:323) */
+  int output_activation;         /* enum rtxn_activation (main.cu:65) */
+} rtxn_mlp_config;
+
+typedef struct rtxn_mlp rtxn_mlp;
+
+int rtxn_mlp_create(const rtxn_mlp_config* cfg, rtxn_mlp** out);
+int rtxn_mlp_destroy(rtxn_mlp* m);
+/* number of fp16 parameters, tcnn layout: per layer a row-major [out][in]
+ * matrix (first: n_neurons x enc_padded; hidden: n_neurons^2; last: 16 x
+ * n_neurons), layers concatenated. */
+long rtxn_mlp_n_params(const rtxn_mlp* m);
+int rtxn_mlp_padded_output_width(const rtxn_mlp* m); /* 16 (main.cu:715) */
+int rtxn_mlp_encoded_width(const rtxn_mlp* m);       /* padded to a multiple of 16 */
+/* Xavier-uniform init from a PCG32 stream into HOST fp32 (main.cu:344-349). */
+int rtxn_mlp_initialize_params(const rtxn_mlp* m, uint64_t seed, float* host_params_fp32);
+/* Point the model at device fp16 params (tcnn layout); re-packs them into the
+ * MFMA fragment order the kernels read.  Call again after every update. */
+int rtxn_mlp_set_params(rtxn_mlp* m, const void* params_fp16, rtxn_stream_t stream);
+/* network->forward: input float[N*5] (column-major 5xN = the sampler's AoS),
+ * output half[N*16] (column-major 16xN). */
+int rtxn_mlp_forward(const rtxn_mlp* m, const float* input, void* output_half, long n, rtxn_stream_t stream);
+/* forward fused with the fp16->fp32 radiance glue: radiance float[N*4]. */
+int rtxn_mlp_forward_radiance(const rtxn_mlp* m, const float* input, float* radiance, long n,
+                              rtxn_stream_t stream);
+/* Sampler (REGULAR) + encoding + MLP + glue fused: reads packed segments,
+ * never materialises the 5-float samples.  *total_segments is the device int
+ * written by rtxn_scan_hits; the launch is sized by max_segments (capacity of
+ * the caller's buffers) and exits early beyond *total_segments.
+ * radiance: float[max_segments*32*4]; t_vals: float[max_segments*32] or NULL. */
+int rtxn_mlp_forward_segments(const rtxn_mlp* m, const float* start_points, const float* end_points,
+                              const float* view_dirs, const int* seg_ray, const int* total_segments,
+                              long max_segments, float* radiance, float* t_vals, rtxn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTXN_H */

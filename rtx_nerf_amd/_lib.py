@@ -1,0 +1,111 @@
+"""Loader for librtxn.so (the HIP implementation behind include/rtxn.h).
+
+torch is imported FIRST so that the HIP runtime torch ships (soname
+libamdhip64.so.7) is the one instance both torch and librtxn use: device
+pointers of torch tensors are then valid in librtxn's kernels and streams are
+shared.  There is no CPU fallback: a missing library is an ImportError-grade
+failure, and compute entry points fail with RTXN_ERR_HIP without a GPU.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librtxn.so")
+
+RTXN_OK = 0
+
+
+class RtxnError(RuntimeError):
+    pass
+
+
+class TraceParams(C.Structure):
+    """struct rtxn_trace_params (include/rtxn.h)."""
+    _fields_ = [
+        ("look_at", C.c_void_p),
+        ("focal_length", C.c_float),
+        ("aspect_ratio", C.c_float),
+        ("width", C.c_uint32),
+        ("height", C.c_uint32),
+        ("rays_o", C.c_void_p),
+        ("rays_d", C.c_void_p),
+        ("ray_begin", C.c_uint32),
+        ("ray_count", C.c_uint32),
+        ("window_chunk", C.c_uint32),
+        ("window_stride", C.c_uint32),
+        ("grid_res", C.c_int),
+        ("occupancy", C.c_void_p),
+        ("occupancy_coarse", C.c_void_p),
+        ("mode", C.c_int),
+        ("ray_origins", C.c_void_p),
+        ("viewing_direction", C.c_void_p),
+        ("num_hits", C.c_void_p),
+        ("intersection_arr_size", C.c_int),
+        ("indices", C.c_void_p),
+        ("start_points", C.c_void_p),
+        ("end_points", C.c_void_p),
+        ("t_start", C.c_void_p),
+        ("t_end", C.c_void_p),
+        ("seg_ray", C.c_void_p),
+        ("segment_capacity", C.c_long),
+    ]
+
+
+class MlpConfig(C.Structure):
+    """struct rtxn_mlp_config (include/rtxn.h)."""
+    _fields_ = [(n, C.c_int) for n in (
+        "n_pos_dims", "n_pos_freqs", "n_dir_dims", "n_dir_freqs",
+        "n_neurons", "n_hidden_layers", "n_output_dims", "output_activation")]
+
+
+# every symbol include/rtxn.h declares: name -> (restype, argtypes)
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_long, C.c_float
+SYMBOLS = {
+    "rtxn_version": (_I, []),
+    "rtxn_last_error": (C.c_char_p, []),
+    "rtxn_trace_grid": (_I, [C.POINTER(TraceParams), _P]),
+    "rtxn_build_occupancy_mip": (_I, [_P, _I, _P, _P]),
+    "rtxn_scan_workspace_bytes": (C.c_size_t, [_I]),
+    "rtxn_scan_hits": (_I, [_P, _P, _P, _I, _P, C.c_size_t, _P]),
+    "rtxn_sample": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _P]),
+    "rtxn_volrender_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _I, _P]),
+    "rtxn_volrender_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P]),
+    "rtxn_mlp_create": (_I, [C.POINTER(MlpConfig), C.POINTER(_P)]),
+    "rtxn_mlp_destroy": (_I, [_P]),
+    "rtxn_mlp_n_params": (_L, [_P]),
+    "rtxn_mlp_padded_output_width": (_I, [_P]),
+    "rtxn_mlp_encoded_width": (_I, [_P]),
+    "rtxn_mlp_initialize_params": (_I, [_P, C.c_uint64, _P]),
+    "rtxn_mlp_set_params": (_I, [_P, _P, _P]),
+    "rtxn_mlp_forward": (_I, [_P, _P, _P, _L, _P]),
+    "rtxn_mlp_forward_radiance": (_I, [_P, _P, _P, _L, _P]),
+    "rtxn_mlp_forward_segments": (_I, [_P, _P, _P, _P, _P, _P, _L, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises if it has not been built (python -c
+    'import __graft_entry__ as g; g.build()' or `make`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RtxnError(
+                f"{LIB_PATH} is missing: build it with `make` (hipcc --offload-arch=gfx950). "
+                "rtx_nerf_amd has no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(handle, name)  # AttributeError if the ABI drifted from the header
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what="librtxn"):
+    if rc != RTXN_OK:
+        msg = lib().rtxn_last_error()
+        raise RtxnError(f"{what} failed with status {rc}: {msg.decode() if msg else '?'}")

@@ -1,0 +1,215 @@
+"""Host-side mirror of the reference's operator interface over the C ABI.
+
+Function names, argument order and argument meaning follow the reference
+headers (sampler/sampler.h:19-30, vol_render/vol_render.h:5-25,
+rtx/include/params.h:14-42, and the tiny-cuda-nn calls of main.cu:325-349,721)
+so the parity tests read like the reference's call sites.  Arguments are torch
+CUDA tensors (plumbing: device memory + streams); all work is enqueued on
+torch's current stream.  Nothing here computes on the CPU.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import MlpConfig, TraceParams, check
+
+NUM_SAMPLES_PER_SEGMENT = 32           # sampler/sampler.h:4
+SAMPLING_REGULAR = 0                   # sampler/sampler.h:5-9
+SAMPLING_STRATIFIED_JITTERING = 1
+SAMPLING_UNIFORM = 2
+TRACE_COMPAT, TRACE_DDA = 0, 1
+VR_COMPAT, VR_NERF = 0, 1
+ACT_NONE, ACT_SIGMOID = 0, 1
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t, dtype=None, name="tensor"):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.RtxnError(f"{name} must be a CUDA tensor (librtxn has no CPU path)")
+    if not t.is_contiguous():
+        raise _lib.RtxnError(f"{name} must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise _lib.RtxnError(f"{name} must be {dtype}, got {t.dtype}")
+    return C.c_void_p(t.data_ptr())
+
+
+# --------------------------------------------------------------------------- traversal
+def trace_grid(look_at=None, focal_length=1.0, aspect_ratio=1.0, width=0, height=0, *, grid_res,
+               rays_o=None, rays_d=None, ray_begin=0, ray_count=None, occupancy=None,
+               occupancy_coarse=None, mode=TRACE_COMPAT, ray_origins=None, viewing_direction=None,
+               num_hits=None, intersection_arr_size=0, indices=None, start_points=None,
+               end_points=None, t_start=None, t_end=None, seg_ray=None, segment_capacity=0,
+               window_chunk=0, window_stride=0):
+    """optixLaunch(pipeline_ray_march, ..., width, height, 1) with Params (main.cu:481-508)."""
+    p = TraceParams()
+    p.look_at = _ptr(look_at, torch.float32, "look_at")
+    p.focal_length, p.aspect_ratio = focal_length, aspect_ratio
+    p.width, p.height = width, height
+    p.rays_o = _ptr(rays_o, torch.float32, "rays_o")
+    p.rays_d = _ptr(rays_d, torch.float32, "rays_d")
+    if look_at is None and rays_o is not None and width == 0:
+        p.width, p.height = rays_o.shape[0], 1
+    p.ray_begin = ray_begin
+    p.ray_count = (p.width * p.height - ray_begin) if ray_count is None else ray_count
+    p.grid_res = grid_res
+    p.occupancy = _ptr(occupancy, torch.int32, "occupancy")
+    p.occupancy_coarse = _ptr(occupancy_coarse, torch.int32, "occupancy_coarse")
+    p.mode = mode
+    p.ray_origins = _ptr(ray_origins, torch.float32, "ray_origins")
+    p.viewing_direction = _ptr(viewing_direction, torch.float32, "viewing_direction")
+    p.num_hits = _ptr(num_hits, torch.int32, "num_hits")
+    p.intersection_arr_size = intersection_arr_size
+    p.indices = _ptr(indices, torch.int32, "indices")
+    p.start_points = _ptr(start_points, torch.float32, "start_points")
+    p.end_points = _ptr(end_points, torch.float32, "end_points")
+    p.t_start = _ptr(t_start, torch.float32, "t_start")
+    p.t_end = _ptr(t_end, torch.float32, "t_end")
+    p.seg_ray = _ptr(seg_ray, torch.int32, "seg_ray")
+    p.segment_capacity = segment_capacity
+    p.window_chunk, p.window_stride = window_chunk, window_stride
+    check(_lib.lib().rtxn_trace_grid(C.byref(p), _stream()), "rtxn_trace_grid")
+
+
+def build_occupancy_mip(occupancy, grid_res):
+    rc = grid_res // 4
+    words = (rc ** 3 + 31) // 32
+    coarse = torch.empty(words, dtype=torch.int32, device=occupancy.device)
+    check(_lib.lib().rtxn_build_occupancy_mip(_ptr(occupancy, torch.int32), grid_res, _ptr(coarse), _stream()),
+          "rtxn_build_occupancy_mip")
+    return coarse
+
+
+# --------------------------------------------------------------------------- CSR compaction
+def scan_hits(num_hits, indices=None, total=None, workspace=None):
+    """thrust::reduce + thrust::exclusive_scan (main.cu:631-637); total stays on the device."""
+    n = num_hits.numel()
+    dev = num_hits.device
+    if indices is None:
+        indices = torch.empty(n, dtype=torch.int32, device=dev)
+    if total is None:
+        total = torch.empty(1, dtype=torch.int32, device=dev)
+    need = _lib.lib().rtxn_scan_workspace_bytes(n)
+    if workspace is None:
+        workspace = torch.empty((need + 3) // 4, dtype=torch.int32, device=dev)
+    check(_lib.lib().rtxn_scan_hits(_ptr(num_hits, torch.int32, "num_hits"), _ptr(indices, torch.int32),
+                                    _ptr(total, torch.int32), n, _ptr(workspace), workspace.numel() * 4, _stream()),
+          "rtxn_scan_hits")
+    return indices, total
+
+
+# --------------------------------------------------------------------------- sampler
+def launchSampler(d_start_points, d_end_points, d_view_dirs, d_t_vals, d_sampled_points, batch_size,
+                  grid_res, d_num_hits, d_indices, sample_type=SAMPLING_REGULAR):
+    """sampler/sampler.h:19-30 (the stream argument is torch's current stream)."""
+    check(_lib.lib().rtxn_sample(_ptr(d_start_points, torch.float32, "d_start_points"),
+                                 _ptr(d_end_points, torch.float32, "d_end_points"),
+                                 _ptr(d_view_dirs, torch.float32, "d_view_dirs"),
+                                 _ptr(d_t_vals, torch.float32, "d_t_vals"),
+                                 _ptr(d_sampled_points, torch.float32, "d_sampled_points"),
+                                 batch_size, grid_res, _ptr(d_num_hits, torch.int32, "d_num_hits"),
+                                 _ptr(d_indices, torch.int32, "d_indices"), sample_type, _stream()),
+          "rtxn_sample")
+
+
+# --------------------------------------------------------------------------- volume rendering
+def launch_volrender_cuda(network_inputs, network_outputs, num_hits, indices, ray_hit, batch_size,
+                          num_samples_per_hit, pixels, mode=VR_COMPAT):
+    """vol_render/vol_render.h:5-13."""
+    check(_lib.lib().rtxn_volrender_fwd(_ptr(network_inputs), _ptr(network_outputs, torch.float32, "network_outputs"),
+                                        _ptr(num_hits, torch.int32, "num_hits"), _ptr(indices, torch.int32, "indices"),
+                                        _ptr(ray_hit, torch.float32, "ray_hit"), batch_size, num_samples_per_hit,
+                                        _ptr(pixels, torch.float32, "pixels"), mode, _stream()),
+          "rtxn_volrender_fwd")
+
+
+def launch_volrender_backward_cuda(loss_values, loss_gradients, sampled_points_radiance, t_hit, num_hits,
+                                   indices, batch_size, num_samples_per_hit, radiance_gradients, mode=VR_COMPAT):
+    """vol_render/vol_render.h:15-25."""
+    check(_lib.lib().rtxn_volrender_bwd(_ptr(loss_values), _ptr(loss_gradients, torch.float16, "loss_gradients"),
+                                        _ptr(sampled_points_radiance, torch.float32, "sampled_points_radiance"),
+                                        _ptr(t_hit, torch.float32, "t_hit"), _ptr(num_hits, torch.int32, "num_hits"),
+                                        _ptr(indices, torch.int32, "indices"), batch_size, num_samples_per_hit,
+                                        _ptr(radiance_gradients, torch.float16, "radiance_gradients"), mode, _stream()),
+          "rtxn_volrender_bwd")
+
+
+# --------------------------------------------------------------------------- MLP
+class Network:
+    """tcnn::create_from_config(n_input_dims=5, n_output_dims=4, config) (main.cu:35-69,325)."""
+
+    def __init__(self, n_neurons=128, n_hidden_layers=8, n_pos_freqs=10, n_dir_freqs=12, n_pos_dims=3,
+                 n_dir_dims=2, n_output_dims=4, output_activation=ACT_SIGMOID):
+        self.cfg = MlpConfig(n_pos_dims, n_pos_freqs, n_dir_dims, n_dir_freqs, n_neurons, n_hidden_layers,
+                             n_output_dims, output_activation)
+        h = C.c_void_p()
+        check(_lib.lib().rtxn_mlp_create(C.byref(self.cfg), C.byref(h)), "rtxn_mlp_create")
+        self._h = h
+        self.params = None
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _lib.lib().rtxn_mlp_destroy(h)
+
+    def n_params(self):
+        return int(_lib.lib().rtxn_mlp_n_params(self._h))
+
+    def padded_output_width(self):
+        return int(_lib.lib().rtxn_mlp_padded_output_width(self._h))
+
+    def encoded_width(self):
+        return int(_lib.lib().rtxn_mlp_encoded_width(self._h))
+
+    def flops_per_sample(self):
+        w, p, nh = self.cfg.n_neurons, self.encoded_width(), self.cfg.n_hidden_layers
+        return 2 * (p * w + (nh - 1) * w * w + 16 * w)
+
+    def initialize_params(self, seed=1337):
+        """network->initialize_params(rng, params_full_precision) (main.cu:344-349): host fp32."""
+        out = torch.empty(self.n_params(), dtype=torch.float32)
+        check(_lib.lib().rtxn_mlp_initialize_params(self._h, seed, C.c_void_p(out.data_ptr())),
+              "rtxn_mlp_initialize_params")
+        return out
+
+    def set_params(self, params_fp16):
+        """network->set_params(params, params_inference, gradients) (main.cu:342)."""
+        if params_fp16.numel() != self.n_params():
+            raise _lib.RtxnError(f"params has {params_fp16.numel()} elements, model needs {self.n_params()}")
+        self.params = params_fp16
+        check(_lib.lib().rtxn_mlp_set_params(self._h, _ptr(params_fp16, torch.float16, "params"), _stream()),
+              "rtxn_mlp_set_params")
+
+    def forward(self, input_batch, output=None):
+        """network->forward(stream, input(5xN), &output(16xN)) (main.cu:715-721)."""
+        n = input_batch.numel() // 5
+        if output is None:
+            output = torch.empty((n, 16), dtype=torch.float16, device=input_batch.device)
+        check(_lib.lib().rtxn_mlp_forward(self._h, _ptr(input_batch, torch.float32, "input"), _ptr(output, torch.float16),
+                                          n, _stream()), "rtxn_mlp_forward")
+        return output
+
+    def forward_radiance(self, input_batch, radiance=None):
+        """forward + convertHalfToFloat of rows 0..3 (main.cu:721-728)."""
+        n = input_batch.numel() // 5
+        if radiance is None:
+            radiance = torch.empty((n, 4), dtype=torch.float32, device=input_batch.device)
+        check(_lib.lib().rtxn_mlp_forward_radiance(self._h, _ptr(input_batch, torch.float32, "input"),
+                                                   _ptr(radiance, torch.float32), n, _stream()),
+              "rtxn_mlp_forward_radiance")
+        return radiance
+
+    def forward_segments(self, start_points, end_points, view_dirs, seg_ray, total_segments, max_segments,
+                         radiance, t_vals=None):
+        """launchSampler(REGULAR) + forward + glue fused over packed segments."""
+        check(_lib.lib().rtxn_mlp_forward_segments(
+            self._h, _ptr(start_points, torch.float32, "start_points"), _ptr(end_points, torch.float32, "end_points"),
+            _ptr(view_dirs, torch.float32, "view_dirs"), _ptr(seg_ray, torch.int32, "seg_ray"),
+            _ptr(total_segments, torch.int32, "total_segments"), max_segments, _ptr(radiance, torch.float32, "radiance"),
+            _ptr(t_vals, torch.float32, "t_vals"), _stream()), "rtxn_mlp_forward_segments")
+        return radiance

@@ -1,0 +1,577 @@
+// Frequency encoding + fully-fused MLP forward on MFMA.
+// Replaces the tiny-cuda-nn surface main.cu uses for inference: create_from_config
+// (main.cu:35-69,325), n_params/set_params/initialize_params (:327-349),
+// network->forward (:721) and the convertHalfToFloat glue (:203-208,723-728); the
+// segment variant also folds launchSampler (REGULAR, sampler/sampler.cu:52-66) in.
+// tiny-cuda-nn itself is an un-vendored, unpinned submodule: the numerics below are
+// this build's restatement of its published algorithm (see oracle/rtxn_oracle.c).
+//
+// Design (gfx950, wave64, v_mfma_f32_32x32x16_f16)
+//   * The network is evaluated TRANSPOSED: H_{l+1}^T [W x samples] = W_l [W x K] . H_l^T.
+//     A 32x32 f32 accumulator tile has its column (= sample) on the lane and its rows
+//     (= features) in the 16 registers, which is exactly the B-operand layout of the
+//     next 32x32x16 MFMA once pairs of registers are packed to f16.  Activations
+//     therefore never leave registers between layers: no LDS round trip, no barrier
+//     on the activation path.  The k order this imposes (element j of lane-half h of
+//     k-step s is feature 16s + 8(j>>2) + 4h + (j&3)) is baked into the weight packing.
+//   * Weights are pre-packed (rtxn_mlp_set_params) into 1-KiB "A fragments": chunk
+//     (layer, k-step, row-tile) holds lane l's 8 halves at byte l*16, so the LDS image
+//     is lane-linear: staged with global_load_lds (16 B/lane, no VGPR round trip) and
+//     read back with one conflict-free ds_read_b128 per fragment.
+//   * One layer (<= 32 KiB) is resident per LDS buffer; layer l+1 streams into the other
+//     buffer while layer l computes.  All blocks read the same 0.03-0.3 MB of packed
+//     weights, so the stream is served by L2, not HBM.
+//   * A wave owns 64 samples (two 32-column tiles sharing every A fragment); a 256-thread
+//     block owns 256 samples; two blocks per CU (2 waves/SIMD from different blocks, so
+//     one block's encode/convert VALU phase overlaps the other's MFMA phase).
+//   * First layer: the encoding is computed straight into B fragments.  Lane-half h of
+//     slot p = 8*kstep + j holds feature 2p+h, i.e. h selects sin/cos of one (dim, freq)
+//     pair, so dim and frequency are compile-time per slot.  sin(2^f pi x + h pi/2) =
+//     v_sin_f32(fract(x 2^(f-1)) + h/4): the argument reduction is exact.
+//
+// MFMA-bound: 2*(enc_padded*W + (L-1)*W^2 + 16*W) FLOP per sample (262,144 for the
+// reference's 8x128 model), against 28 B/sample of HBM traffic in radiance mode.
+#include "common.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+struct rtxn_mlp {
+  rtxn_mlp_config cfg;
+  int enc_width;    // 2*(pos_dims*pos_freqs + dir_dims*dir_freqs)
+  int enc_padded;   // multiple of 16, padding features are 1.0
+  int k0;           // first-layer K as staged (multiple of 16 covering all encode slots)
+  long n_params;
+  void* packed;     // device: packed A fragments, all layers
+  size_t packed_bytes;
+  int variant;      // index into the kernel table
+};
+
+namespace {
+
+constexpr int kTileSamples = 256;  // per block per iteration
+constexpr int kThreads = 256;
+
+struct FwdArgs {
+  const uint8_t* packed;
+  int n_hidden;     // hidden layers (>= 1); the first one consumes the encoding
+  int out_act;
+  // IN_MODE 0
+  const float* input;
+  long n;
+  // IN_MODE 1
+  const float* start;
+  const float* end;
+  const float* view_dirs;
+  const int* seg_ray;
+  const int* total_segments;
+  long max_segments;
+  // outputs
+  _Float16* out_half;  // [n][16]
+  float4* radiance;    // [n]
+  float* t_vals;       // [n] or NULL (IN_MODE 1 only)
+};
+
+// ---------------------------------------------------------------------------
+// weight packing
+// ---------------------------------------------------------------------------
+// params (tcnn layout): layer 0 [W][enc_padded], hidden [W][W] x (L-1), out [16][W], row-major fp16.
+// packed: per layer, chunks ordered [kstep][rowtile], each 64 lanes x 8 halves.
+//   layer 0  : element (lane r,h ; kstep kk ; j) = W0[32*rt + r][2*(8kk+j) + h]          (0 if >= enc_padded)
+//   others   : element = Wl[32*rt + r][16kk + 8(j>>2) + 4h + (j&3)]                       (0 if row >= rows)
+__global__ void pack_kernel(const _Float16* __restrict__ params, _Float16* __restrict__ packed, int W, int enc_padded,
+                            int k0, int n_hidden) {
+  const int RT = W / 32;
+  const long l0_elems = (long)(k0 / 16) * RT * 512;
+  const long hid_elems = (long)(W / 16) * RT * 512;
+  const long out_elems = (long)(W / 16) * 512;
+  const long total = l0_elems + (long)(n_hidden - 1) * hid_elems + out_elems;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    long q = e;
+    int layer, rt_count, in_w, rows;
+    long src_base;
+    if (q < l0_elems) {
+      layer = 0; rt_count = RT; in_w = enc_padded; rows = W; src_base = 0;
+    } else {
+      q -= l0_elems;
+      long hl = q / hid_elems;
+      if (hl < n_hidden - 1) {
+        layer = 1 + (int)hl; q -= hl * hid_elems; rt_count = RT; in_w = W; rows = W;
+        src_base = (long)W * enc_padded + hl * (long)W * W;
+      } else {
+        q -= (long)(n_hidden - 1) * hid_elems;
+        layer = n_hidden; rt_count = 1; in_w = W; rows = 16;
+        src_base = (long)W * enc_padded + (long)(n_hidden - 1) * W * W;
+      }
+    }
+    const int j = (int)(q & 7), lane = (int)((q >> 3) & 63);
+    const long chunk = q >> 9;
+    const int rt = (int)(chunk % rt_count), kk = (int)(chunk / rt_count);
+    const int r = lane & 31, h = lane >> 5;
+    const int row = 32 * rt + r;
+    int feat;
+    if (layer == 0) feat = 2 * (8 * kk + j) + h;
+    else feat = 16 * kk + 8 * (j >> 2) + 4 * h + (j & 3);
+    _Float16 v = (_Float16)0.0f;
+    if (row < rows && feat < in_w) v = params[src_base + (long)row * in_w + feat];
+    packed[e] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// forward kernel
+// ---------------------------------------------------------------------------
+template <int BYTES>
+__device__ __forceinline__ void stage(const uint8_t* __restrict__ g, uint8_t* lds_buf, int tid) {
+  static_assert(BYTES % 1024 == 0, "layer bytes must be whole 1-KiB fragments");
+#pragma unroll
+  for (int i = 0; i < BYTES / 4096; ++i) {
+    const uint8_t* src = g + i * 4096 + tid * 16;
+    uint8_t* dst = lds_buf + i * 4096 + (tid & ~63) * 16;  // wave-uniform base; HW adds lane*16
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  }
+  constexpr int TAIL = (BYTES % 4096) / 1024;  // whole fragments left: one wave each
+  if (TAIL > 0 && (tid >> 6) < TAIL) {
+    const int off = (BYTES / 4096) * 4096;
+    const uint8_t* src = g + off + tid * 16;
+    uint8_t* dst = lds_buf + off + (tid & ~63) * 16;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  }
+}
+
+template <int RT, int KS, int NB>
+__device__ __forceinline__ void layer_mma(const uint8_t* lds_buf, const half8 (&bf)[NB][2], floatx16 (&acc)[RT][2],
+                                          int lane) {
+#pragma unroll
+  for (int kk = 0; kk < KS; ++kk) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const half8 a = *reinterpret_cast<const half8*>(lds_buf + ((kk * RT + rt) * 64 + lane) * 16);
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[kk][ct], acc[rt][ct], 0, 0, 0);
+    }
+  }
+}
+
+__device__ __forceinline__ half8 relu_pack(const floatx16& c, int s) {
+  half8 v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (_Float16)fmaxf(c[8 * s + j], 0.0f);
+  return v;
+}
+
+// Encoding slot p (0..): pair (dim, freq) of Composite(Frequency(PD,PF), Frequency(DD,DF)).
+template <int PD, int PF, int DD, int DF>
+struct EncSpec {
+  static constexpr int n_pairs = PD * PF + DD * DF;
+  static constexpr int enc_width = 2 * n_pairs;
+  static constexpr int enc_padded = (enc_width + 15) / 16 * 16;
+  static constexpr int n_slots = enc_padded / 2;           // slots holding real or padding(=1) features
+  static constexpr int k0 = (n_slots + 7) / 8 * 16;        // first-layer K as staged
+};
+
+template <class ES, int PD, int PF, int DD, int DF>
+__device__ __forceinline__ _Float16 encode_slot(int p, const float (&x)[5], float phase) {
+  // p is a compile-time constant after unrolling
+  if (p < PD * PF) {
+    const int dim = p / PF, f = p % PF;
+    const float rev = __builtin_amdgcn_fractf(x[dim] * (float)(1u << f) * 0.5f) + phase;
+    return (_Float16)__builtin_amdgcn_sinf(rev);
+  } else if (p < ES::n_pairs) {
+    const int q = p - PD * PF;
+    const int dim = PD + q / DF, f = q % DF;
+    const float rev = __builtin_amdgcn_fractf(x[dim] * (float)(1u << f) * 0.5f) + phase;
+    return (_Float16)__builtin_amdgcn_sinf(rev);
+  } else if (p < ES::n_slots) {
+    return (_Float16)1.0f;
+  }
+  return (_Float16)0.0f;
+}
+
+template <int W, int PD, int PF, int DD, int DF, int IN_MODE, int OUT_MODE>
+__global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
+  using ES = EncSpec<PD, PF, DD, DF>;
+  constexpr int RT = W / 32, KS = W / 16, KS0 = ES::k0 / 16;
+  constexpr int NB = KS0 > KS ? KS0 : KS;
+  constexpr int L0_BYTES = KS0 * RT * 1024, HID_BYTES = KS * RT * 1024, OUT_BYTES = KS * 1024;
+  constexpr int BUF = L0_BYTES > HID_BYTES ? L0_BYTES : HID_BYTES;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 2 * BUF
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
+  long n_tiles;
+  long total_seg = 0;
+  if (IN_MODE == 1) {
+    total_seg = *a.total_segments;
+    if (total_seg > a.max_segments) total_seg = a.max_segments;
+    n_tiles = (total_seg + 7) / 8;
+  } else {
+    n_tiles = (a.n + kTileSamples - 1) / kTileSamples;
+  }
+  if ((long)blockIdx.x >= n_tiles) return;
+
+  const int n_layers = a.n_hidden + 1;  // hidden layers + output layer
+  // byte offset of layer l in the packed buffer
+  auto layer_off = [&](int l) -> long {
+    if (l == 0) return 0;
+    return (long)L0_BYTES + (long)(l - 1) * HID_BYTES;
+  };
+
+  // prologue: layer 0 of the first tile
+  stage<L0_BYTES>(a.packed, smem, tid);
+  int q = 0;  // global stage counter: buffer = q & 1
+
+  for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // ---- inputs of this wave's two column tiles -> first-layer B fragments ----
+    half8 bf[NB][2];
+    bool valid[2];
+    long samp[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      float x[5];
+      if (IN_MODE == 1) {
+        const long seg = tile * 8 + wave * 2 + ct;
+        valid[ct] = seg < total_seg;
+        samp[ct] = seg * 32 + col;
+        const long sg = valid[ct] ? seg : 0;
+        const int ray = a.seg_ray[sg];
+        const float inc = 1.0f / 32;
+        const float t = (float)col * inc;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float og = a.start[3 * sg + c];
+          x[c] = fmaf(t, a.end[3 * sg + c] - og, og);
+        }
+        x[3] = a.view_dirs[2 * (long)ray];
+        x[4] = a.view_dirs[2 * (long)ray + 1];
+        if (a.t_vals && valid[ct] && h == 0) a.t_vals[samp[ct]] = (float)(col + 1) * inc;
+      } else {
+        samp[ct] = tile * kTileSamples + wave * 64 + ct * 32 + col;
+        valid[ct] = samp[ct] < a.n;
+        const long sidx = valid[ct] ? samp[ct] : 0;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) x[c] = a.input[5 * sidx + c];
+      }
+      const float phase = 0.25f * (float)h;
+#pragma unroll
+      for (int kk = 0; kk < KS0; ++kk) {
+        half8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = encode_slot<ES, PD, PF, DD, DF>(8 * kk + j, x, phase);
+        bf[kk][ct] = v;
+      }
+    }
+
+    // ---- layers ----
+    for (int l = 0; l < n_layers; ++l, ++q) {
+      uint8_t* cur = smem + (q & 1) * BUF;
+      uint8_t* nxt = smem + ((q + 1) & 1) * BUF;
+      __syncthreads();  // stage q landed (compiler drains vmcnt before the barrier); buffer nxt is free
+      // prefetch the next stage
+      if (l + 1 < n_layers) {
+        if (l + 1 == n_layers - 1) stage<OUT_BYTES>(a.packed + layer_off(l + 1), nxt, tid);
+        else stage<HID_BYTES>(a.packed + layer_off(l + 1), nxt, tid);
+      } else if (tile + gridDim.x < n_tiles) {
+        stage<L0_BYTES>(a.packed, nxt, tid);
+      }
+      if (l == 0) {
+        floatx16 acc[RT][2];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[rt][ct][e] = 0.0f;
+        layer_mma<RT, KS0, NB>(cur, bf, acc, lane);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) bf[2 * rt + s][ct] = relu_pack(acc[rt][ct], s);
+      } else if (l < n_layers - 1) {
+        floatx16 acc[RT][2];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[rt][ct][e] = 0.0f;
+        layer_mma<RT, KS, NB>(cur, bf, acc, lane);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) bf[2 * rt + s][ct] = relu_pack(acc[rt][ct], s);
+      } else {
+        floatx16 acc[1][2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[0][ct][e] = 0.0f;
+        layer_mma<1, KS, NB>(cur, bf, acc, lane);
+        // rows 4h..4h+3 are regs 0..3, rows 8+4h..8+4h+3 are regs 4..7 of this lane
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          float y[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float z = acc[0][ct][e];
+            y[e] = a.out_act == RTXN_ACT_SIGMOID ? 1.0f / (1.0f + __expf(-z)) : z;
+          }
+          if (valid[ct]) {
+            if (OUT_MODE == 0) {
+              half4v lo, hi;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { lo[e] = (_Float16)y[e]; hi[e] = (_Float16)y[4 + e]; }
+              _Float16* o = a.out_half + samp[ct] * 16;
+              *reinterpret_cast<half4v*>(o + 4 * h) = lo;
+              *reinterpret_cast<half4v*>(o + 8 + 4 * h) = hi;
+            } else if (h == 0) {
+              // radiance = fp32(fp16(y)): the half output of network->forward, then convertHalfToFloat
+              a.radiance[samp[ct]] = make_float4((float)(_Float16)y[0], (float)(_Float16)y[1],
+                                                 (float)(_Float16)y[2], (float)(_Float16)y[3]);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+typedef void (*fwd_fn)(FwdArgs);
+
+struct Variant {
+  int W, PD, PF, DD, DF;
+  fwd_fn fn[2][2];  // [IN_MODE][OUT_MODE]
+  int k0;
+  size_t lds;
+};
+
+template <int W, int PD, int PF, int DD, int DF>
+Variant make_variant() {
+  using ES = EncSpec<PD, PF, DD, DF>;
+  constexpr int RT = W / 32, KS = W / 16, KS0 = ES::k0 / 16;
+  constexpr int L0 = KS0 * RT * 1024, HID = KS * RT * 1024;
+  Variant v;
+  v.W = W; v.PD = PD; v.PF = PF; v.DD = DD; v.DF = DF;
+  v.fn[0][0] = mlp_fwd_kernel<W, PD, PF, DD, DF, 0, 0>;
+  v.fn[0][1] = mlp_fwd_kernel<W, PD, PF, DD, DF, 0, 1>;
+  v.fn[1][0] = mlp_fwd_kernel<W, PD, PF, DD, DF, 1, 0>;
+  v.fn[1][1] = mlp_fwd_kernel<W, PD, PF, DD, DF, 1, 1>;
+  v.k0 = ES::k0;
+  v.lds = 2 * (size_t)(L0 > HID ? L0 : HID);
+  return v;
+}
+
+const std::vector<Variant>& variants() {
+  static const std::vector<Variant> v = {
+      make_variant<128, 3, 10, 2, 12>(),  // the reference model (main.cu:47-68)
+      make_variant<64, 3, 10, 2, 12>(),   // BASELINE config 1 (2x64)
+      make_variant<128, 3, 10, 2, 4>(),
+      make_variant<64, 3, 10, 2, 4>(),
+  };
+  return v;
+}
+
+// PCG32 (O'Neill), the generator tiny-cuda-nn seeds its initialisers with.
+struct Pcg32 {
+  uint64_t state, inc;
+  explicit Pcg32(uint64_t seed, uint64_t seq = 1) {
+    state = 0u;
+    inc = (seq << 1u) | 1u;
+    next_uint();
+    state += seed;
+    next_uint();
+  }
+  uint32_t next_uint() {
+    uint64_t old = state;
+    state = old * 6364136223846793005ull + inc;
+    uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+    uint32_t rot = (uint32_t)(old >> 59u);
+    return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
+  }
+  float next_float() {
+    union { uint32_t u; float f; } x;
+    x.u = (next_uint() >> 9) | 0x3f800000u;
+    return x.f - 1.0f;
+  }
+};
+
+int launch_fwd(const rtxn_mlp* m, FwdArgs& a, int in_mode, int out_mode, long n_tiles, hipStream_t s) {
+  const Variant& v = variants()[m->variant];
+  a.packed = static_cast<const uint8_t*>(m->packed);
+  a.n_hidden = m->cfg.n_hidden_layers;
+  a.out_act = m->cfg.output_activation;
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    RTXN_HIP(hipGetDevice(&dev));
+    RTXN_HIP(hipGetDeviceProperties(&prop, dev));
+    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  long grid = n_tiles < (long)n_cu * 2 ? n_tiles : (long)n_cu * 2;  // persistent: 2 blocks per CU
+  if (grid < 1) grid = 1;
+  fwd_fn fn = v.fn[in_mode][out_mode];
+  static bool attr_set[16][2][2] = {};
+  if (!attr_set[m->variant][in_mode][out_mode]) {
+    RTXN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)v.lds));
+    attr_set[m->variant][in_mode][out_mode] = true;
+  }
+  hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(kThreads), v.lds, s, a);
+  RTXN_LAUNCH_CHECK("mlp_fwd_kernel");
+  return RTXN_OK;
+}
+
+}  // namespace
+
+extern "C" int rtxn_mlp_create(const rtxn_mlp_config* cfg, rtxn_mlp** out) {
+  RTXN_REQUIRE(cfg && out, "rtxn_mlp_create: NULL argument");
+  RTXN_REQUIRE(cfg->n_hidden_layers >= 1 && cfg->n_hidden_layers <= 64, "rtxn_mlp_create: n_hidden_layers = %d",
+               cfg->n_hidden_layers);
+  RTXN_REQUIRE(cfg->n_output_dims >= 1 && cfg->n_output_dims <= 16, "rtxn_mlp_create: n_output_dims = %d",
+               cfg->n_output_dims);
+  RTXN_REQUIRE(cfg->output_activation == RTXN_ACT_NONE || cfg->output_activation == RTXN_ACT_SIGMOID,
+               "rtxn_mlp_create: unknown output_activation %d", cfg->output_activation);
+  int variant = -1;
+  const auto& vs = variants();
+  for (size_t i = 0; i < vs.size(); ++i)
+    if (vs[i].W == cfg->n_neurons && vs[i].PD == cfg->n_pos_dims && vs[i].PF == cfg->n_pos_freqs &&
+        vs[i].DD == cfg->n_dir_dims && vs[i].DF == cfg->n_dir_freqs)
+      variant = (int)i;
+  if (variant < 0) {
+    rtxn::set_error("rtxn_mlp_create: no kernel for n_neurons=%d enc=(%d x %d, %d x %d); built: 64/128 wide, (3x10, 2x12|2x4)",
+                    cfg->n_neurons, cfg->n_pos_dims, cfg->n_pos_freqs, cfg->n_dir_dims, cfg->n_dir_freqs);
+    return RTXN_ERR_UNSUPPORTED;
+  }
+  rtxn_mlp* m = new rtxn_mlp();
+  m->cfg = *cfg;
+  m->variant = variant;
+  m->enc_width = 2 * (cfg->n_pos_dims * cfg->n_pos_freqs + cfg->n_dir_dims * cfg->n_dir_freqs);
+  m->enc_padded = (m->enc_width + 15) / 16 * 16;
+  m->k0 = vs[variant].k0;
+  const long W = cfg->n_neurons;
+  m->n_params = W * m->enc_padded + (long)(cfg->n_hidden_layers - 1) * W * W + 16 * W;
+  const long RT = W / 32;
+  m->packed_bytes = (size_t)((m->k0 / 16) * RT + (long)(cfg->n_hidden_layers - 1) * (W / 16) * RT + (W / 16)) * 1024;
+  m->packed = nullptr;
+  *out = m;
+  return RTXN_OK;
+}
+
+extern "C" int rtxn_mlp_destroy(rtxn_mlp* m) {
+  if (!m) return RTXN_OK;
+  if (m->packed) (void)hipFree(m->packed);
+  delete m;
+  return RTXN_OK;
+}
+
+extern "C" long rtxn_mlp_n_params(const rtxn_mlp* m) { return m ? m->n_params : -1; }
+extern "C" int rtxn_mlp_padded_output_width(const rtxn_mlp* m) { return m ? 16 : -1; }
+extern "C" int rtxn_mlp_encoded_width(const rtxn_mlp* m) { return m ? m->enc_padded : -1; }
+
+extern "C" int rtxn_mlp_initialize_params(const rtxn_mlp* m, uint64_t seed, float* host_params_fp32) {
+  RTXN_REQUIRE(m && host_params_fp32, "rtxn_mlp_initialize_params: NULL argument");
+  Pcg32 rng(seed);
+  const long W = m->cfg.n_neurons;
+  float* p = host_params_fp32;
+  auto fill = [&](long rows, long cols) {
+    const float scale = std::sqrt(6.0f / (float)(rows + cols));  // Xavier uniform
+    for (long i = 0; i < rows * cols; ++i) *p++ = (rng.next_float() * 2.0f - 1.0f) * scale;
+  };
+  fill(W, m->enc_padded);
+  for (int l = 1; l < m->cfg.n_hidden_layers; ++l) fill(W, W);
+  fill(16, W);
+  return RTXN_OK;
+}
+
+extern "C" int rtxn_mlp_set_params(rtxn_mlp* m, const void* params_fp16, rtxn_stream_t stream) {
+  RTXN_REQUIRE(m && params_fp16, "rtxn_mlp_set_params: NULL argument");
+  RTXN_DEVICE_OR_FAIL();
+  if (!m->packed) RTXN_HIP(hipMalloc(&m->packed, m->packed_bytes));
+  const long total = (long)(m->packed_bytes / 2);
+  const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+  pack_kernel<<<blocks, 256, 0, rtxn::as_stream(stream)>>>(static_cast<const _Float16*>(params_fp16),
+                                                           static_cast<_Float16*>(m->packed), m->cfg.n_neurons,
+                                                           m->enc_padded, m->k0, m->cfg.n_hidden_layers);
+  RTXN_LAUNCH_CHECK("pack_kernel");
+  return RTXN_OK;
+}
+
+static int check_ready(const rtxn_mlp* m, const char* who) {
+  if (!m) { rtxn::set_error("%s: NULL model", who); return RTXN_ERR_INVALID; }
+  if (!m->packed) { rtxn::set_error("%s: rtxn_mlp_set_params has not been called", who); return RTXN_ERR_INVALID; }
+  return RTXN_OK;
+}
+
+extern "C" int rtxn_mlp_forward(const rtxn_mlp* m, const float* input, void* output_half, long n,
+                                rtxn_stream_t stream) {
+  int rc = check_ready(m, "rtxn_mlp_forward");
+  if (rc != RTXN_OK) return rc;
+  RTXN_REQUIRE(n >= 0, "rtxn_mlp_forward: n = %ld < 0", n);
+  RTXN_DEVICE_OR_FAIL();
+  if (n == 0) return RTXN_OK;
+  RTXN_REQUIRE(input && output_half, "rtxn_mlp_forward: NULL buffer");
+  RTXN_REQUIRE(((uintptr_t)output_half & 7) == 0, "rtxn_mlp_forward: output must be 8-byte aligned");
+  FwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.input = input;
+  a.n = n;
+  a.out_half = static_cast<_Float16*>(output_half);
+  return launch_fwd(m, a, 0, 0, (n + kTileSamples - 1) / kTileSamples, rtxn::as_stream(stream));
+}
+
+extern "C" int rtxn_mlp_forward_radiance(const rtxn_mlp* m, const float* input, float* radiance, long n,
+                                         rtxn_stream_t stream) {
+  int rc = check_ready(m, "rtxn_mlp_forward_radiance");
+  if (rc != RTXN_OK) return rc;
+  RTXN_REQUIRE(n >= 0, "rtxn_mlp_forward_radiance: n = %ld < 0", n);
+  RTXN_DEVICE_OR_FAIL();
+  if (n == 0) return RTXN_OK;
+  RTXN_REQUIRE(input && radiance, "rtxn_mlp_forward_radiance: NULL buffer");
+  RTXN_REQUIRE(((uintptr_t)radiance & 15) == 0, "rtxn_mlp_forward_radiance: radiance must be 16-byte aligned");
+  FwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.input = input;
+  a.n = n;
+  a.radiance = reinterpret_cast<float4*>(radiance);
+  return launch_fwd(m, a, 0, 1, (n + kTileSamples - 1) / kTileSamples, rtxn::as_stream(stream));
+}
+
+extern "C" int rtxn_mlp_forward_segments(const rtxn_mlp* m, const float* start_points, const float* end_points,
+                                         const float* view_dirs, const int* seg_ray, const int* total_segments,
+                                         long max_segments, float* radiance, float* t_vals, rtxn_stream_t stream) {
+  int rc = check_ready(m, "rtxn_mlp_forward_segments");
+  if (rc != RTXN_OK) return rc;
+  RTXN_REQUIRE(max_segments >= 0, "rtxn_mlp_forward_segments: max_segments = %ld < 0", max_segments);
+  RTXN_DEVICE_OR_FAIL();
+  if (max_segments == 0) return RTXN_OK;
+  RTXN_REQUIRE(start_points && end_points && view_dirs && seg_ray && total_segments && radiance,
+               "rtxn_mlp_forward_segments: NULL buffer");
+  RTXN_REQUIRE(((uintptr_t)radiance & 15) == 0, "rtxn_mlp_forward_segments: radiance must be 16-byte aligned");
+  FwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.start = start_points;
+  a.end = end_points;
+  a.view_dirs = view_dirs;
+  a.seg_ray = seg_ray;
+  a.total_segments = total_segments;
+  a.max_segments = max_segments;
+  a.radiance = reinterpret_cast<float4*>(radiance);
+  a.t_vals = t_vals;
+  return launch_fwd(m, a, 1, 1, (max_segments + 7) / 8, rtxn::as_stream(stream));
+}

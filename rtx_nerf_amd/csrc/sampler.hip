@@ -1,0 +1,130 @@
+// Per-segment sampler.  Replaces generate_samples / launchSampler
+// (reference sampler/sampler.cu:14-131).
+//
+// The reference runs one thread per ray and writes each 20-byte sample with
+// five strided stores.  Here one 64-lane wavefront owns a ray and emits two
+// segments (64 samples = 320 contiguous floats) per step: lane l writes flat
+// floats l, l+64, ..., l+256 of that 1280-byte run, so every store instruction
+// covers 256 contiguous bytes.  HBM-bound: 792 B per segment algorithmic
+// (24 B read, 640 B samples + 128 B t_vals written).
+//
+// Arithmetic follows the restatement in oracle/rtxn_oracle.c bit for bit
+// (explicit fmaf where nvcc's default -fmad contracts; file built with
+// -ffp-contract=off).
+#include "common.h"
+
+namespace {
+
+constexpr int K = RTXN_NUM_SAMPLES_PER_SEGMENT;
+
+// thrust::minstd_rand: x <- 48271 x mod (2^31-1), default seed 1; the reference
+// passes the engine by value (sampler.cu:25,117) so every ray replays the same
+// stream, draw number (segment*32 + i + 1) belonging to sample (segment, i).
+__device__ __forceinline__ uint32_t mulmod(uint32_t a, uint32_t b) {
+  return (uint32_t)(((uint64_t)a * b) % 2147483647ull);
+}
+__device__ __forceinline__ uint32_t minstd_pow(uint32_t n) {  // 48271^n mod m
+  uint32_t r = 1, b = 48271u;
+  while (n) {
+    if (n & 1u) r = mulmod(r, b);
+    b = mulmod(b, b);
+    n >>= 1;
+  }
+  return r;
+}
+__device__ __forceinline__ float thrust_uniform(uint32_t x, float a, float b) {
+  float r = (float)(x - 1u);
+  r /= (1.0f + (float)2147483645u);
+  return fmaf(r, b - a, a);
+}
+
+template <int TYPE>
+__global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ start_points,
+                                                     const float* __restrict__ end_points,
+                                                     const float* __restrict__ view_dirs,
+                                                     float* __restrict__ t_vals, float* __restrict__ samples,
+                                                     int batch_size, const int* __restrict__ num_hits,
+                                                     const int* __restrict__ indices) {
+  const int lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= batch_size) return;  // reference reads indices[x] before its guard (sampler.cu:32-37); we do not
+  const int start_index = indices[ray];
+  const int n_hits = num_hits[ray];
+  const float theta = view_dirs[2 * ray], phi = view_dirs[2 * ray + 1];
+  const float inc = 1.0f / K;
+  const int i = lane & (K - 1);  // sample within segment
+  for (int j0 = 0; j0 < n_hits; j0 += 2) {
+    const int nseg = min(2, n_hits - j0);
+    const long seg0 = (long)start_index + j0;
+    // this lane's own sample: (segment j0 + lane/32, i)
+    float t, tv;
+    if (TYPE == RTXN_SAMPLING_REGULAR) {
+      t = (float)i * inc;  // i repeated additions of 2^-5 are exact
+      tv = (float)(i + 1) * inc;
+    } else {
+      uint32_t draw = (uint32_t)(j0 + (lane >> 5)) * K + i + 1;
+      uint32_t x = minstd_pow(draw);  // seed 1
+      if (TYPE == RTXN_SAMPLING_UNIFORM) {
+        t = thrust_uniform(x, 0.0f, 1.0f);
+        tv = 0.0f;
+      } else {
+        float ti = (float)i * inc, tf = (float)(i + 1) * inc;
+        t = thrust_uniform(x, ti, tf);
+        tv = ti;
+      }
+    }
+    if ((lane >> 5) < nseg) t_vals[(seg0 + (lane >> 5)) * K + i] = tv;
+    float* out = samples + seg0 * (K * 5);
+    const int nflat = nseg * K * 5;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int f = lane + 64 * k;  // flat float within the 2-segment run
+      const int s = f / 5, comp = f - s * 5;
+      const float ts = __shfl(t, s, 64);
+      if (f < nflat) {
+        float val;
+        if (comp < 3) {
+          const long g = (seg0 + (s >> 5)) * 3 + comp;
+          const float og = start_points[g];
+          const float dir = end_points[g] - og;
+          val = fmaf(ts, dir, og);
+        } else {
+          val = comp == 3 ? theta : phi;
+        }
+        out[f] = val;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int rtxn_sample(const float* start_points, const float* end_points, const float* view_dirs,
+                           float* t_vals, float* sampled_points, int batch_size, int grid_res,
+                           const int* num_hits, const int* indices, int sample_type, rtxn_stream_t stream) {
+  (void)grid_res;
+  RTXN_REQUIRE(batch_size >= 0, "rtxn_sample: batch_size = %d < 0", batch_size);
+  RTXN_REQUIRE(sample_type >= 0 && sample_type <= 2, "rtxn_sample: unknown sample_type %d", sample_type);
+  RTXN_DEVICE_OR_FAIL();
+  if (batch_size == 0) return RTXN_OK;
+  RTXN_REQUIRE(start_points && end_points && view_dirs && t_vals && sampled_points && num_hits && indices,
+               "rtxn_sample: NULL buffer");
+  hipStream_t s = rtxn::as_stream(stream);
+  dim3 grid((batch_size + 3) / 4), block(256);
+  switch (sample_type) {
+    case RTXN_SAMPLING_REGULAR:
+      sample_kernel<RTXN_SAMPLING_REGULAR><<<grid, block, 0, s>>>(start_points, end_points, view_dirs, t_vals,
+                                                                   sampled_points, batch_size, num_hits, indices);
+      break;
+    case RTXN_SAMPLING_STRATIFIED_JITTERING:
+      sample_kernel<RTXN_SAMPLING_STRATIFIED_JITTERING><<<grid, block, 0, s>>>(
+          start_points, end_points, view_dirs, t_vals, sampled_points, batch_size, num_hits, indices);
+      break;
+    default:
+      sample_kernel<RTXN_SAMPLING_UNIFORM><<<grid, block, 0, s>>>(start_points, end_points, view_dirs, t_vals,
+                                                                   sampled_points, batch_size, num_hits, indices);
+      break;
+  }
+  RTXN_LAUNCH_CHECK("sample_kernel");
+  return RTXN_OK;
+}

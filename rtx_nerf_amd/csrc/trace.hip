@@ -1,0 +1,342 @@
+// Ray generation + ray/grid traversal.  Replaces the OptiX pipeline of the
+// reference: __raygen__/__intersection__/__closesthit__/__miss__ray_march
+// (rtx/src/optixPrograms.cu:43-248), the AABB grid + GAS build
+// (main.cu:154-174, rtx/src/rtxFunctions.cpp:293-351) and optixLaunch
+// (main.cu:506-508).
+//
+// OptiX finds "the closest AABB" with a full BVH traversal per crossed cell.
+// The primitives are the cells of a uniform grid, so the same ordered list of
+// (entry, exit) points falls out of an analytic walk, one thread per ray:
+//   RTXN_TRACE_COMPAT  the reference's arithmetic: slab test and exit planes
+//                      from the re-launched origin, next origin = exit point;
+//   RTXN_TRACE_DDA     global-t 3D-DDA whose plane crossings are pure
+//                      functions of the integer cell index, so a two-level
+//                      walk over a coarse occupancy mip (staged in LDS) skips
+//                      empty 4^3 blocks and still reproduces the flat walk
+//                      bit for bit.
+// Both follow oracle/rtxn_oracle.c operation for operation (explicit fmaf,
+// -ffp-contract=off, IEEE division) so segment end points match bit-exactly;
+// only atan2f (theta, phi) differs between libm and the device library.
+//
+// HBM-bound on its outputs: 24 B/ray (origin 12 + direction 8 + count 4) and
+// 28 B/segment in packed mode (start 12 + end 12 + seg_ray 4; t_start/t_end,
+// which nothing downstream reads, optional +8).  The occupancy bitfield
+// (R^3/8 bytes: 256 KiB at 128^3, 2 MiB at 256^3) is L2-resident.
+#include "common.h"
+
+namespace {
+
+struct Sink {
+  float* start;
+  float* end;
+  float* t0;
+  float* t1;
+  int* seg_ray;
+  long base;
+  long limit;  // first slot this ray may not write
+  int ray;
+  int n;
+  __device__ __forceinline__ void emit(const float (&p0)[3], const float (&p1)[3], float a, float b) {
+    const long k = base + n;
+    if (k < limit) {
+      if (start) { start[3 * k] = p0[0]; start[3 * k + 1] = p0[1]; start[3 * k + 2] = p0[2]; }
+      if (end) { end[3 * k] = p1[0]; end[3 * k + 1] = p1[1]; end[3 * k + 2] = p1[2]; }
+      if (t0) t0[k] = a;
+      if (t1) t1[k] = b;
+      if (seg_ray) seg_ray[k] = ray;
+    }
+    ++n;
+  }
+};
+
+__device__ __forceinline__ float cell_lo(int i, float L) { return -1.0f + (float)i * L; }
+__device__ __forceinline__ float cell_hi(int i, float L) { return -1.0f + (float)i * L + L; }
+
+__device__ __forceinline__ bool occ_test(const uint32_t* __restrict__ occ, int R, int x, int y, int z) {
+  if (!occ) return true;
+  const uint32_t idx = ((uint32_t)x * (uint32_t)R + (uint32_t)y) * (uint32_t)R + (uint32_t)z;
+  return (occ[idx >> 5] >> (idx & 31)) & 1u;
+}
+
+// a2: optixPrograms.cu:43-82
+__device__ __forceinline__ void make_ray(const float* __restrict__ la, float focal_length, float aspect_ratio,
+                                         unsigned width, unsigned height, unsigned px, unsigned py, float (&o)[3],
+                                         float (&d)[3], float (&v)[2]) {
+  const float u = (float)((2 * (px + 0.5) / width - 1) * aspect_ratio);
+  const float vv = (float)(2 * (py + 0.5) / height - 1);
+  const float nf0 = la[2] * -1.0f, nf1 = la[6] * -1.0f, nf2 = la[10] * -1.0f;
+  float xd = fmaf(nf0, focal_length, fmaf(la[0], u, la[1] * vv));
+  float yd = fmaf(nf1, focal_length, fmaf(la[4], u, la[5] * vv));
+  float zd = fmaf(nf2, focal_length, fmaf(la[8], u, la[9] * vv));
+  const float norm = sqrtf(fmaf(zd, zd, fmaf(xd, xd, yd * yd)));
+  xd /= norm;
+  yd /= norm;
+  zd /= norm;
+  v[0] = atan2f(sqrtf(fmaf(xd, xd, yd * yd)), zd);
+  v[1] = atan2f(yd, xd);
+  d[0] = xd; d[1] = yd; d[2] = zd;
+  o[0] = la[3] / 10;
+  o[1] = la[7] / 10;
+  o[2] = la[11] / 10;
+}
+
+__device__ __forceinline__ bool grid_entry(const float (&o)[3], const float (&d)[3], int R, float L, int (&cell)[3],
+                                           float& t_enter) {
+  bool inside = true;
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+    if (!(o[a] >= -1.0f && o[a] <= 1.0f)) inside = false;
+  float t0 = 0.0f;
+  int enter_axis = -1;
+  if (!inside) {
+    float tmin = -INFINITY, tmax = INFINITY;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float t1 = (-1.0f - o[a]) / d[a];
+      const float t2 = (1.0f - o[a]) / d[a];
+      const float tn = fminf(t1, t2), tf = fmaxf(t1, t2);
+      if (tn > tmin) { tmin = tn; enter_axis = a; }
+      tmax = fminf(tmax, tf);
+    }
+    if (!(tmax > tmin) || tmin < 0.0f) return false;
+    t0 = tmin;
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float p = fmaf(t0, d[a], o[a]);
+    const int c = (int)floorf((p + 1.0f) / L);
+    cell[a] = min(max(c, 0), R - 1);
+    if (a == enter_axis) cell[a] = d[a] > 0 ? 0 : R - 1;
+  }
+  t_enter = t0;
+  return true;
+}
+
+// a3-a5 restated as a cell walk (see oracle march_compat for the derivation).
+__device__ void march_compat(const float (&o0)[3], const float (&d)[3], int R, const uint32_t* __restrict__ occ,
+                             Sink& s) {
+  const float L = 2.0f / (float)R;
+  int c[3];
+  float tE;
+  if (!grid_entry(o0, d, R, L, c, tE)) return;
+  float o[3] = {o0[0], o0[1], o0[2]};
+  for (int guard = 0; guard < 3 * R + 8; ++guard) {
+    float lo[3], hi[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { lo[a] = cell_lo(c[a], L); hi[a] = cell_hi(c[a], L); }
+    // __intersection__ray_march: optixPrograms.cu:132-169
+    float tmin = -INFINITY, tmax = INFINITY;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float t1 = (lo[a] - o[a]) / d[a];
+      const float t2 = (hi[a] - o[a]) / d[a];
+      tmin = fmaxf(tmin, fminf(t1, t2));
+      tmax = fminf(tmax, fmaxf(t1, t2));
+    }
+    const bool rep = tmax > tmin;
+    if (rep && tmin < 0 && (double)tmax > 1e-6) tmin = 0;
+    const float t_hit = tmin;
+    // __closesthit__ray_march: optixPrograms.cu:180-248
+    float te[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float plane = d[a] < 0 ? lo[a] : hi[a];
+      te[a] = (plane - o[a]) / d[a];
+    }
+    const float t_e = fminf(fminf(te[0], te[1]), te[2]);
+    float p0[3], p1[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { p0[a] = fmaf(t_hit, d[a], o[a]); p1[a] = fmaf(t_e, d[a], o[a]); }
+    if (rep && t_hit >= 0.0f && occ_test(occ, R, c[0], c[1], c[2])) s.emit(p0, p1, t_hit, t_e);
+    bool out = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      if (te[a] == t_e) {
+        c[a] += d[a] < 0 ? -1 : 1;
+        if (c[a] < 0 || c[a] >= R) out = true;
+      }
+    }
+    if (out) break;
+    o[0] = p1[0]; o[1] = p1[1]; o[2] = p1[2];
+  }
+}
+
+__device__ __forceinline__ float plane_t(int i, float L, float o, float inv) { return (cell_lo(i, L) - o) * inv; }
+
+// Global-t DDA.  `coarse` (LDS or global, may be NULL): bit ((X*Rc+Y)*Rc+Z) of the
+// (R/4)^3 mip.  An empty coarse block is crossed in one step: every axis advances
+// while its exit plane's t is <= the block's exit t, which is exactly the state
+// the flat walk reaches (plane_t depends only on the cell index).
+__device__ void march_dda(const float (&o)[3], const float (&d)[3], int R, const uint32_t* __restrict__ occ,
+                          const uint32_t* coarse, Sink& s) {
+  const float L = 2.0f / (float)R;
+  int c[3];
+  float t_in;
+  if (!grid_entry(o, d, R, L, c, t_in)) return;
+  float inv[3];
+  int step[3], up[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    inv[a] = 1.0f / d[a];
+    step[a] = d[a] < 0 ? -1 : 1;
+    up[a] = d[a] < 0 ? 0 : 1;
+  }
+  const int Rc = R >> 2;
+  for (int guard = 0; guard < 3 * R + 8; ++guard) {
+    bool out = false;
+    if (coarse) {
+      const uint32_t ci = ((uint32_t)(c[0] >> 2) * Rc + (uint32_t)(c[1] >> 2)) * Rc + (uint32_t)(c[2] >> 2);
+      if (!((coarse[ci >> 5] >> (ci & 31)) & 1u)) {
+        float tc = INFINITY;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          if (d[a] != 0.0f) tc = fminf(tc, plane_t(((c[a] >> 2) + up[a]) << 2, L, o[a], inv[a]));
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          if (d[a] != 0.0f) {
+            while (plane_t(c[a] + up[a], L, o[a], inv[a]) <= tc) {
+              c[a] += step[a];
+              if (c[a] < 0 || c[a] >= R) { out = true; break; }
+            }
+          }
+        }
+        if (out) break;
+        if (tc > t_in) t_in = tc;
+        continue;
+      }
+    }
+    float te[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) te[a] = d[a] == 0.0f ? INFINITY : plane_t(c[a] + up[a], L, o[a], inv[a]);
+    const float t_out = fminf(fminf(te[0], te[1]), te[2]);
+    if (t_out > t_in && occ_test(occ, R, c[0], c[1], c[2])) {
+      float p0[3], p1[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { p0[a] = fmaf(t_in, d[a], o[a]); p1[a] = fmaf(t_out, d[a], o[a]); }
+      s.emit(p0, p1, t_in, t_out);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      if (te[a] == t_out) {
+        c[a] += step[a];
+        if (c[a] < 0 || c[a] >= R) out = true;
+      }
+    }
+    if (out) break;
+    if (t_out > t_in) t_in = t_out;
+  }
+}
+
+constexpr int kCoarseLdsWords = 8192;  // 32 KiB: coarse mip of up to 256^3 (64^3 bits)
+
+template <int MODE>
+__global__ __launch_bounds__(256) void trace_kernel(rtxn_trace_params p) {
+  __shared__ uint32_t coarse_lds[MODE == RTXN_TRACE_DDA ? kCoarseLdsWords : 1];
+  const uint32_t* coarse = nullptr;
+  if (MODE == RTXN_TRACE_DDA && p.occupancy_coarse) {
+    const int Rc = p.grid_res >> 2;
+    const int words = (Rc * Rc * Rc + 31) >> 5;
+    if (words <= kCoarseLdsWords) {
+      for (int i = threadIdx.x; i < words; i += blockDim.x) coarse_lds[i] = p.occupancy_coarse[i];
+      __syncthreads();
+      coarse = coarse_lds;
+    } else {
+      coarse = p.occupancy_coarse;
+    }
+  }
+  // 16x16 pixel tiles per block keep a block's rays on neighbouring cells (shared
+  // occupancy words); a ray window that is not tile-aligned falls back to linear order.
+  const unsigned r = blockIdx.x * 256u + threadIdx.x;
+  if (r >= p.ray_count) return;
+  const unsigned gid = p.window_chunk ? p.ray_begin + (r / p.window_chunk) * p.window_stride + (r % p.window_chunk)
+                                      : p.ray_begin + r;
+  float o[3], d[3], v[2];
+  if (p.look_at) {
+    make_ray(p.look_at, p.focal_length, p.aspect_ratio, p.width, p.height, gid % p.width, gid / p.width, o, d, v);
+  } else {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { o[a] = p.rays_o[3 * (size_t)gid + a]; d[a] = p.rays_d[3 * (size_t)gid + a]; }
+    v[0] = atan2f(sqrtf(fmaf(d[0], d[0], d[1] * d[1])), d[2]);
+    v[1] = atan2f(d[1], d[0]);
+  }
+  if (p.ray_origins) { p.ray_origins[3 * (size_t)r] = o[0]; p.ray_origins[3 * (size_t)r + 1] = o[1]; p.ray_origins[3 * (size_t)r + 2] = o[2]; }
+  if (p.viewing_direction) { p.viewing_direction[2 * (size_t)r] = v[0]; p.viewing_direction[2 * (size_t)r + 1] = v[1]; }
+  Sink s;
+  s.start = p.start_points; s.end = p.end_points; s.t0 = p.t_start; s.t1 = p.t_end; s.seg_ray = p.seg_ray;
+  s.ray = (int)r; s.n = 0;
+  if (p.indices) { s.base = p.indices[r]; s.limit = p.segment_capacity > 0 ? p.segment_capacity : 0x7fffffffffffffffL; }
+  else { s.base = (long)r * p.intersection_arr_size; s.limit = s.base + p.intersection_arr_size; }
+  if (!p.start_points && !p.end_points && !p.t_start && !p.t_end && !p.seg_ray) s.limit = 0;
+  if (MODE == RTXN_TRACE_COMPAT) march_compat(o, d, p.grid_res, p.occupancy, s);
+  else march_dda(o, d, p.grid_res, p.occupancy, coarse, s);
+  p.num_hits[r] = s.n;
+}
+
+// one thread per coarse WORD (32 coarse cells), deterministic, no pre-zeroing
+__global__ void mip_kernel(const uint32_t* __restrict__ occ, int R, uint32_t* __restrict__ coarse) {
+  const int Rc = R >> 2;
+  const int ncell = Rc * Rc * Rc;
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w * 32 >= ncell) return;
+  uint32_t word = 0;
+  for (int b = 0; b < 32; ++b) {
+    const int ci = w * 32 + b;
+    if (ci >= ncell) break;
+    const int Z = ci % Rc, Y = (ci / Rc) % Rc, X = ci / (Rc * Rc);
+    uint32_t any = 0;
+    for (int dx = 0; dx < 4; ++dx)
+      for (int dy = 0; dy < 4; ++dy) {
+        // the 4 z-cells of this row are 4 consecutive bits inside one word (R % 4 == 0)
+        const uint32_t idx = ((uint32_t)(4 * X + dx) * R + (uint32_t)(4 * Y + dy)) * R + (uint32_t)(4 * Z);
+        any |= (occ[idx >> 5] >> (idx & 31)) & 0xfu;
+      }
+    if (any) word |= 1u << b;
+  }
+  coarse[w] = word;
+}
+
+}  // namespace
+
+extern "C" int rtxn_trace_grid(const rtxn_trace_params* p, rtxn_stream_t stream) {
+  RTXN_REQUIRE(p != nullptr, "rtxn_trace_grid: params is NULL");
+  RTXN_REQUIRE(p->grid_res >= 1 && p->grid_res <= 1024, "rtxn_trace_grid: grid_res = %d out of [1,1024]", p->grid_res);
+  RTXN_REQUIRE(p->mode == RTXN_TRACE_COMPAT || p->mode == RTXN_TRACE_DDA, "rtxn_trace_grid: unknown mode %d", p->mode);
+  RTXN_REQUIRE(p->look_at || (p->rays_o && p->rays_d), "rtxn_trace_grid: neither look_at nor rays_o/rays_d given");
+  {
+    uint64_t last = p->ray_count ? (uint64_t)p->ray_count - 1 : 0;
+    if (p->window_chunk) last = (last / p->window_chunk) * (uint64_t)p->window_stride + last % p->window_chunk;
+    RTXN_REQUIRE(p->ray_count == 0 || (uint64_t)p->ray_begin + last < (uint64_t)p->width * p->height,
+                 "rtxn_trace_grid: ray window [%u,+%u) (chunk %u stride %u) exceeds the %ux%u launch", p->ray_begin,
+                 p->ray_count, p->window_chunk, p->window_stride, p->width, p->height);
+    RTXN_REQUIRE(!p->window_chunk || p->window_stride >= p->window_chunk,
+                 "rtxn_trace_grid: window_stride %u < window_chunk %u", p->window_stride, p->window_chunk);
+  }
+  RTXN_REQUIRE(!p->occupancy_coarse || (p->occupancy && p->grid_res % 4 == 0),
+               "rtxn_trace_grid: occupancy_coarse needs occupancy and grid_res %% 4 == 0");
+  const bool wants_segments = p->start_points || p->end_points || p->t_start || p->t_end || p->seg_ray;
+  RTXN_REQUIRE(!wants_segments || p->indices || p->intersection_arr_size > 0,
+               "rtxn_trace_grid: segment outputs need indices (packed) or intersection_arr_size > 0 (strided)");
+  RTXN_DEVICE_OR_FAIL();
+  if (p->ray_count == 0) return RTXN_OK;
+  RTXN_REQUIRE(p->num_hits != nullptr, "rtxn_trace_grid: num_hits is NULL");
+  hipStream_t s = rtxn::as_stream(stream);
+  dim3 grid((p->ray_count + 255) / 256), block(256);
+  if (p->mode == RTXN_TRACE_COMPAT) trace_kernel<RTXN_TRACE_COMPAT><<<grid, block, 0, s>>>(*p);
+  else trace_kernel<RTXN_TRACE_DDA><<<grid, block, 0, s>>>(*p);
+  RTXN_LAUNCH_CHECK("trace_kernel");
+  return RTXN_OK;
+}
+
+extern "C" int rtxn_build_occupancy_mip(const uint32_t* occupancy, int grid_res, uint32_t* coarse,
+                                        rtxn_stream_t stream) {
+  RTXN_REQUIRE(occupancy && coarse, "rtxn_build_occupancy_mip: NULL buffer");
+  RTXN_REQUIRE(grid_res >= 4 && grid_res % 4 == 0 && grid_res <= 1024,
+               "rtxn_build_occupancy_mip: grid_res = %d must be a multiple of 4 in [4,1024]", grid_res);
+  RTXN_DEVICE_OR_FAIL();
+  const int Rc = grid_res / 4;
+  const int words = (Rc * Rc * Rc + 31) / 32;
+  mip_kernel<<<(words + 255) / 256, 256, 0, rtxn::as_stream(stream)>>>(occupancy, grid_res, coarse);
+  RTXN_LAUNCH_CHECK("mip_kernel");
+  return RTXN_OK;
+}

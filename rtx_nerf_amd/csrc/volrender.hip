@@ -1,0 +1,268 @@
+// Alpha-compositing volume renderer, forward and backward.
+// Replaces volrender_cuda / volrender_backward_cuda and their launchers
+// (reference vol_render/vol_render.cu:19-190).
+//
+// The reference walks a ray's samples serially in one thread.  Here one
+// 64-lane wavefront owns a ray and consumes 64 consecutive samples per step
+// (a ray's samples are contiguous: [indices[r]*K, (indices[r]+num_hits[r])*K)):
+// coalesced 16-B radiance loads (1 KiB per wave instruction), the optical depth
+// running sum as a wavefront-wide inclusive prefix scan carried across steps,
+// and a final cross-lane reduction of the weighted colour.
+//
+// HBM-bound.  Algorithmic bytes: forward 20 B/sample (16 radiance + 4 t) + 20
+// B/ray; backward 20 B/sample read + 8 B/sample written + 14 B/ray.
+//
+// RTXN_VR_COMPAT reproduces the reference arithmetic:
+//   delta_i = |t_i - t_{i-1}|, t_{-1} = 0, NOT reset at segment boundaries;
+//   T_i = sum_{k<=i} delta_k sigma_k (inclusive); w_i = exp(-T_i)(1-exp(-delta_i sigma_i)).
+// The scan sums in a different order than the reference's serial loop, hence
+// the 1e-5 absolute tolerance on pixels stated in tests/.
+// RTXN_VR_NERF is the canonical quadrature (exclusive transmittance, ray_hit
+// holds each sample's world-space step length) with its exact gradient.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_incl_scan_f(float v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    float t = __shfl_up(v, d, 64);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void volrender_fwd_kernel(const float4* __restrict__ radiance,
+                                                            const int* __restrict__ num_hits,
+                                                            const int* __restrict__ indices,
+                                                            const float* __restrict__ ray_hit, int batch_size, int K,
+                                                            float* __restrict__ pixels) {
+  const int lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= batch_size) return;
+  const long base = (long)indices[ray] * K;
+  const long n = (long)num_hits[ray] * K;
+  float T_carry = 0.0f, t_carry = 0.0f;
+  float ar = 0.0f, ag = 0.0f, ab = 0.0f;
+  for (long s0 = 0; s0 < n; s0 += 64) {
+    const bool act = s0 + lane < n;
+    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+    float t = 0.0f;
+    if (act) {
+      c = radiance[base + s0 + lane];
+      t = ray_hit[base + s0 + lane];
+    }
+    float x, w;
+    if (MODE == RTXN_VR_COMPAT) {
+      float tp = __shfl_up(t, 1, 64);
+      if (lane == 0) tp = t_carry;
+      const float delta = fabsf(t - tp);
+      x = act ? delta * c.w : 0.0f;
+      const float T = T_carry + wave_incl_scan_f(x, lane);
+      w = act ? expf(-T) * (1.0f - expf(-x)) : 0.0f;
+      T_carry = __shfl(T, 63, 64);
+      // last ACTIVE lane's t carries over; inactive lanes only occur in the final step
+      t_carry = __shfl(t, 63, 64);
+    } else {
+      x = act ? t * c.w : 0.0f;  // ray_hit = step length
+      const float incl = wave_incl_scan_f(x, lane);
+      const float T_excl = T_carry + incl - x;
+      w = act ? expf(-T_excl) * (1.0f - expf(-x)) : 0.0f;
+      T_carry += __shfl(incl, 63, 64);
+    }
+    ar = fmaf(w, c.x, ar);
+    ag = fmaf(w, c.y, ag);
+    ab = fmaf(w, c.z, ab);
+  }
+  ar = wave_sum(ar);
+  ag = wave_sum(ag);
+  ab = wave_sum(ab);
+  if (lane == 0) {
+    pixels[3 * (long)ray] = ar;
+    pixels[3 * (long)ray + 1] = ag;
+    pixels[3 * (long)ray + 2] = ab;
+  }
+}
+
+struct alignas(8) half4 {
+  __half x, y, z, w;
+};
+
+// COMPAT backward: per-sample, reference vol_render.cu:75-143 (not the analytic
+// gradient of the forward).
+__global__ __launch_bounds__(256) void volrender_bwd_compat_kernel(const __half* __restrict__ loss_gradients,
+                                                                   const float4* __restrict__ radiance,
+                                                                   const float* __restrict__ t_hit,
+                                                                   const int* __restrict__ num_hits,
+                                                                   const int* __restrict__ indices, int batch_size,
+                                                                   int K, half4* __restrict__ grads) {
+  const int lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= batch_size) return;
+  const long base = (long)indices[ray] * K;
+  const long n = (long)num_hits[ray] * K;
+  const float g0 = __half2float(loss_gradients[3 * (long)ray]);
+  const float g1 = __half2float(loss_gradients[3 * (long)ray + 1]);
+  const float g2 = __half2float(loss_gradients[3 * (long)ray + 2]);
+  float t_carry = 0.0f;
+  for (long s0 = 0; s0 < n; s0 += 64) {
+    const bool act = s0 + lane < n;
+    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+    float t = 0.0f;
+    if (act) {
+      c = radiance[base + s0 + lane];
+      t = t_hit[base + s0 + lane];
+    }
+    float tp = __shfl_up(t, 1, 64);
+    if (lane == 0) tp = t_carry;
+    t_carry = __shfl(t, 63, 64);
+    if (act) {
+      const float delta = fabsf(t - tp);
+      const float sigma = c.w;
+      const float tr = delta * sigma;
+      const float e = expf(-sigma * delta);
+      float dg = 0.0f;
+      dg += g0 * tr * c.x * delta * e;
+      dg += g1 * tr * c.y * delta * e;
+      dg += g2 * tr * c.z * delta * e;
+      const float om = 1.0f - expf(-delta * sigma);
+      half4 o;
+      o.x = __float2half(g0 * tr * om);
+      o.y = __float2half(g1 * tr * om);
+      o.z = __float2half(g2 * tr * om);
+      o.w = __float2half(dg);
+      grads[base + s0 + lane] = o;
+    }
+  }
+}
+
+// NERF backward: exact gradient of the RTXN_VR_NERF forward.
+//   C = sum_i T_i a_i c_i,  a_i = 1 - exp(-x_i), x_i = d_i sigma_i, T_i = exp(-sum_{k<i} x_k)
+//   dC/dc_i = T_i a_i ;  dC/dsigma_i = d_i ( T_i exp(-x_i) c_i  -  sum_{k>i} T_k a_k c_k )   (per channel, dotted with g)
+// Two sweeps per ray: forward sweep accumulates the total S = sum_k w_k (g.c_k); the
+// per-sample suffix is S - inclusive_prefix.
+__global__ __launch_bounds__(256) void volrender_bwd_nerf_kernel(const __half* __restrict__ loss_gradients,
+                                                                 const float4* __restrict__ radiance,
+                                                                 const float* __restrict__ step_len,
+                                                                 const int* __restrict__ num_hits,
+                                                                 const int* __restrict__ indices, int batch_size,
+                                                                 int K, half4* __restrict__ grads) {
+  const int lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= batch_size) return;
+  const long base = (long)indices[ray] * K;
+  const long n = (long)num_hits[ray] * K;
+  const float g0 = __half2float(loss_gradients[3 * (long)ray]);
+  const float g1 = __half2float(loss_gradients[3 * (long)ray + 1]);
+  const float g2 = __half2float(loss_gradients[3 * (long)ray + 2]);
+  // sweep 1: S = sum_k w_k (g . c_k)
+  float T_carry = 0.0f, S = 0.0f;
+  for (long s0 = 0; s0 < n; s0 += 64) {
+    const bool act = s0 + lane < n;
+    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+    float d = 0.0f;
+    if (act) {
+      c = radiance[base + s0 + lane];
+      d = step_len[base + s0 + lane];
+    }
+    const float x = d * c.w;
+    const float incl = wave_incl_scan_f(x, lane);
+    const float w = expf(-(T_carry + incl - x)) * (1.0f - expf(-x));
+    S += w * (g0 * c.x + g1 * c.y + g2 * c.z);
+    T_carry += __shfl(incl, 63, 64);
+  }
+  S = wave_sum(S);
+  // sweep 2: per-sample gradients
+  T_carry = 0.0f;
+  float P_carry = 0.0f;  // inclusive prefix of w_k (g.c_k)
+  for (long s0 = 0; s0 < n; s0 += 64) {
+    const bool act = s0 + lane < n;
+    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+    float d = 0.0f;
+    if (act) {
+      c = radiance[base + s0 + lane];
+      d = step_len[base + s0 + lane];
+    }
+    const float x = d * c.w;
+    const float incl = wave_incl_scan_f(x, lane);
+    const float Ti = expf(-(T_carry + incl - x));
+    const float ex = expf(-x);
+    const float a = 1.0f - ex;
+    const float gc = g0 * c.x + g1 * c.y + g2 * c.z;
+    const float wgc = Ti * a * gc;
+    const float pincl = P_carry + wave_incl_scan_f(wgc, lane);
+    if (act) {
+      const float suffix = S - pincl;
+      half4 o;
+      o.x = __float2half(g0 * Ti * a);
+      o.y = __float2half(g1 * Ti * a);
+      o.z = __float2half(g2 * Ti * a);
+      o.w = __float2half(d * (Ti * ex * gc - suffix));
+      grads[base + s0 + lane] = o;
+    }
+    T_carry += __shfl(incl, 63, 64);
+    P_carry = __shfl(pincl, 63, 64);
+  }
+}
+
+}  // namespace
+
+extern "C" int rtxn_volrender_fwd(const float* network_inputs, const float* network_outputs, const int* num_hits,
+                                  const int* indices, const float* ray_hit, int batch_size,
+                                  int num_samples_per_hit, float* pixels, int mode, rtxn_stream_t stream) {
+  (void)network_inputs;  // unused by the reference as well (vol_render.cu:19-73)
+  RTXN_REQUIRE(batch_size >= 0, "rtxn_volrender_fwd: batch_size = %d < 0", batch_size);
+  RTXN_REQUIRE(num_samples_per_hit > 0, "rtxn_volrender_fwd: num_samples_per_hit = %d", num_samples_per_hit);
+  RTXN_REQUIRE(mode == RTXN_VR_COMPAT || mode == RTXN_VR_NERF, "rtxn_volrender_fwd: unknown mode %d", mode);
+  RTXN_DEVICE_OR_FAIL();
+  if (batch_size == 0) return RTXN_OK;
+  RTXN_REQUIRE(network_outputs && num_hits && indices && ray_hit && pixels, "rtxn_volrender_fwd: NULL buffer");
+  RTXN_REQUIRE(((uintptr_t)network_outputs & 15) == 0, "rtxn_volrender_fwd: network_outputs must be 16-byte aligned");
+  hipStream_t s = rtxn::as_stream(stream);
+  dim3 grid((batch_size + 3) / 4), block(256);
+  const float4* rad = reinterpret_cast<const float4*>(network_outputs);
+  if (mode == RTXN_VR_COMPAT)
+    volrender_fwd_kernel<RTXN_VR_COMPAT><<<grid, block, 0, s>>>(rad, num_hits, indices, ray_hit, batch_size,
+                                                                 num_samples_per_hit, pixels);
+  else
+    volrender_fwd_kernel<RTXN_VR_NERF><<<grid, block, 0, s>>>(rad, num_hits, indices, ray_hit, batch_size,
+                                                               num_samples_per_hit, pixels);
+  RTXN_LAUNCH_CHECK("volrender_fwd_kernel");
+  return RTXN_OK;
+}
+
+extern "C" int rtxn_volrender_bwd(const float* loss_values, const void* loss_gradients,
+                                  const float* sampled_points_radiance, const float* t_hit, const int* num_hits,
+                                  const int* indices, int batch_size, int num_samples_per_hit,
+                                  void* radiance_gradients, int mode, rtxn_stream_t stream) {
+  (void)loss_values;  // unused by the reference as well (vol_render.cu:75-143)
+  RTXN_REQUIRE(batch_size >= 0, "rtxn_volrender_bwd: batch_size = %d < 0", batch_size);
+  RTXN_REQUIRE(num_samples_per_hit > 0, "rtxn_volrender_bwd: num_samples_per_hit = %d", num_samples_per_hit);
+  RTXN_REQUIRE(mode == RTXN_VR_COMPAT || mode == RTXN_VR_NERF, "rtxn_volrender_bwd: unknown mode %d", mode);
+  RTXN_DEVICE_OR_FAIL();
+  if (batch_size == 0) return RTXN_OK;
+  RTXN_REQUIRE(loss_gradients && sampled_points_radiance && t_hit && num_hits && indices && radiance_gradients,
+               "rtxn_volrender_bwd: NULL buffer");
+  RTXN_REQUIRE(((uintptr_t)sampled_points_radiance & 15) == 0 && ((uintptr_t)radiance_gradients & 7) == 0,
+               "rtxn_volrender_bwd: radiance must be 16-byte and gradients 8-byte aligned");
+  hipStream_t s = rtxn::as_stream(stream);
+  dim3 grid((batch_size + 3) / 4), block(256);
+  const float4* rad = reinterpret_cast<const float4*>(sampled_points_radiance);
+  const __half* lg = static_cast<const __half*>(loss_gradients);
+  half4* out = static_cast<half4*>(radiance_gradients);
+  if (mode == RTXN_VR_COMPAT)
+    volrender_bwd_compat_kernel<<<grid, block, 0, s>>>(lg, rad, t_hit, num_hits, indices, batch_size,
+                                                       num_samples_per_hit, out);
+  else
+    volrender_bwd_nerf_kernel<<<grid, block, 0, s>>>(lg, rad, t_hit, num_hits, indices, batch_size,
+                                                     num_samples_per_hit, out);
+  RTXN_LAUNCH_CHECK("volrender_bwd_kernel");
+  return RTXN_OK;
+}

@@ -1,0 +1,89 @@
+"""CPU-side checks of the C-ABI boundary: the library loads, exports every
+symbol include/rtxn.h declares, the ctypes table covers exactly those symbols,
+and (without a GPU) compute entry points fail loudly instead of falling back."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "rtxn.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rtxn_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    from rtx_nerf_amd import _lib
+    names = _declared_symbols()
+    assert len(names) >= 18
+    lib = _lib.lib()
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/rtxn.h but not exported by librtxn.so"
+    assert sorted(_lib.SYMBOLS) == names
+    assert lib.rtxn_version() == 100
+
+
+def test_struct_layouts_match_header_order():
+    from rtx_nerf_amd import _lib
+    src = open(os.path.join(ROOT, "include", "rtxn.h")).read()
+    body = src[src.index("typedef struct rtxn_trace_params {"):src.index("} rtxn_trace_params;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.split("{")[-1].strip()
+        if not decl:
+            continue
+        for part in decl.split(","):
+            fields.append(re.findall(r"([A-Za-z_][A-Za-z0-9_]*)\s*$", part.strip())[0])
+    assert fields == [f[0] for f in _lib.TraceParams._fields_]
+    assert C.sizeof(_lib.MlpConfig) == 32
+
+
+def test_no_cpu_fallback():
+    import torch
+    from rtx_nerf_amd import _lib
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu tests")
+    lib = _lib.lib()
+    rc = lib.rtxn_scan_hits(None, None, C.c_void_p(8), 0, None, 0, None)
+    assert rc == 2, "compute entry points must fail with RTXN_ERR_HIP when there is no device"
+    assert b"no HIP device" in lib.rtxn_last_error()
+    from rtx_nerf_amd import api
+    with pytest.raises(_lib.RtxnError):
+        api.scan_hits(torch.zeros(4, dtype=torch.int32))
+
+
+def test_argument_validation_precedes_device_use():
+    from rtx_nerf_amd import _lib
+    lib = _lib.lib()
+    assert lib.rtxn_sample(None, None, None, None, None, -1, 8, None, None, 0, None) == 1
+    assert b"batch_size" in lib.rtxn_last_error()
+    assert lib.rtxn_volrender_fwd(None, None, None, None, None, 4, 0, None, 0, None) == 1
+    cfg = _lib.MlpConfig(3, 10, 2, 12, 96, 8, 4, 1)   # 96-wide: not built
+    h = C.c_void_p()
+    assert lib.rtxn_mlp_create(C.byref(cfg), C.byref(h)) == 3
+    cfg = _lib.MlpConfig(3, 10, 2, 12, 128, 8, 4, 1)
+    assert lib.rtxn_mlp_create(C.byref(cfg), C.byref(h)) == 0
+    assert lib.rtxn_mlp_n_params(h) == 131072
+    assert lib.rtxn_mlp_encoded_width(h) == 112 and lib.rtxn_mlp_padded_output_width(h) == 16
+    assert lib.rtxn_mlp_destroy(h) == 0
+
+
+def test_initialize_params_is_seeded_xavier():
+    import numpy as np
+    import torch  # noqa: F401
+    from rtx_nerf_amd import api
+    net = api.Network(n_neurons=64, n_hidden_layers=2)
+    a = net.initialize_params(1337).numpy()
+    b = net.initialize_params(1337).numpy()
+    c = net.initialize_params(1338).numpy()
+    assert a.shape == (64 * 112 + 64 * 64 + 16 * 64,)
+    np.testing.assert_array_equal(a, b)
+    assert np.abs(a - c).max() > 0
+    lim0 = (6.0 / (64 + 112)) ** 0.5
+    assert np.abs(a[:64 * 112]).max() <= lim0 and np.abs(a[:64 * 112]).max() > 0.95 * lim0
+    assert abs(a.mean()) < 5e-3

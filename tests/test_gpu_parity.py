@@ -1,0 +1,408 @@
+"""GPU parity: every HIP kernel, called through the C ABI (rtx_nerf_amd.api ->
+librtxn.so), against the CPU oracle on the same seeded inputs.
+
+Stated bars (the oracle itself is "parity unpinned", see its header):
+  traversal  num_hits, start/end points, t: bit-exact; theta/phi: 2e-6 (atan2f differs between libms)
+  scan       bit-exact
+  sampler    bit-exact, all three modes
+  volrender  forward 1e-5 abs (wave scan sums in a different order; device expf);
+             backward: fp16 outputs within 1 fp16 ulp (device expf vs glibc)
+  MLP        fp16 sigmoid outputs within 1e-2 abs, mean abs error < 1e-3 (MFMA summation order)
+"""
+import numpy as np
+import pytest
+
+from rtx_nerf_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(torch, a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def _occ_dev(torch, words):
+    return torch.from_numpy(words.view(np.int32).copy()).cuda()
+
+
+# ------------------------------------------------------------------ scan
+@pytest.mark.parametrize("n", [0, 1, 63, 4096, 4097, 640000, 5_000_001])
+def test_scan_hits(gpu, oracle, n):
+    torch = gpu
+    from rtx_nerf_amd import api
+    rng = np.random.default_rng(n)
+    nh = rng.integers(0, 40, n).astype(np.int32)
+    idx, total = api.scan_hits(_dev(torch, nh))
+    want_idx, want_total = oracle.scan_hits(nh)
+    assert int(total.item()) == want_total
+    np.testing.assert_array_equal(idx.cpu().numpy(), want_idx)
+
+
+# ------------------------------------------------------------------ traversal
+def _trace_gpu(torch, api, *, R, mode, look_at=None, f=1.0, W=0, H=0, rays_o=None, rays_d=None, occ=None,
+               coarse=None, ray_begin=0, ray_count=None, S=None):
+    n_all = W * H if look_at is not None else rays_o.shape[0]
+    n = n_all - ray_begin if ray_count is None else ray_count
+    S = 3 * R if S is None else S
+    out = dict(
+        origins=torch.full((n, 3), -2.0, device="cuda"), view_dirs=torch.full((n, 2), -2.0, device="cuda"),
+        num_hits=torch.zeros(n, dtype=torch.int32, device="cuda"),
+        start=torch.full((n * S, 3), -2.0, device="cuda"), end=torch.full((n * S, 3), -2.0, device="cuda"),
+        t_start=torch.full((n * S,), -2.0, device="cuda"), t_end=torch.full((n * S,), -2.0, device="cuda"))
+    api.trace_grid(None if look_at is None else _dev(torch, look_at.reshape(16)), f, 1.0, W, H, grid_res=R,
+                   rays_o=None if rays_o is None else _dev(torch, rays_o),
+                   rays_d=None if rays_d is None else _dev(torch, rays_d),
+                   ray_begin=ray_begin, ray_count=n, occupancy=occ, occupancy_coarse=coarse, mode=mode,
+                   ray_origins=out["origins"], viewing_direction=out["view_dirs"], num_hits=out["num_hits"],
+                   intersection_arr_size=S, start_points=out["start"], end_points=out["end"],
+                   t_start=out["t_start"], t_end=out["t_end"])
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in out.items()}
+
+
+def _assert_trace_equal(got, want):
+    np.testing.assert_array_equal(got["num_hits"], want["num_hits"])
+    np.testing.assert_array_equal(got["origins"], want["origins"])
+    np.testing.assert_allclose(got["view_dirs"], want["view_dirs"], rtol=0, atol=2e-6)
+    for k in ("start", "end", "t_start", "t_end"):
+        np.testing.assert_array_equal(got[k], want[k].reshape(got[k].shape), err_msg=k)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("R,W,H,pose", [(8, 32, 32, (30.0, -30.0, 10.0)), (8, 32, 32, (0.0, 0.0, 1.0)),
+                                        (32, 40, 24, (120.0, -60.0, 10.0)), (12, 17, 9, (75.0, -10.0, 10.0))])
+def test_trace_dense_bit_exact(gpu, oracle, mode, R, W, H, pose):
+    torch = gpu
+    from rtx_nerf_amd import api
+    la = scenes.pose_spherical(pose[0], pose[1], origin_scale=pose[2])   # scale 1: camera inside the grid (quirk Q2)
+    f = scenes.lego_focal_length(True)
+    want = oracle.trace(look_at=la, focal=f, aspect=1.0, W=W, H=H, R=R, mode=mode)
+    got = _trace_gpu(torch, api, R=R, mode=mode, look_at=la, f=f, W=W, H=H)
+    assert want["num_hits"].max() > 0
+    _assert_trace_equal(got, want)
+
+
+def test_trace_q1_literal_focal(gpu, oracle):
+    torch = gpu
+    from rtx_nerf_amd import api
+    la = scenes.pose_spherical(30.0, -30.0, origin_scale=1.0)
+    f = scenes.lego_focal_length(False)   # negative: rays point backwards, still must agree
+    want = oracle.trace(look_at=la, focal=f, aspect=1.0, W=32, H=32, R=8, mode=0)
+    got = _trace_gpu(torch, api, R=8, mode=0, look_at=la, f=f, W=32, H=32)
+    _assert_trace_equal(got, want)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_trace_explicit_rays_edge_cases(gpu, oracle, mode):
+    torch = gpu
+    from rtx_nerf_amd import api
+    s3 = np.float32(1 / np.sqrt(3))
+    o = np.array([[-2.0, 0.1, 0.1], [-2.0, 1.5, 0.0], [0.05, 0.05, 0.05], [-2.0, -2.0, -2.0], [2.0, 0.1, 0.1],
+                  [0.0, 0.0, 3.0], [-1.0, -1.0, -1.0]], np.float32)
+    d = np.array([[1, 0, 0], [1, 0, 0], [1, 0, 0], [s3, s3, s3], [1, 0, 0], [0, 0, -1], [s3, s3, s3]], np.float32)
+    rng = np.random.default_rng(11)
+    ro = rng.uniform(-3, 3, (500, 3)).astype(np.float32)
+    rd = rng.standard_normal((500, 3)).astype(np.float32)
+    rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+    o, d = np.concatenate([o, ro]), np.concatenate([d, rd.astype(np.float32)])
+    want = oracle.trace(rays_o=o, rays_d=d, R=16, mode=mode)
+    got = _trace_gpu(torch, api, R=16, mode=mode, rays_o=o, rays_d=d)
+    assert got["num_hits"][0] == 16 and got["num_hits"][1] == 0 and got["num_hits"][3] == 16
+    _assert_trace_equal(got, want)
+
+
+@pytest.mark.parametrize("use_coarse", [False, True])
+@pytest.mark.parametrize("R", [16, 64])
+def test_trace_occupancy_and_hierarchical_skip(gpu, oracle, R, use_coarse):
+    """The two-level DDA (coarse mip in LDS) must reproduce the oracle's FLAT walk bit for bit."""
+    torch = gpu
+    from rtx_nerf_amd import api
+    dense = scenes.lego_standin_density(R, seed=1)
+    words = scenes.pack_occupancy(dense)
+    occ = _occ_dev(torch, words)
+    coarse = api.build_occupancy_mip(occ, R) if use_coarse else None
+    if use_coarse:
+        want_c = scenes.pack_occupancy(scenes.coarse_occupancy(dense))
+        np.testing.assert_array_equal(coarse.cpu().numpy().view(np.uint32), want_c)
+    la = scenes.pose_spherical(50.0, -35.0, origin_scale=10.0)
+    f = scenes.lego_focal_length(True)
+    for mode in ([1] if use_coarse else [0, 1]):
+        want = oracle.trace(look_at=la, focal=f, aspect=1.0, W=48, H=40, R=R, occ=words, mode=mode, S=R)
+        got = _trace_gpu(torch, api, R=R, mode=mode, look_at=la, f=f, W=48, H=40, occ=occ, coarse=coarse, S=R)
+        assert 0 < want["num_hits"].sum()
+        _assert_trace_equal(got, want)
+
+
+def test_trace_window_and_packed_two_pass(gpu, oracle):
+    """Ray window (the multi-GPU shard) + count -> scan -> write into the packed CSR layout."""
+    torch = gpu
+    from rtx_nerf_amd import api
+    R, W, H = 32, 64, 48
+    dense = scenes.lego_standin_density(R, seed=2)
+    words = scenes.pack_occupancy(dense)
+    occ = _occ_dev(torch, words)
+    coarse = api.build_occupancy_mip(occ, R)
+    la = scenes.pose_spherical(-40.0, -20.0, origin_scale=10.0)
+    f = scenes.lego_focal_length(True)
+    begin, count = 64 * 10 + 7, 64 * 21 + 5
+    want = oracle.trace_packed(look_at=la, focal=f, aspect=1.0, W=W, H=H, R=R, occ=words, mode=1,
+                               ray_begin=begin, ray_count=count)
+    la_d = _dev(torch, la.reshape(16))
+    nh = torch.zeros(count, dtype=torch.int32, device="cuda")
+    vd = torch.zeros((count, 2), device="cuda")
+    kw = dict(grid_res=R, ray_begin=begin, ray_count=count, occupancy=occ, occupancy_coarse=coarse, mode=1,
+              viewing_direction=vd, num_hits=nh)
+    api.trace_grid(la_d, f, 1.0, W, H, **kw)
+    idx, total = api.scan_hits(nh)
+    P = int(total.item())
+    assert P == want["total"] > 0
+    cap = P - 3   # capacity guard: the last 3 slots must stay untouched
+    sp = torch.full((P, 3), -2.0, device="cuda")
+    ep = torch.full((P, 3), -2.0, device="cuda")
+    sr = torch.full((P,), -1, dtype=torch.int32, device="cuda")
+    api.trace_grid(la_d, f, 1.0, W, H, indices=idx, start_points=sp, end_points=ep, seg_ray=sr,
+                   segment_capacity=cap, **kw)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(nh.cpu().numpy(), want["num_hits"])
+    np.testing.assert_array_equal(idx.cpu().numpy(), want["indices"])
+    np.testing.assert_array_equal(sp.cpu().numpy()[:cap], want["start"][:cap])
+    np.testing.assert_array_equal(ep.cpu().numpy()[:cap], want["end"][:cap])
+    np.testing.assert_array_equal(sr.cpu().numpy()[:cap], want["seg_ray"][:cap])
+    assert np.all(sp.cpu().numpy()[cap:] == -2.0) and np.all(sr.cpu().numpy()[cap:] == -1)
+
+
+# ------------------------------------------------------------------ sampler
+def _ragged_segments(rng, B, max_hits):
+    nh = rng.integers(0, max_hits + 1, B).astype(np.int32)
+    nh[rng.integers(0, B, max(1, B // 5))] = 0
+    idx = np.concatenate([[0], np.cumsum(nh)[:-1]]).astype(np.int32)
+    P = int(nh.sum())
+    sp = rng.uniform(-1, 1, (max(P, 1), 3)).astype(np.float32)
+    ep = rng.uniform(-1, 1, (max(P, 1), 3)).astype(np.float32)
+    vd = rng.uniform(-3.1, 3.1, (B, 2)).astype(np.float32)
+    return nh, idx, P, sp, ep, vd
+
+
+@pytest.mark.parametrize("sample_type", [0, 1, 2])
+@pytest.mark.parametrize("B,max_hits", [(64, 7), (1, 1), (1000, 46), (5, 0)])
+def test_sampler_bit_exact(gpu, oracle, sample_type, B, max_hits):
+    torch = gpu
+    from rtx_nerf_amd import api
+    rng = np.random.default_rng(B * 10 + sample_type)
+    nh, idx, P, sp, ep, vd = _ragged_segments(rng, B, max_hits)
+    samples = torch.full((max(P, 1) * 32, 5), -7.0, device="cuda")
+    t_vals = torch.full((max(P, 1) * 32,), -7.0, device="cuda")
+    api.launchSampler(_dev(torch, sp), _dev(torch, ep), _dev(torch, vd), t_vals, samples, B, 8,
+                      _dev(torch, nh), _dev(torch, idx), sample_type)
+    torch.cuda.synchronize()
+    ws, wt = oracle.sample(sp[:P], ep[:P], vd, nh, idx, sample_type)
+    np.testing.assert_array_equal(samples.cpu().numpy()[:P * 32], ws)
+    np.testing.assert_array_equal(t_vals.cpu().numpy()[:P * 32], wt)
+    if P == 0:
+        assert np.all(samples.cpu().numpy() == -7.0)
+
+
+# ------------------------------------------------------------------ volume rendering
+def _vr_inputs(rng, B, max_hits, K):
+    nh, idx, P, _, _, _ = _ragged_segments(rng, B, max_hits)
+    N = max(P, 1) * K
+    rad = rng.uniform(0, 1, (N, 4)).astype(np.float32)
+    t = np.tile(((np.arange(K) + 1) / K).astype(np.float32), max(P, 1))
+    return nh, idx, P, rad, t
+
+
+@pytest.mark.parametrize("B,max_hits,K", [(64, 7, 32), (1000, 46, 32), (3, 0, 32), (200, 5, 7), (50, 300, 32)])
+def test_volrender_fwd_compat(gpu, oracle, B, max_hits, K):
+    torch = gpu
+    from rtx_nerf_amd import api
+    rng = np.random.default_rng(B + K)
+    nh, idx, P, rad, t = _vr_inputs(rng, B, max_hits, K)
+    pix = torch.full((B, 3), -1.0, device="cuda")
+    api.launch_volrender_cuda(None, _dev(torch, rad), _dev(torch, nh), _dev(torch, idx), _dev(torch, t), B, K, pix)
+    torch.cuda.synchronize()
+    want = oracle.volrender_fwd(rad, nh, idx, t, K=K)
+    np.testing.assert_allclose(pix.cpu().numpy(), want, rtol=0, atol=1e-5)
+    assert np.all(pix.cpu().numpy()[nh == 0] == 0.0)
+
+
+def test_volrender_fwd_jittered_t(gpu, oracle):
+    """t_vals of the other sampler modes (non-monotone across segment boundaries)."""
+    torch = gpu
+    from rtx_nerf_amd import api
+    rng = np.random.default_rng(9)
+    nh, idx, P, rad, _ = _vr_inputs(rng, 300, 9, 32)
+    t = rng.uniform(0, 1, max(P, 1) * 32).astype(np.float32)
+    pix = torch.zeros((300, 3), device="cuda")
+    api.launch_volrender_cuda(None, _dev(torch, rad), _dev(torch, nh), _dev(torch, idx), _dev(torch, t), 300, 32, pix)
+    want = oracle.volrender_fwd(rad, nh, idx, t)
+    np.testing.assert_allclose(pix.cpu().numpy(), want, rtol=0, atol=1e-5)
+
+
+def _half_ulp_close(got_f16, want_f16, ulps=1):
+    a = got_f16.view(np.int16).astype(np.int32)
+    b = want_f16.view(np.int16).astype(np.int32)
+    a = np.where(a < 0, -(a & 0x7fff), a)
+    b = np.where(b < 0, -(b & 0x7fff), b)
+    return np.abs(a - b).max() <= ulps
+
+
+@pytest.mark.parametrize("B,max_hits,K", [(64, 7, 32), (1000, 30, 32), (3, 0, 32), (100, 5, 7)])
+def test_volrender_bwd_compat(gpu, oracle, B, max_hits, K):
+    torch = gpu
+    from rtx_nerf_amd import api
+    rng = np.random.default_rng(B + 3 * K)
+    nh, idx, P, rad, t = _vr_inputs(rng, B, max_hits, K)
+    g = rng.standard_normal((B, 3)).astype(np.float16)
+    out = torch.zeros((max(P, 1) * K, 4), dtype=torch.float16, device="cuda")
+    api.launch_volrender_backward_cuda(None, _dev(torch, g), _dev(torch, rad), _dev(torch, t), _dev(torch, nh),
+                                       _dev(torch, idx), B, K, out)
+    torch.cuda.synchronize()
+    want = oracle.volrender_bwd(g, rad, t, nh, idx, K=K)
+    got = out.cpu().numpy()[:P * K]
+    assert _half_ulp_close(got, want[:P * K])
+    assert (got.view(np.uint16) == want[:P * K].view(np.uint16)).mean() > 0.995
+
+
+def test_volrender_nerf_mode(gpu, oracle):
+    torch = gpu
+    from rtx_nerf_amd import api
+    rng = np.random.default_rng(21)
+    B, K = 400, 32
+    nh, idx, P, rad, _ = _vr_inputs(rng, B, 12, K)
+    rad[:, 3] *= 20.0
+    step = rng.uniform(0.001, 0.02, max(P, 1) * K).astype(np.float32)
+    g = rng.standard_normal((B, 3)).astype(np.float16)
+    pix = torch.zeros((B, 3), device="cuda")
+    api.launch_volrender_cuda(None, _dev(torch, rad), _dev(torch, nh), _dev(torch, idx), _dev(torch, step), B, K, pix,
+                              mode=api.VR_NERF)
+    np.testing.assert_allclose(pix.cpu().numpy(), oracle.volrender_fwd_nerf(rad, nh, idx, step, K=K), rtol=0, atol=2e-5)
+    out = torch.zeros((max(P, 1) * K, 4), dtype=torch.float16, device="cuda")
+    api.launch_volrender_backward_cuda(None, _dev(torch, g), _dev(torch, rad), _dev(torch, step), _dev(torch, nh),
+                                       _dev(torch, idx), B, K, out, mode=api.VR_NERF)
+    want = oracle.volrender_bwd_nerf(g, rad, step, nh, idx, K=K)[:P * K]
+    got = out.cpu().numpy()[:P * K].astype(np.float32)
+    # fp16 output: half an ulp relative (2^-11) plus the fp32-vs-double suffix-sum noise
+    np.testing.assert_allclose(got, want, rtol=1.5e-3, atol=2e-5)
+
+
+# ------------------------------------------------------------------ MLP
+def _mlp_case(oracle, W, nh, n, seed, dir_freqs=12):
+    cfg = oracle.mlp_cfg(n_neurons=W, n_hidden_layers=nh, n_dir_freqs=dir_freqs)
+    params = scenes.xavier_params_fp16(W, nh, oracle.mlp_enc_padded(cfg), seed=seed)
+    rng = np.random.default_rng(seed)
+    x = np.concatenate([rng.uniform(-1, 1, (n, 3)), rng.uniform(0, 3.1416, (n, 1)), rng.uniform(-3.1416, 3.1416, (n, 1))],
+                       axis=1).astype(np.float32)
+    return cfg, params, x
+
+
+@pytest.mark.parametrize("W,nh,n,dir_freqs", [(128, 8, 1000, 12), (64, 2, 777, 12), (128, 1, 256, 12), (64, 4, 3, 12),
+                                              (128, 3, 515, 4), (64, 3, 300, 4)])
+def test_mlp_forward_half_output(gpu, oracle, W, nh, n, dir_freqs):
+    torch = gpu
+    from rtx_nerf_amd import api
+    cfg, params, x = _mlp_case(oracle, W, nh, n, seed=W + nh, dir_freqs=dir_freqs)
+    net = api.Network(n_neurons=W, n_hidden_layers=nh, n_dir_freqs=dir_freqs)
+    assert net.n_params() == params.size
+    net.set_params(_dev(torch, params))
+    out = torch.full((n, 16), -5.0, dtype=torch.float16, device="cuda")
+    net.forward(_dev(torch, x), out)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().astype(np.float32)
+    want = oracle.mlp_forward(cfg, params, x).astype(np.float32)
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-2)
+    assert np.abs(got - want).mean() < 1e-3
+    assert want[:, :4].std() > 0.01
+
+
+def test_mlp_forward_radiance_and_no_activation(gpu, oracle):
+    torch = gpu
+    from rtx_nerf_amd import api
+    cfg, params, x = _mlp_case(oracle, 128, 8, 2049, seed=5)
+    net = api.Network()
+    net.set_params(_dev(torch, params))
+    rad = net.forward_radiance(_dev(torch, x)).cpu().numpy()
+    want = oracle.mlp_forward(cfg, params, x).astype(np.float32)[:, :4]
+    np.testing.assert_allclose(rad, want, rtol=0, atol=1e-2)
+    # radiance is the fp16 network output widened to fp32 (convertHalfToFloat): exactly fp16-representable
+    np.testing.assert_array_equal(rad, rad.astype(np.float16).astype(np.float32))
+    cfg2 = oracle.mlp_cfg(output_activation=0)
+    net2 = api.Network(output_activation=api.ACT_NONE)
+    net2.set_params(_dev(torch, params))
+    out = net2.forward(_dev(torch, x[:300])).cpu().numpy().astype(np.float32)
+    want2 = oracle.mlp_forward(cfg2, params, x[:300]).astype(np.float32)
+    np.testing.assert_allclose(out, want2, rtol=0, atol=2e-2)
+
+
+def test_mlp_identity_weights_expose_layouts(gpu, oracle):
+    """Structured weights (one 1.0 per row at an asymmetric position) make the output an exact copy
+    of chosen encoding features: catches any transposed/permuted MFMA fragment map outright."""
+    torch = gpu
+    from rtx_nerf_amd import api
+    W, nh, P = 128, 3, 112
+    cfg = oracle.mlp_cfg(n_neurons=W, n_hidden_layers=nh, output_activation=0)
+    p = np.zeros(W * P + (nh - 1) * W * W + 16 * W, np.float16)
+    w0 = p[:W * P].reshape(W, P)
+    perm0 = (np.arange(W) * 37 + 5) % P            # row r of layer 0 copies encoding feature perm0[r]
+    w0[np.arange(W), perm0] = 1
+    off = W * P
+    perms = []
+    for l in range(nh - 1):
+        wl = p[off:off + W * W].reshape(W, W)
+        pl = (np.arange(W) * 29 + 11 * (l + 1)) % W
+        wl[np.arange(W), pl] = 1
+        perms.append(pl)
+        off += W * W
+    wo = p[off:].reshape(16, W)
+    po = (np.arange(16) * 7 + 3) % W
+    wo[np.arange(16), po] = 1
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-1, 1, (512, 3)), rng.uniform(-3, 3, (512, 2))], axis=1).astype(np.float32)
+    net = api.Network(n_neurons=W, n_hidden_layers=nh, output_activation=api.ACT_NONE)
+    net.set_params(_dev(torch, p))
+    got = net.forward(_dev(torch, x)).cpu().numpy().astype(np.float32)
+    want = oracle.mlp_forward(cfg, p, x).astype(np.float32)
+    # copies of relu(fp16 feature): exact up to the v_sin_f32-vs-libm rounding of the feature itself
+    np.testing.assert_allclose(got, want, rtol=0, atol=1.5e-3)
+    assert (got == want).mean() > 0.97
+    src = perm0
+    for pl in perms:
+        src = src[pl]
+    src = src[po]
+    assert len(set(src.tolist())) > 8 and want.std() > 0.1
+
+
+def test_mlp_forward_segments_equals_sampler_plus_forward(gpu, oracle):
+    torch = gpu
+    from rtx_nerf_amd import api
+    rng = np.random.default_rng(4)
+    B = 700
+    nh, idx, P, sp, ep, vd = _ragged_segments(rng, B, 9)
+    seg_ray = np.repeat(np.arange(B, dtype=np.int32), nh)
+    cfg, params, _ = _mlp_case(oracle, 128, 8, 1, seed=9)
+    net = api.Network()
+    net.set_params(_dev(torch, params))
+    cap = P + 13
+    rad = torch.full((cap * 32, 4), -3.0, device="cuda")
+    tv = torch.full((cap * 32,), -3.0, device="cuda")
+    sp_d = _dev(torch, np.concatenate([sp[:P], np.zeros((13, 3), np.float32)]))
+    ep_d = _dev(torch, np.concatenate([ep[:P], np.zeros((13, 3), np.float32)]))
+    sr_d = _dev(torch, np.concatenate([seg_ray, np.zeros(13, np.int32)]))
+    total = torch.tensor([P], dtype=torch.int32, device="cuda")
+    net.forward_segments(sp_d, ep_d, _dev(torch, vd), sr_d, total, cap, rad, tv)
+    torch.cuda.synchronize()
+    # same samples as the standalone sampler (bit-exact), then the same network
+    samples, t_vals = oracle.sample(sp[:P], ep[:P], vd, nh, idx, 0)
+    s_d = torch.zeros((P * 32, 5), device="cuda")
+    t_d = torch.zeros((P * 32,), device="cuda")
+    api.launchSampler(sp_d, ep_d, _dev(torch, vd), t_d, s_d, B, 8, _dev(torch, nh), _dev(torch, idx), 0)
+    rad2 = net.forward_radiance(s_d).cpu().numpy()
+    got = rad.cpu().numpy()
+    np.testing.assert_array_equal(got[:P * 32], rad2)                  # fused == staged, bit for bit
+    np.testing.assert_array_equal(tv.cpu().numpy()[:P * 32], t_vals)
+    assert np.all(got[P * 32:] == -3.0) and np.all(tv.cpu().numpy()[P * 32:] == -3.0)   # nothing beyond *total
+    want = oracle.mlp_forward(cfg, params, samples).astype(np.float32)[:, :4]
+    np.testing.assert_allclose(got[:P * 32], want, rtol=0, atol=1e-2)
