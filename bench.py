@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--neurons", type=int, default=128)
     ap.add_argument("--layers", type=int, default=8)
     ap.add_argument("--poses", type=int, default=4)
-    ap.add_argument("--cpu-rays", type=int, default=1536, help="rays of the cpu_baseline / PSNR sample")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--kernel-steps", type=int, default=5, help="extra frames with HIP events around the MLP kernel")
     return ap.parse_args()
@@ -191,13 +191,22 @@ def main():
     # ---- cpu_baseline + PSNR vs oracle on a bounded ray sample (rank 0, N=1 only) ----
     if rank == 0 and world == 1 and not args.no_cpu:
         import oracle as O   # checker / baseline only
-        stride = max(1, (W * H) // args.cpu_rays)
-        ray_ids = (np.arange(args.cpu_rays, dtype=np.int64) * stride + (stride // 2) * 0).astype(np.uint32)
-        # centre-weighted sample so that it is not dominated by empty rays: every `stride`-th ray of the frame
         cfg = O.mlp_cfg(n_neurons=args.neurons, n_hidden_layers=args.layers)
         pose = poses[0]
         pipe.look_at.copy_(poses_d[0])
         gpu_pix = pipe.render(ray_begin=0, ray_count=n_local).cpu().numpy()
+
+        def every(nrays):
+            stride = max(1, (W * H) // nrays)
+            return stride, (np.arange(min(nrays, W * H), dtype=np.int64) * stride).astype(np.uint32)
+
+        # probe to size a bounded sample of ~cpu_seconds of work on this host's cores
+        _, probe_ids = every(2048)
+        t1 = time.perf_counter()
+        O.render(pose, focal, W / H, W, H, R, words, 1, cfg, params, probe_ids)
+        probe_s = max(time.perf_counter() - t1, 1e-3)
+        n_cpu = int(min(W * H, max(2048, 2048 * args.cpu_seconds / probe_s)))
+        stride, ray_ids = every(n_cpu)
         t1 = time.perf_counter()
         cpu_pix, cpu_samples = O.render(pose, focal, W / H, W, H, R, words, 1, cfg, params, ray_ids)
         cpu_s = time.perf_counter() - t1
@@ -205,9 +214,9 @@ def main():
         out["psnr_vs_oracle_db"] = round(10.0 * np.log10(1.0 / max(mse, 1e-20)), 2)
         out["max_abs_err_vs_oracle"] = float(np.abs(gpu_pix[ray_ids] - cpu_pix).max())
         out["cpu_baseline"] = {
-            "value": round(args.cpu_rays / cpu_s / 1e6, 6), "unit": "Mrays/s", "cores": O.num_threads(),
+            "value": round(len(ray_ids) / cpu_s / 1e6, 6), "unit": "Mrays/s", "cores": O.num_threads(),
             "kind": "port",
-            "sample": f"{args.cpu_rays} rays (every {stride}th ray of pose 0's frame, {cpu_samples} samples), "
+            "sample": f"{len(ray_ids)} rays (every {stride}th ray of pose 0's frame, {cpu_samples} samples), "
                       f"oracle/rtxn_oracle.c orc_render, OpenMP over rays, {cpu_s:.1f} s",
         }
     if rank == 0:

@@ -246,7 +246,7 @@ def _half_ulp_close(got_f16, want_f16, ulps=1):
     b = want_f16.view(np.int16).astype(np.int32)
     a = np.where(a < 0, -(a & 0x7fff), a)
     b = np.where(b < 0, -(b & 0x7fff), b)
-    return np.abs(a - b).max() <= ulps
+    return a.size == 0 or np.abs(a - b).max() <= ulps
 
 
 @pytest.mark.parametrize("B,max_hits,K", [(64, 7, 32), (1000, 30, 32), (3, 0, 32), (100, 5, 7)])
@@ -263,7 +263,7 @@ def test_volrender_bwd_compat(gpu, oracle, B, max_hits, K):
     want = oracle.volrender_bwd(g, rad, t, nh, idx, K=K)
     got = out.cpu().numpy()[:P * K]
     assert _half_ulp_close(got, want[:P * K])
-    assert (got.view(np.uint16) == want[:P * K].view(np.uint16)).mean() > 0.995
+    assert P == 0 or (got.view(np.uint16) == want[:P * K].view(np.uint16)).mean() > 0.995
 
 
 def test_volrender_nerf_mode(gpu, oracle):
