@@ -6,7 +6,7 @@ SRCS := $(wildcard $(CSRC)/*.hip)
 OBJS := $(patsubst $(CSRC)/%.hip,build/%.o,$(SRCS))
 HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -Iinclude -I$(CSRC) -Wall -Wno-unused-function
 
-all: rtx_nerf_amd/librtxn.so oracle
+all: rtx_nerf_amd/librtxn.so oracle examples/render_host
 
 build/%.o: $(CSRC)/%.hip $(CSRC)/common.h include/rtxn.h
 	@mkdir -p build
@@ -18,8 +18,13 @@ rtx_nerf_amd/librtxn.so: $(OBJS)
 oracle:
 	$(MAKE) -C oracle -s
 
+# C++ host over the drop-in headers (reference-style call sites); links librtxn.so by rpath
+DROPIN := -Iinclude -Iinclude/rtxn_dropin -Iinclude/rtxn_dropin/sampler -Iinclude/rtxn_dropin/vol_render
+examples/render_host: examples/render_host.cpp rtx_nerf_amd/librtxn.so $(wildcard include/rtxn_dropin/*/*.h include/rtxn_dropin/rtx/include/*.h)
+	$(HIPCC) -O2 -std=c++17 --offload-arch=$(ARCH) $(DROPIN) $< -o $@ -Lrtx_nerf_amd -lrtxn -Wl,-rpath,'$$ORIGIN/../rtx_nerf_amd'
+
 clean:
-	rm -rf build rtx_nerf_amd/librtxn.so
+	rm -rf build rtx_nerf_amd/librtxn.so examples/render_host
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean
