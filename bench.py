@@ -67,6 +67,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from rtx_nerf_amd import api, render, scenes
+    from rtx_nerf_amd.shard import RowShard
 
     W, H, R = args.width, args.height, args.grid
     dense = scenes.lego_standin_density(R, seed=0)
@@ -78,21 +79,19 @@ def main():
     focal = scenes.lego_focal_length(True)
     poses = [scenes.pose_spherical(360.0 * i / args.poses + 15.0, -30.0, origin_scale=10.0) for i in range(args.poses)]
 
-    # ray shard of this rank: image rows rank, rank+world, ... (chunk = one row)
-    rows = list(range(rank, H, world))
-    n_local = len(rows) * W
-    window = (W, world * W) if world > 1 else (0, 0)
+    # ray shard of this rank: image rows rank, rank+world, ... (rtx_nerf_amd/shard.py)
+    sh = RowShard(W, H, rank, world)
+    n_local, ray_begin = sh.n_local, sh.ray_begin
     pipe = render.RenderPipeline(net, R, W, H, focal, occupancy=occ, max_rays=n_local, max_segments=1024,
-                                 window=window)
-    ray_begin = rank * W if world > 1 else 0
+                                 window=sh.window)
     worst = pipe.calibrate(poses, ray_begin=ray_begin, ray_count=n_local)
     poses_d = [torch.from_numpy(p.reshape(16)).cuda() for p in poses]
 
-    # gather plumbing: equal shards only when H % world == 0; otherwise pad to the largest shard
-    n_max = ((H + world - 1) // world) * W
+    # gather plumbing: shards are padded to the largest one so every rank sends n_max rows
+    n_max = sh.n_max
     pix_bufs = [torch.zeros((n_max, 3), device="cuda") for _ in range(2)]
     gather_bufs = [[torch.empty((n_max, 3), device="cuda") for _ in range(world)] for _ in range(2)] \
-        if (world > 1 and rank == 0) else None
+        if (world > 1 and rank == 0) else [None, None]
     pending = [None, None]
 
     def step(i):
@@ -103,7 +102,7 @@ def main():
         pipe.look_at.copy_(poses_d[i % len(poses_d)], non_blocking=True)
         pipe.render(ray_begin=ray_begin, ray_count=n_local, out=pix_bufs[b][:n_local])
         if world > 1:
-            pending[b] = dist.gather(pix_bufs[b], gather_bufs[b] if rank == 0 else None, dst=0, async_op=True)
+            pending[b] = sh.gather(pix_bufs[b], gather_bufs[b], async_op=True)
 
     def drain():
         for b in range(2):
