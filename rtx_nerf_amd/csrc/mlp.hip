@@ -15,7 +15,7 @@
 //     on the activation path.  The k order this imposes (element j of lane-half h of
 //     k-step s is feature 16s + 8(j>>2) + 4h + (j&3)) is baked into the weight packing.
 //   * Weights are pre-packed (rtxn_mlp_set_params) into 1-KiB "A fragments": chunk
-//     (layer, k-step, row-tile) holds lane l's 8 halves at byte l*16, so the LDS image
+//     (layer, row-tile, k-step) holds lane l's 8 halves at byte l*16, so the LDS image
 //     is lane-linear: staged with global_load_lds (16 B/lane, no VGPR round trip) and
 //     read back with one conflict-free ds_read_b128 per fragment.
 //   * One layer (<= 32 KiB) is resident per LDS buffer; layer l+1 streams into the other
@@ -83,7 +83,7 @@ struct FwdArgs {
 // weight packing
 // ---------------------------------------------------------------------------
 // params (tcnn layout): layer 0 [W][enc_padded], hidden [W][W] x (L-1), out [16][W], row-major fp16.
-// packed: per layer, chunks ordered [kstep][rowtile], each 64 lanes x 8 halves.
+// packed: per layer, chunks ordered [rowtile][kstep], each 64 lanes x 8 halves.
 //   layer 0  : element (lane r,h ; kstep kk ; j) = W0[32*rt + r][2*(8kk+j) + h]          (0 if >= enc_padded)
 //   others   : element = Wl[32*rt + r][16kk + 8(j>>2) + 4h + (j&3)]                       (0 if row >= rows)
 __global__ void pack_kernel(const _Float16* __restrict__ params, _Float16* __restrict__ packed, int W, int enc_padded,
@@ -95,25 +95,26 @@ __global__ void pack_kernel(const _Float16* __restrict__ params, _Float16* __res
   const long total = l0_elems + (long)(n_hidden - 1) * hid_elems + out_elems;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     long q = e;
-    int layer, rt_count, in_w, rows;
+    int layer, in_w, rows;
     long src_base;
     if (q < l0_elems) {
-      layer = 0; rt_count = RT; in_w = enc_padded; rows = W; src_base = 0;
+      layer = 0; in_w = enc_padded; rows = W; src_base = 0;
     } else {
       q -= l0_elems;
       long hl = q / hid_elems;
       if (hl < n_hidden - 1) {
-        layer = 1 + (int)hl; q -= hl * hid_elems; rt_count = RT; in_w = W; rows = W;
+        layer = 1 + (int)hl; q -= hl * hid_elems; in_w = W; rows = W;
         src_base = (long)W * enc_padded + hl * (long)W * W;
       } else {
         q -= (long)(n_hidden - 1) * hid_elems;
-        layer = n_hidden; rt_count = 1; in_w = W; rows = 16;
+        layer = n_hidden; in_w = W; rows = 16;
         src_base = (long)W * enc_padded + (long)(n_hidden - 1) * W * W;
       }
     }
     const int j = (int)(q & 7), lane = (int)((q >> 3) & 63);
     const long chunk = q >> 9;
-    const int rt = (int)(chunk % rt_count), kk = (int)(chunk / rt_count);
+    const int ks_count = layer == 0 ? k0 / 16 : W / 16;
+    const int kk = (int)(chunk % ks_count), rt = (int)(chunk / ks_count);
     const int r = lane & 31, h = lane >> 5;
     const int row = 32 * rt + r;
     int feat;
@@ -148,25 +149,74 @@ __device__ __forceinline__ void stage(const uint8_t* __restrict__ g, uint8_t* ld
   }
 }
 
-template <int RT, int KS, int NB>
-__device__ __forceinline__ void layer_mma(const uint8_t* lds_buf, const half8 (&bf)[NB][2], floatx16 (&acc)[RT][2],
-                                          int lane) {
-#pragma unroll
-  for (int kk = 0; kk < KS; ++kk) {
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      const half8 a = *reinterpret_cast<const half8*>(lds_buf + ((kk * RT + rt) * 64 + lane) * 16);
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[kk][ct], acc[rt][ct], 0, 0, 0);
-    }
-  }
+typedef short short8 __attribute__((ext_vector_type(8)));
+
+// ReLU + f32->f16 of 8 accumulator registers = one B fragment of the next layer.
+// Convert first (v_cvt_pk_f16_f32, 2 values/op), then clamp the PACKED halves with a
+// signed-integer max against 0 (v_pk_max_i16, 2 values/op): a negative half has its
+// sign bit set, i.e. is a negative int16, and rounding is monotone, so this equals
+// fp16(max(x, 0)).  A float max would cost one op per value plus the canonicalising
+// v_max hipcc inserts in front of fmaxf on MFMA results.
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef short short2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ half2v relu_pack2(float a, float b) {
+  float2v f = {a, b};
+  half2v hv = __builtin_convertvector(f, half2v);           // v_cvt_pk_f16_f32
+  short2v sv = __builtin_bit_cast(short2v, hv);
+  sv = __builtin_elementwise_max(sv, (short2v)0);          // v_pk_max_i16
+  return __builtin_bit_cast(half2v, sv);
 }
 
 __device__ __forceinline__ half8 relu_pack(const floatx16& c, int s) {
-  half8 v;
+  const half2v p0 = relu_pack2(c[8 * s + 0], c[8 * s + 1]);
+  const half2v p1 = relu_pack2(c[8 * s + 2], c[8 * s + 3]);
+  const half2v p2 = relu_pack2(c[8 * s + 4], c[8 * s + 5]);
+  const half2v p3 = relu_pack2(c[8 * s + 6], c[8 * s + 7]);
+  const half4v q0 = __builtin_shufflevector(p0, p1, 0, 1, 2, 3);
+  const half4v q1 = __builtin_shufflevector(p2, p3, 0, 1, 2, 3);
+  return __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// One layer: out rows [32*rt, 32*rt+32) for rt < RT, K = 16*KS, for the wave's two column
+// tiles.  Row-tile-outer: an accumulator is live for one row tile only, and its ReLU/convert
+// (VALU) overlaps the next row tile's MFMAs.  A fragments: chunk (rt, kk) at ((rt*KS+kk)*64+lane)*16.
+template <int RT, int KS, int NB>
+__device__ __forceinline__ void layer_mma(const uint8_t* lds_buf, const half8 (&bf)[NB][2], half8 (&nbf)[NB][2],
+                                          int lane) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] = (_Float16)fmaxf(c[8 * s + j], 0.0f);
-  return v;
+  for (int rt = 0; rt < RT; ++rt) {
+    floatx16 acc[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[ct][e] = 0.0f;
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      const half8 a = *reinterpret_cast<const half8*>(lds_buf + ((rt * KS + kk) * 64 + lane) * 16);
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[kk][ct], acc[ct], 0, 0, 0);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) nbf[2 * rt + s][ct] = relu_pack(acc[ct], s);
+  }
+}
+
+// Output layer: 32 rows (16 real), raw accumulators returned.
+template <int KS, int NB>
+__device__ __forceinline__ void out_mma(const uint8_t* lds_buf, const half8 (&bf)[NB][2], floatx16 (&acc)[2], int lane) {
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[ct][e] = 0.0f;
+#pragma unroll
+  for (int kk = 0; kk < KS; ++kk) {
+    const half8 a = *reinterpret_cast<const half8*>(lds_buf + (kk * 64 + lane) * 16);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[kk][ct], acc[ct], 0, 0, 0);
+  }
 }
 
 // Encoding slot p (0..): pair (dim, freq) of Composite(Frequency(PD,PF), Frequency(DD,DF)).
@@ -270,80 +320,68 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
       }
     }
 
-    // ---- layers ----
-    for (int l = 0; l < n_layers; ++l, ++q) {
-      uint8_t* cur = smem + (q & 1) * BUF;
+    // ---- layers ----  (two fragment sets used ping-pong: no register copies between layers)
+    half8 bg[NB][2];
+    // barrier + prefetch of the following stage; returns the LDS buffer holding layer l
+    auto begin_stage = [&](int l) -> const uint8_t* {
+      const uint8_t* cur = smem + (q & 1) * BUF;
       uint8_t* nxt = smem + ((q + 1) & 1) * BUF;
-      __syncthreads();  // stage q landed (compiler drains vmcnt before the barrier); buffer nxt is free
-      // prefetch the next stage
+      __syncthreads();  // stage q landed (hipcc drains vmcnt before the barrier); buffer nxt is free
       if (l + 1 < n_layers) {
         if (l + 1 == n_layers - 1) stage<OUT_BYTES>(a.packed + layer_off(l + 1), nxt, tid);
         else stage<HID_BYTES>(a.packed + layer_off(l + 1), nxt, tid);
       } else if (tile + gridDim.x < n_tiles) {
         stage<L0_BYTES>(a.packed, nxt, tid);
       }
-      if (l == 0) {
-        floatx16 acc[RT][2];
+      ++q;
+      return cur;
+    };
+    auto finish = [&](const half8 (&in)[NB][2]) {
+      const uint8_t* w = begin_stage(n_layers - 1);
+      floatx16 acc[2];
+      out_mma<KS, NB>(w, in, acc, lane);
+      // rows 4h..4h+3 are regs 0..3, rows 8+4h..8+4h+3 are regs 4..7 of this lane
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
+      for (int ct = 0; ct < 2; ++ct) {
+        float y[8];
 #pragma unroll
-          for (int ct = 0; ct < 2; ++ct)
+        for (int e = 0; e < 8; ++e) {
+          const float z = acc[ct][e];
+          y[e] = a.out_act == RTXN_ACT_SIGMOID ? 1.0f / (1.0f + __expf(-z)) : z;
+        }
+        if (valid[ct]) {
+          if (OUT_MODE == 0) {
+            half4v lo, hi;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[rt][ct][e] = 0.0f;
-        layer_mma<RT, KS0, NB>(cur, bf, acc, lane);
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-          for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) bf[2 * rt + s][ct] = relu_pack(acc[rt][ct], s);
-      } else if (l < n_layers - 1) {
-        floatx16 acc[RT][2];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-          for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[rt][ct][e] = 0.0f;
-        layer_mma<RT, KS, NB>(cur, bf, acc, lane);
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-          for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) bf[2 * rt + s][ct] = relu_pack(acc[rt][ct], s);
-      } else {
-        floatx16 acc[1][2];
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) acc[0][ct][e] = 0.0f;
-        layer_mma<1, KS, NB>(cur, bf, acc, lane);
-        // rows 4h..4h+3 are regs 0..3, rows 8+4h..8+4h+3 are regs 4..7 of this lane
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-          float y[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float z = acc[0][ct][e];
-            y[e] = a.out_act == RTXN_ACT_SIGMOID ? 1.0f / (1.0f + __expf(-z)) : z;
-          }
-          if (valid[ct]) {
-            if (OUT_MODE == 0) {
-              half4v lo, hi;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) { lo[e] = (_Float16)y[e]; hi[e] = (_Float16)y[4 + e]; }
-              _Float16* o = a.out_half + samp[ct] * 16;
-              *reinterpret_cast<half4v*>(o + 4 * h) = lo;
-              *reinterpret_cast<half4v*>(o + 8 + 4 * h) = hi;
-            } else if (h == 0) {
-              // radiance = fp32(fp16(y)): the half output of network->forward, then convertHalfToFloat
-              a.radiance[samp[ct]] = make_float4((float)(_Float16)y[0], (float)(_Float16)y[1],
-                                                 (float)(_Float16)y[2], (float)(_Float16)y[3]);
-            }
+            for (int e = 0; e < 4; ++e) { lo[e] = (_Float16)y[e]; hi[e] = (_Float16)y[4 + e]; }
+            _Float16* o = a.out_half + samp[ct] * 16;
+            *reinterpret_cast<half4v*>(o + 4 * h) = lo;
+            *reinterpret_cast<half4v*>(o + 8 + 4 * h) = hi;
+          } else if (h == 0) {
+            // radiance = fp32(fp16(y)): the half output of network->forward, then convertHalfToFloat
+            a.radiance[samp[ct]] = make_float4((float)(_Float16)y[0], (float)(_Float16)y[1],
+                                               (float)(_Float16)y[2], (float)(_Float16)y[3]);
           }
         }
       }
+    };
+    {
+      const uint8_t* w = begin_stage(0);
+      layer_mma<RT, KS0, NB>(w, bf, bg, lane);
+    }
+    int l = 1;
+    for (; l + 1 < n_layers - 1; l += 2) {  // activations in bg at the top
+      const uint8_t* w = begin_stage(l);
+      layer_mma<RT, KS, NB>(w, bg, bf, lane);
+      w = begin_stage(l + 1);
+      layer_mma<RT, KS, NB>(w, bf, bg, lane);
+    }
+    if (l < n_layers - 1) {
+      const uint8_t* w = begin_stage(l);
+      layer_mma<RT, KS, NB>(w, bg, bf, lane);
+      finish(bf);
+    } else {
+      finish(bg);
     }
   }
 }
