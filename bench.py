@@ -61,10 +61,17 @@ def main():
                   f"--nproc-per-node {args.gpus}", file=sys.stderr)
         sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
-    torch.cuda.set_device(local_rank)
+    # RTXN_REHEARSE_ON_ONE_GPU=1: every rank uses cuda:0 and the gather goes over gloo -- only to rehearse the
+    # N>1 code path on a one-GPU box; never used by the driver's real runs (one GPU per rank, RCCL).
+    rehearse = os.environ.get("RTXN_REHEARSE_ON_ONE_GPU") == "1"
+    dev_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
 
     from rtx_nerf_amd import api, render, scenes
     from rtx_nerf_amd.shard import RowShard
@@ -126,7 +133,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert not pipe.overflowed(), "segment capacity overflow: calibrate() margin too small"
@@ -168,7 +175,8 @@ def main():
                         f"{100.0 * dense.mean():.1f}% cells), {args.layers}x{args.neurons} ReLU MLP + Composite-Frequency "
                         f"encoding, 32 samples/segment, {args.poses} hemisphere poses, seeded random fp16 weights",
             "rays_per_step": rays_per_step,
-            "parallelism": f"ray-shard x{world} (rows round-robin) + RCCL gather" if world > 1 else "single GPU",
+            "parallelism": (f"ray-shard x{world} (rows round-robin) + " + ("gloo gather (one-GPU rehearsal)" if rehearse
+                            else "RCCL gather")) if world > 1 else "single GPU",
             "trace_mode": "dda+mip",
         },
     }
