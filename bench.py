@@ -148,7 +148,7 @@ def main():
         pipe._trace(ray_begin, n_local, write=True)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        net.forward_segments(pipe.start, pipe.end, pipe.view_dirs, pipe.seg_ray, pipe.total, pipe.max_segments,
+        net.forward_segments(pipe.start, pipe.end, pipe.seg_view, pipe.total, pipe.max_segments,
                              pipe.radiance, pipe.t_vals)
         e1.record()
         torch.cuda.synchronize()

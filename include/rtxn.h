@@ -107,6 +107,7 @@ typedef struct rtxn_trace_params {
   float* t_start;            /* float per slot  (params.h:28) */
   float* t_end;              /* float per slot  (params.h:29) */
   int* seg_ray;              /* int per slot: local ray of the segment (packed layout; new) */
+  float* seg_view;           /* float2 per slot: (theta, phi) of the segment's ray (packed layout; new) */
   long segment_capacity;     /* packed layout: slots >= capacity are not written (0 = unbounded) */
 } rtxn_trace_params;
 
@@ -201,13 +202,16 @@ int rtxn_mlp_forward(const rtxn_mlp* m, const float* input, void* output_half, l
 int rtxn_mlp_forward_radiance(const rtxn_mlp* m, const float* input, float* radiance, long n,
                               rtxn_stream_t stream);
 /* Sampler (REGULAR) + encoding + MLP + glue fused: reads packed segments,
- * never materialises the 5-float samples.  *total_segments is the device int
- * written by rtxn_scan_hits; the launch is sized by max_segments (capacity of
- * the caller's buffers) and exits early beyond *total_segments.
+ * never materialises the 5-float samples.  seg_view: float2 per segment, the
+ * (theta, phi) of its ray as written by rtxn_trace_grid (packed layout), so a
+ * segment's inputs are three independent 12/12/8-byte records.
+ * *total_segments is the device int written by rtxn_scan_hits; the launch is
+ * sized by max_segments (capacity of the caller's buffers) and exits early
+ * beyond *total_segments.
  * radiance: float[max_segments*32*4]; t_vals: float[max_segments*32] or NULL. */
 int rtxn_mlp_forward_segments(const rtxn_mlp* m, const float* start_points, const float* end_points,
-                              const float* view_dirs, const int* seg_ray, const int* total_segments,
-                              long max_segments, float* radiance, float* t_vals, rtxn_stream_t stream);
+                              const float* seg_view, const int* total_segments, long max_segments,
+                              float* radiance, float* t_vals, rtxn_stream_t stream);
 
 #ifdef __cplusplus
 }

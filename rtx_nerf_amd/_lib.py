@@ -12,7 +12,8 @@ import os
 import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtxn.so")
+# RTXN_LIB_PATH: load an alternative build of the same ABI (kernel A/B experiments in tools/)
+LIB_PATH = os.environ.get("RTXN_LIB_PATH") or os.path.join(_HERE, "librtxn.so")
 
 RTXN_OK = 0
 
@@ -49,6 +50,7 @@ class TraceParams(C.Structure):
         ("t_start", C.c_void_p),
         ("t_end", C.c_void_p),
         ("seg_ray", C.c_void_p),
+        ("seg_view", C.c_void_p),
         ("segment_capacity", C.c_long),
     ]
 
@@ -81,7 +83,7 @@ SYMBOLS = {
     "rtxn_mlp_set_params": (_I, [_P, _P, _P]),
     "rtxn_mlp_forward": (_I, [_P, _P, _P, _L, _P]),
     "rtxn_mlp_forward_radiance": (_I, [_P, _P, _P, _L, _P]),
-    "rtxn_mlp_forward_segments": (_I, [_P, _P, _P, _P, _P, _P, _L, _P, _P, _P]),
+    "rtxn_mlp_forward_segments": (_I, [_P, _P, _P, _P, _P, _L, _P, _P, _P]),
 }
 
 _lib = None

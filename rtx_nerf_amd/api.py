@@ -44,7 +44,7 @@ def trace_grid(look_at=None, focal_length=1.0, aspect_ratio=1.0, width=0, height
                rays_o=None, rays_d=None, ray_begin=0, ray_count=None, occupancy=None,
                occupancy_coarse=None, mode=TRACE_COMPAT, ray_origins=None, viewing_direction=None,
                num_hits=None, intersection_arr_size=0, indices=None, start_points=None,
-               end_points=None, t_start=None, t_end=None, seg_ray=None, segment_capacity=0,
+               end_points=None, t_start=None, t_end=None, seg_ray=None, seg_view=None, segment_capacity=0,
                window_chunk=0, window_stride=0):
     """optixLaunch(pipeline_ray_march, ..., width, height, 1) with Params (main.cu:481-508)."""
     p = TraceParams()
@@ -71,6 +71,7 @@ def trace_grid(look_at=None, focal_length=1.0, aspect_ratio=1.0, width=0, height
     p.t_start = _ptr(t_start, torch.float32, "t_start")
     p.t_end = _ptr(t_end, torch.float32, "t_end")
     p.seg_ray = _ptr(seg_ray, torch.int32, "seg_ray")
+    p.seg_view = _ptr(seg_view, torch.float32, "seg_view")
     p.segment_capacity = segment_capacity
     p.window_chunk, p.window_stride = window_chunk, window_stride
     check(_lib.lib().rtxn_trace_grid(C.byref(p), _stream()), "rtxn_trace_grid")
@@ -154,8 +155,8 @@ class Network:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
-            _lib.lib().rtxn_mlp_destroy(h)
+        if h and _lib is not None and getattr(_lib, "_lib", None) is not None:   # not during interpreter shutdown
+            _lib._lib.rtxn_mlp_destroy(h)
 
     def n_params(self):
         return int(_lib.lib().rtxn_mlp_n_params(self._h))
@@ -204,12 +205,12 @@ class Network:
               "rtxn_mlp_forward_radiance")
         return radiance
 
-    def forward_segments(self, start_points, end_points, view_dirs, seg_ray, total_segments, max_segments,
-                         radiance, t_vals=None):
+    def forward_segments(self, start_points, end_points, seg_view, total_segments, max_segments, radiance,
+                         t_vals=None):
         """launchSampler(REGULAR) + forward + glue fused over packed segments."""
         check(_lib.lib().rtxn_mlp_forward_segments(
             self._h, _ptr(start_points, torch.float32, "start_points"), _ptr(end_points, torch.float32, "end_points"),
-            _ptr(view_dirs, torch.float32, "view_dirs"), _ptr(seg_ray, torch.int32, "seg_ray"),
-            _ptr(total_segments, torch.int32, "total_segments"), max_segments, _ptr(radiance, torch.float32, "radiance"),
-            _ptr(t_vals, torch.float32, "t_vals"), _stream()), "rtxn_mlp_forward_segments")
+            _ptr(seg_view, torch.float32, "seg_view"), _ptr(total_segments, torch.int32, "total_segments"),
+            max_segments, _ptr(radiance, torch.float32, "radiance"), _ptr(t_vals, torch.float32, "t_vals"), _stream()),
+            "rtxn_mlp_forward_segments")
         return radiance

@@ -69,8 +69,7 @@ struct FwdArgs {
   // IN_MODE 1
   const float* start;
   const float* end;
-  const float* view_dirs;
-  const int* seg_ray;
+  const float* seg_view;
   const int* total_segments;
   long max_segments;
   // outputs
@@ -193,14 +192,28 @@ __device__ __forceinline__ void layer_mma(const uint8_t* lds_buf, const half8 (&
       for (int e = 0; e < 16; ++e) acc[ct][e] = 0.0f;
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
+#ifdef RTXN_ABLATE_DSREAD
+      half8 a = bf[kk][0];
+#else
       const half8 a = *reinterpret_cast<const half8*>(lds_buf + ((rt * KS + kk) * 64 + lane) * 16);
+#endif
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[kk][ct], acc[ct], 0, 0, 0);
     }
+#ifdef RTXN_ABLATE_CONVERT
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        asm volatile("" ::"v"(acc[ct]));
+        nbf[2 * rt + s][ct] = bf[2 * rt + s][ct];
+      }
+#else
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) nbf[2 * rt + s][ct] = relu_pack(acc[ct], s);
+#endif
   }
 }
 
@@ -279,46 +292,62 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
   stage<L0_BYTES>(a.packed, smem, tid);
   int q = 0;  // global stage counter: buffer = q & 1
 
-  for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    // ---- inputs of this wave's two column tiles -> first-layer B fragments ----
-    half8 bf[NB][2];
-    bool valid[2];
-    long samp[2];
+  // Inputs are fetched ONE TILE AHEAD: the loads for tile t+1 are issued right after tile t's
+  // encoding and have the whole layer stack of tile t to land (the first barrier drains them).
+  float xin[2][5];
+  bool valid_n[2];
+  long samp_n[2];
+  auto load_inputs = [&](long tile) {
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
-      float x[5];
       if (IN_MODE == 1) {
         const long seg = tile * 8 + wave * 2 + ct;
-        valid[ct] = seg < total_seg;
-        samp[ct] = seg * 32 + col;
-        const long sg = valid[ct] ? seg : 0;
-        const int ray = a.seg_ray[sg];
-        const float inc = 1.0f / 32;
-        const float t = (float)col * inc;
+        valid_n[ct] = seg < total_seg;
+        samp_n[ct] = seg * 32 + col;
+        const long sg = valid_n[ct] ? seg : 0;
+        const float t = (float)col * (1.0f / 32);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           const float og = a.start[3 * sg + c];
-          x[c] = fmaf(t, a.end[3 * sg + c] - og, og);
+          xin[ct][c] = fmaf(t, a.end[3 * sg + c] - og, og);   // REGULAR sample, sampler.cu:52-66
         }
-        x[3] = a.view_dirs[2 * (long)ray];
-        x[4] = a.view_dirs[2 * (long)ray + 1];
-        if (a.t_vals && valid[ct] && h == 0) a.t_vals[samp[ct]] = (float)(col + 1) * inc;
+        xin[ct][3] = a.seg_view[2 * sg];
+        xin[ct][4] = a.seg_view[2 * sg + 1];
       } else {
-        samp[ct] = tile * kTileSamples + wave * 64 + ct * 32 + col;
-        valid[ct] = samp[ct] < a.n;
-        const long sidx = valid[ct] ? samp[ct] : 0;
+        samp_n[ct] = tile * kTileSamples + wave * 64 + ct * 32 + col;
+        valid_n[ct] = samp_n[ct] < a.n;
+        const long sidx = valid_n[ct] ? samp_n[ct] : 0;
 #pragma unroll
-        for (int c = 0; c < 5; ++c) x[c] = a.input[5 * sidx + c];
+        for (int c = 0; c < 5; ++c) xin[ct][c] = a.input[5 * sidx + c];
       }
-      const float phase = 0.25f * (float)h;
+    }
+  };
+  load_inputs(blockIdx.x);
+
+  for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // ---- this wave's two column tiles -> first-layer B fragments ----
+    half8 bf[NB][2];
+    bool valid[2];
+    long samp[2];
+    const float phase = 0.25f * (float)h;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      valid[ct] = valid_n[ct];
+      samp[ct] = samp_n[ct];
 #pragma unroll
       for (int kk = 0; kk < KS0; ++kk) {
         half8 v;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = encode_slot<ES, PD, PF, DD, DF>(8 * kk + j, x, phase);
+#ifdef RTXN_ABLATE_ENCODE
+        for (int j = 0; j < 8; ++j) v[j] = (_Float16)(xin[ct][j % 5] + phase);
+#else
+        for (int j = 0; j < 8; ++j) v[j] = encode_slot<ES, PD, PF, DD, DF>(8 * kk + j, xin[ct], phase);
+#endif
         bf[kk][ct] = v;
       }
+      if (IN_MODE == 1 && a.t_vals && valid[ct] && h == 0) a.t_vals[samp[ct]] = (float)(col + 1) * (1.0f / 32);
     }
+    if (tile + gridDim.x < n_tiles) load_inputs(tile + gridDim.x);
 
     // ---- layers ----  (two fragment sets used ping-pong: no register copies between layers)
     half8 bg[NB][2];
@@ -326,7 +355,9 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
     auto begin_stage = [&](int l) -> const uint8_t* {
       const uint8_t* cur = smem + (q & 1) * BUF;
       uint8_t* nxt = smem + ((q + 1) & 1) * BUF;
+#ifndef RTXN_ABLATE_BARRIER
       __syncthreads();  // stage q landed (hipcc drains vmcnt before the barrier); buffer nxt is free
+#endif
       if (l + 1 < n_layers) {
         if (l + 1 == n_layers - 1) stage<OUT_BYTES>(a.packed + layer_off(l + 1), nxt, tid);
         else stage<HID_BYTES>(a.packed + layer_off(l + 1), nxt, tid);
@@ -591,22 +622,21 @@ extern "C" int rtxn_mlp_forward_radiance(const rtxn_mlp* m, const float* input, 
 }
 
 extern "C" int rtxn_mlp_forward_segments(const rtxn_mlp* m, const float* start_points, const float* end_points,
-                                         const float* view_dirs, const int* seg_ray, const int* total_segments,
-                                         long max_segments, float* radiance, float* t_vals, rtxn_stream_t stream) {
+                                         const float* seg_view, const int* total_segments, long max_segments,
+                                         float* radiance, float* t_vals, rtxn_stream_t stream) {
   int rc = check_ready(m, "rtxn_mlp_forward_segments");
   if (rc != RTXN_OK) return rc;
   RTXN_REQUIRE(max_segments >= 0, "rtxn_mlp_forward_segments: max_segments = %ld < 0", max_segments);
   RTXN_DEVICE_OR_FAIL();
   if (max_segments == 0) return RTXN_OK;
-  RTXN_REQUIRE(start_points && end_points && view_dirs && seg_ray && total_segments && radiance,
+  RTXN_REQUIRE(start_points && end_points && seg_view && total_segments && radiance,
                "rtxn_mlp_forward_segments: NULL buffer");
   RTXN_REQUIRE(((uintptr_t)radiance & 15) == 0, "rtxn_mlp_forward_segments: radiance must be 16-byte aligned");
   FwdArgs a;
   memset(&a, 0, sizeof(a));
   a.start = start_points;
   a.end = end_points;
-  a.view_dirs = view_dirs;
-  a.seg_ray = seg_ray;
+  a.seg_view = seg_view;
   a.total_segments = total_segments;
   a.max_segments = max_segments;
   a.radiance = reinterpret_cast<float4*>(radiance);

@@ -55,7 +55,7 @@ class RenderPipeline:
         d, m = self.dev, self.max_segments
         self.start = torch.empty((m, 3), device=d)
         self.end = torch.empty((m, 3), device=d)
-        self.seg_ray = torch.empty(m, dtype=torch.int32, device=d)
+        self.seg_view = torch.empty((m, 2), device=d)
         self.radiance = torch.empty((m * api.NUM_SAMPLES_PER_SEGMENT, 4), device=d)
         self.t_vals = torch.empty(m * api.NUM_SAMPLES_PER_SEGMENT, device=d)
 
@@ -68,7 +68,7 @@ class RenderPipeline:
                   occupancy_coarse=self.coarse, mode=self.trace_mode, viewing_direction=self.view_dirs,
                   num_hits=self.num_hits, window_chunk=self.window[0], window_stride=self.window[1])
         if write:
-            kw.update(indices=self.indices, start_points=self.start, end_points=self.end, seg_ray=self.seg_ray,
+            kw.update(indices=self.indices, start_points=self.start, end_points=self.end, seg_view=self.seg_view,
                       segment_capacity=self.max_segments)
         api.trace_grid(self.look_at, self.focal, self.aspect, self.W, self.H, **kw)
 
@@ -100,7 +100,7 @@ class RenderPipeline:
         self._trace(ray_begin, n, write=False)
         api.scan_hits(nh, idx, self.total, self.scan_ws)
         self._trace(ray_begin, n, write=True)
-        self.net.forward_segments(self.start, self.end, self.view_dirs, self.seg_ray, self.total,
+        self.net.forward_segments(self.start, self.end, self.seg_view, self.total,
                                   self.max_segments, self.radiance, self.t_vals)
         # rays whose segments would overflow the capacity are truncated on the device (never out of bounds)
         nhc = self.num_hits_c[:n]

@@ -163,7 +163,8 @@ def test_trace_window_and_packed_two_pass(gpu, oracle):
     sp = torch.full((P, 3), -2.0, device="cuda")
     ep = torch.full((P, 3), -2.0, device="cuda")
     sr = torch.full((P,), -1, dtype=torch.int32, device="cuda")
-    api.trace_grid(la_d, f, 1.0, W, H, indices=idx, start_points=sp, end_points=ep, seg_ray=sr,
+    sv = torch.full((P, 2), -9.0, device="cuda")
+    api.trace_grid(la_d, f, 1.0, W, H, indices=idx, start_points=sp, end_points=ep, seg_ray=sr, seg_view=sv,
                    segment_capacity=cap, **kw)
     torch.cuda.synchronize()
     np.testing.assert_array_equal(nh.cpu().numpy(), want["num_hits"])
@@ -171,7 +172,9 @@ def test_trace_window_and_packed_two_pass(gpu, oracle):
     np.testing.assert_array_equal(sp.cpu().numpy()[:cap], want["start"][:cap])
     np.testing.assert_array_equal(ep.cpu().numpy()[:cap], want["end"][:cap])
     np.testing.assert_array_equal(sr.cpu().numpy()[:cap], want["seg_ray"][:cap])
+    np.testing.assert_array_equal(sv.cpu().numpy()[:cap], vd.cpu().numpy()[want["seg_ray"][:cap]])
     assert np.all(sp.cpu().numpy()[cap:] == -2.0) and np.all(sr.cpu().numpy()[cap:] == -1)
+    assert np.all(sv.cpu().numpy()[cap:] == -9.0)
 
 
 # ------------------------------------------------------------------ sampler
@@ -390,9 +393,9 @@ def test_mlp_forward_segments_equals_sampler_plus_forward(gpu, oracle):
     tv = torch.full((cap * 32,), -3.0, device="cuda")
     sp_d = _dev(torch, np.concatenate([sp[:P], np.zeros((13, 3), np.float32)]))
     ep_d = _dev(torch, np.concatenate([ep[:P], np.zeros((13, 3), np.float32)]))
-    sr_d = _dev(torch, np.concatenate([seg_ray, np.zeros(13, np.int32)]))
+    sv_d = _dev(torch, np.concatenate([vd[seg_ray], np.zeros((13, 2), np.float32)]))
     total = torch.tensor([P], dtype=torch.int32, device="cuda")
-    net.forward_segments(sp_d, ep_d, _dev(torch, vd), sr_d, total, cap, rad, tv)
+    net.forward_segments(sp_d, ep_d, sv_d, total, cap, rad, tv)
     torch.cuda.synchronize()
     # same samples as the standalone sampler (bit-exact), then the same network
     samples, t_vals = oracle.sample(sp[:P], ep[:P], vd, nh, idx, 0)

