@@ -8,7 +8,7 @@ HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -Iincl
 
 all: rtx_nerf_amd/librtxn.so oracle examples/render_host
 
-build/%.o: $(CSRC)/%.hip $(CSRC)/common.h include/rtxn.h
+build/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/mlp_internal.h include/rtxn.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 

@@ -170,6 +170,10 @@ int rtxn_volrender_bwd(const float* loss_values, const void* loss_gradients,
  * n_pos_freqs), Frequency(n_dir_dims, n_dir_freqs)) -> n_hidden_layers x
  * n_neurons ReLU -> 16 (n_output_dims used), fp16 weights, no biases. */
 enum rtxn_activation { RTXN_ACT_NONE = 0, RTXN_ACT_SIGMOID = 1 };
+enum rtxn_encoding {
+  RTXN_ENC_FREQUENCY = 0, /* Composite(Frequency, Frequency) computed inside the kernels (main.cu:47-61) */
+  RTXN_ENC_EXTERNAL = 1   /* the caller encodes (e.g. rtxn_hashgrid_encode); only the rtxn_mlp_train_* entry points apply */
+};
 
 typedef struct rtxn_mlp_config {
   int n_pos_dims, n_pos_freqs;   /* 3, 10 (main.cu:52-54) */
@@ -178,6 +182,8 @@ typedef struct rtxn_mlp_config {
   int n_hidden_layers;           /* >= 1 (main.cu:67) */
   int n_output_dims;             /* <= 16 (main.cu:323) */
   int output_activation;         /* enum rtxn_activation (main.cu:65) */
+  int encoding;                  /* enum rtxn_encoding; 0 = the reference's Composite-Frequency */
+  int n_encoded_features;        /* RTXN_ENC_EXTERNAL only: width of the pre-encoded input, multiple of 16 */
 } rtxn_mlp_config;
 
 typedef struct rtxn_mlp rtxn_mlp;
@@ -212,6 +218,55 @@ int rtxn_mlp_forward_radiance(const rtxn_mlp* m, const float* input, float* radi
 int rtxn_mlp_forward_segments(const rtxn_mlp* m, const float* start_points, const float* end_points,
                               const float* seg_view, const int* total_segments, long max_segments,
                               float* radiance, float* t_vals, rtxn_stream_t stream);
+
+/* ---- training path (tiny-cuda-nn surface of main.cu:721-787) ------------------------ */
+/* Per-sample training tensors are FEATURE-MAJOR fp16: X[feature][S_pad] with
+ * S_pad = rtxn_padded_samples(S) (S rounded up to 256), padding columns zero. */
+long rtxn_padded_samples(long n_samples);
+
+/* Encoders: input float[S][5] (x,y,z in [-1,1]; theta,phi) -> encT half[E][S_pad]. */
+int rtxn_encode_frequency(const rtxn_mlp* m, const float* input, void* encT, long n_samples, rtxn_stream_t stream);
+
+/* Multiresolution hash grid (Mueller et al. 2022, tcnn "HashGrid") for the position, composed
+ * with Frequency(n_dir_freqs) for the view direction; width padded to 16 with ones. */
+typedef struct rtxn_hashgrid_config {
+  int n_levels;            /* <= 16 */
+  int n_features;          /* per level: 1, 2, 4 or 8 */
+  int log2_hashmap_size;   /* table entries per level = min(dense level size, 2^this) */
+  int base_resolution;
+  float per_level_scale;
+} rtxn_hashgrid_config;
+typedef struct rtxn_hashgrid rtxn_hashgrid;
+int rtxn_hashgrid_create(const rtxn_hashgrid_config* cfg, rtxn_hashgrid** out);
+int rtxn_hashgrid_destroy(rtxn_hashgrid* g);
+long rtxn_hashgrid_n_params(const rtxn_hashgrid* g);                 /* fp16 table entries */
+int rtxn_hashgrid_encoded_width(const rtxn_hashgrid* g, int n_dir_freqs);
+int rtxn_hashgrid_encode(const rtxn_hashgrid* g, int n_dir_freqs, const void* table_fp16, const float* input,
+                         void* encT, long n_samples, rtxn_stream_t stream);
+/* dtable (fp32, table layout) += scatter of dencT; the caller zeroes dtable per step. */
+int rtxn_hashgrid_backward(const rtxn_hashgrid* g, const float* input, const void* dencT, long n_samples,
+                           float* dtable, rtxn_stream_t stream);
+
+/* network->forward with saved activations (main.cu:721).  workspace: at least
+ * rtxn_mlp_train_workspace_bytes(m, S) bytes, shared with the backward call.
+ * output_half: half[S][16]; radiance: float[S][4] or NULL (the glue of main.cu:723-728). */
+size_t rtxn_mlp_train_workspace_bytes(const rtxn_mlp* m, long n_samples);
+int rtxn_mlp_train_forward(const rtxn_mlp* m, const void* encT, long n_samples, void* workspace,
+                           void* output_half, float* radiance, rtxn_stream_t stream);
+/* network->backward (main.cu:781).  dout_half4: half[S][4], the layout
+ * launch_volrender_backward_cuda writes (stride 4; output rows 4..15 carry no gradient).
+ * dparams: float[n_params] in the tcnn parameter layout, ACCUMULATED into (zero it per step);
+ * dencT: half[E][S_pad] gradient w.r.t. the encoded input, or NULL. */
+int rtxn_mlp_train_backward(const rtxn_mlp* m, const void* encT, const void* output_half, const void* dout_half4,
+                            long n_samples, void* workspace, float* dparams, void* dencT, rtxn_stream_t stream);
+
+/* loss->evaluate (tcnn "L2", main.cu:36-38,759): values[i] = d^2/n, grads[i] = loss_scale*2d/n (half),
+ * *loss_sum (device float) = sum of values.  values/grads/loss_sum may each be NULL. */
+int rtxn_l2_loss(const float* pred, const float* target, long n, float loss_scale, float* values, void* grads_half,
+                 float* loss_sum, rtxn_stream_t stream);
+/* optimizer->step (tcnn "Adam", main.cu:40-46,787): fp32 master weights + fp16 copy, fp32 gradients. */
+int rtxn_adam_step(long n, float* master, void* params_fp16, const float* grads, float* m, float* v, int step,
+                   float lr, float beta1, float beta2, float eps, float loss_scale, rtxn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -222,3 +222,87 @@ def volrender_bwd_nerf(loss_gradients_f16, radiance, step, num_hits, indices, K=
     out = np.zeros((st.size, 4), np.float32)
     lib().orc_volrender_bwd_nerf(_p(lg), _p(rad), _p(st), _p(nh), _p(idx), C.c_int(nh.size), C.c_int(K), _p(out))
     return out
+
+
+# --------------------------------------------------------------------------- training path
+class HgCfg(C.Structure):
+    _fields_ = [("n_levels", C.c_int), ("n_features", C.c_int), ("log2_hashmap_size", C.c_int),
+                ("base_resolution", C.c_int), ("per_level_scale", C.c_float)]
+
+
+def hg_cfg(n_levels=16, n_features=2, log2_hashmap_size=19, base_resolution=16, per_level_scale=1.5):
+    return HgCfg(n_levels, n_features, log2_hashmap_size, base_resolution, per_level_scale)
+
+
+def hg_n_params(cfg):
+    lib().orc_hg_n_params.restype = C.c_long
+    return int(lib().orc_hg_n_params(C.byref(cfg)))
+
+
+def hg_enc_width(cfg, n_dir_freqs):
+    return int(lib().orc_enc_hg_width(C.byref(cfg), C.c_int(n_dir_freqs)))
+
+
+def encode_hg(cfg, n_dir_freqs, table_f16, in5):
+    x = _f32(in5).reshape(-1, 5)
+    t = np.ascontiguousarray(table_f16, dtype=np.float16)
+    out = np.zeros((x.shape[0], hg_enc_width(cfg, n_dir_freqs)), np.float16)
+    lib().orc_encode_hg(C.byref(cfg), C.c_int(n_dir_freqs), _p(t), _p(x), C.c_long(x.shape[0]), _p(out))
+    return out
+
+
+def hg_backward(cfg, in5, denc_f16):
+    x = _f32(in5).reshape(-1, 5)
+    d = np.ascontiguousarray(denc_f16, dtype=np.float16)
+    out = np.zeros(hg_n_params(cfg), np.float32)
+    lib().orc_hg_backward(C.byref(cfg), _p(x), C.c_long(x.shape[0]), _p(d), C.c_int(d.shape[1]), _p(out))
+    return out
+
+
+def encode_freq(cfg, in5):
+    x = _f32(in5).reshape(-1, 5)
+    out = np.zeros((x.shape[0], mlp_enc_padded(cfg)), np.float16)
+    lib().orc_encode_freq(C.byref(cfg), _p(x), C.c_long(x.shape[0]), _p(out))
+    return out
+
+
+def mlpe_forward(W, L, out_act, params_f16, enc_f16):
+    e = np.ascontiguousarray(enc_f16, dtype=np.float16)
+    S, E = e.shape
+    p = np.ascontiguousarray(params_f16, dtype=np.float16)
+    assert p.size == W * E + (L - 1) * W * W + 16 * W
+    acts = np.zeros((L, S, W), np.float16)
+    out = np.zeros((S, 16), np.float16)
+    lib().orc_mlpe_forward(C.c_int(W), C.c_int(L), C.c_int(E), C.c_int(out_act), _p(p), _p(e), C.c_long(S), _p(acts), _p(out))
+    return acts, out
+
+
+def mlpe_backward(W, L, out_act, params_f16, enc_f16, acts, out, dout_f16, want_denc=True):
+    e = np.ascontiguousarray(enc_f16, dtype=np.float16)
+    S, E = e.shape
+    p = np.ascontiguousarray(params_f16, dtype=np.float16)
+    do = np.ascontiguousarray(dout_f16, dtype=np.float16).reshape(S, 4)
+    dparams = np.zeros(p.size, np.float32)
+    denc = np.zeros((S, E), np.float32) if want_denc else None
+    lib().orc_mlpe_backward(C.c_int(W), C.c_int(L), C.c_int(E), C.c_int(out_act), _p(p), _p(e),
+                            _p(np.ascontiguousarray(acts)), _p(np.ascontiguousarray(out)), _p(do), C.c_long(S),
+                            _p(dparams), _p(denc))
+    return dparams, denc
+
+
+def l2_loss(pred, target, scale=1.0):
+    pr, tg = _f32(pred).reshape(-1), _f32(target).reshape(-1)
+    values = np.zeros_like(pr)
+    g16 = np.zeros(pr.size, np.float16)
+    g32 = np.zeros(pr.size, np.float32)
+    lib().orc_l2_loss.restype = C.c_double
+    tot = lib().orc_l2_loss(_p(pr), _p(tg), C.c_long(pr.size), C.c_float(scale), _p(values), _p(g16), _p(g32))
+    return float(tot), values, g16, g32
+
+
+def adam_step(master, grads, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, loss_scale=1.0):
+    """in-place on master/m/v (float32 arrays); returns the fp16 copy."""
+    p16 = np.zeros(master.size, np.float16)
+    lib().orc_adam_step(C.c_long(master.size), _p(master), _p(p16), _p(_f32(grads)), _p(m), _p(v), C.c_int(step),
+                        C.c_float(lr), C.c_float(beta1), C.c_float(beta2), C.c_float(eps), C.c_float(loss_scale))
+    return p16

@@ -736,3 +736,259 @@ void orc_volrender_bwd_nerf(const uint16_t* loss_gradients, const float* radianc
     }
   }
 }
+
+/* ========================================================================= */
+/* TRAINING PATH                                                              */
+/* Reference call sites: loss->evaluate (main.cu:759), network->backward       */
+/* (:781), optimizer->step (:787), all inside tiny-cuda-nn (un-vendored,       */
+/* unpinned): restated from the published algorithms.  PARITY UNPINNED.        */
+/* ========================================================================= */
+
+/* ---- multiresolution hash grid (Mueller et al. 2022; tcnn "HashGrid") ---- */
+typedef struct {
+  int n_levels, n_features, log2_hashmap_size, base_resolution;
+  float per_level_scale;
+} orc_hg_cfg;
+
+static void hg_level(const orc_hg_cfg* c, int l, float* scale, unsigned* res, unsigned* size, unsigned* offset) {
+  /* scale_l = base * per_level_scale^l - 1 ; res_l = ceil(scale_l) + 1 ;
+   * params_l = min(res_l^3 rounded up to 8, 2^log2_hashmap_size) */
+  unsigned off = 0;
+  for (int i = 0; i <= l; ++i) {
+    float s = exp2f((float)i * log2f(c->per_level_scale)) * (float)c->base_resolution - 1.0f;
+    unsigned r = (unsigned)ceilf(s) + 1u;
+    unsigned long long dense = (unsigned long long)r * r * r;
+    dense = (dense + 7ull) / 8ull * 8ull;
+    unsigned long long cap = 1ull << c->log2_hashmap_size;
+    unsigned sz = (unsigned)(dense < cap ? dense : cap);
+    if (i == l) { *scale = s; *res = r; *size = sz; *offset = off; }
+    off += sz;
+  }
+}
+
+long orc_hg_n_params(const orc_hg_cfg* c) {
+  float s = 0; unsigned r = 0, sz = 0, off = 0;
+  hg_level(c, c->n_levels - 1, &s, &r, &sz, &off);
+  return ((long)off + sz) * c->n_features;
+}
+
+static inline unsigned hg_index(unsigned x, unsigned y, unsigned z, unsigned res, unsigned size) {
+  unsigned long long dense = (unsigned long long)res * res * res;
+  if (dense <= size) return x + y * res + z * res * res;          /* dense level */
+  return ((x * 1u) ^ (y * 2654435761u) ^ (z * 805459861u)) % size; /* coherent prime hash */
+}
+
+/* xyz01: position in [0,1]^3.  table: fp16 bits [n_params].  out: n_levels*n_features floats (fp16-rounded). */
+void orc_hg_encode_one(const orc_hg_cfg* c, const uint16_t* table, const float* xyz01, float* out) {
+  for (int l = 0; l < c->n_levels; ++l) {
+    float scale = 0; unsigned res = 0, size = 0, off = 0;
+    hg_level(c, l, &scale, &res, &size, &off);
+    float pos[3], fr[3]; unsigned g[3];
+    for (int a = 0; a < 3; ++a) {
+      pos[a] = fmaf(xyz01[a], scale, 0.5f);
+      float fl = floorf(pos[a]);
+      g[a] = (unsigned)(int)fl;
+      fr[a] = pos[a] - fl;
+    }
+    for (int f = 0; f < c->n_features; ++f) {
+      float acc = 0.0f;
+      for (int corner = 0; corner < 8; ++corner) {
+        float w = 1.0f; unsigned p[3];
+        for (int a = 0; a < 3; ++a) {
+          int hi = (corner >> a) & 1;
+          w *= hi ? fr[a] : 1.0f - fr[a];
+          p[a] = g[a] + (unsigned)hi;
+        }
+        unsigned idx = hg_index(p[0], p[1], p[2], res, size);
+        acc = fmaf(w, orc_f16_bits_to_f32(table[((size_t)off + idx) * c->n_features + f]), acc);
+      }
+      out[l * c->n_features + f] = rh(acc);
+    }
+  }
+}
+
+/* Composite training encoding: HashGrid(xyz mapped from [-1,1] to [0,1]) (+) Frequency(dirs, n_dir_freqs),
+ * padded with ones to a multiple of 16.  in: [S][5]; out: fp16 bits [S][E]. */
+int orc_enc_hg_width(const orc_hg_cfg* c, int n_dir_freqs) {
+  int w = c->n_levels * c->n_features + 2 * 2 * n_dir_freqs;
+  return (w + 15) / 16 * 16;
+}
+
+void orc_encode_hg(const orc_hg_cfg* c, int n_dir_freqs, const uint16_t* table, const float* in5, long S, uint16_t* out) {
+  int E = orc_enc_hg_width(c, n_dir_freqs), nh = c->n_levels * c->n_features;
+#pragma omp parallel for schedule(static)
+  for (long s = 0; s < S; ++s) {
+    float tmp[64];
+    float x01[3] = {fmaf(in5[5 * s], 0.5f, 0.5f), fmaf(in5[5 * s + 1], 0.5f, 0.5f), fmaf(in5[5 * s + 2], 0.5f, 0.5f)};
+    orc_hg_encode_one(c, table, x01, tmp);
+    uint16_t* o = out + s * E;
+    int j = 0;
+    for (; j < nh; ++j) o[j] = orc_f32_to_f16_bits(tmp[j]);
+    for (int d = 0; d < 2; ++d)
+      for (int f = 0; f < n_dir_freqs; ++f)
+        for (int ph = 0; ph < 2; ++ph) {
+          double arg = M_PI * ldexp((double)in5[5 * s + 3 + d], f) + ph * (M_PI / 2);
+          o[j++] = orc_f32_to_f16_bits((float)sin(arg));
+        }
+    for (; j < E; ++j) o[j] = orc_f32_to_f16_bits(1.0f);
+  }
+}
+
+/* hash-grid backward: dtable[idx][f] += w * denc[s][l*F+f]; double accumulation -> float out */
+void orc_hg_backward(const orc_hg_cfg* c, const float* in5, long S, const uint16_t* denc, int E, float* dtable) {
+  long np_ = orc_hg_n_params(c);
+  double* acc = (double*)calloc((size_t)np_, sizeof(double));
+  for (long s = 0; s < S; ++s) {
+    float x01[3] = {fmaf(in5[5 * s], 0.5f, 0.5f), fmaf(in5[5 * s + 1], 0.5f, 0.5f), fmaf(in5[5 * s + 2], 0.5f, 0.5f)};
+    for (int l = 0; l < c->n_levels; ++l) {
+      float scale = 0; unsigned res = 0, size = 0, off = 0;
+      hg_level(c, l, &scale, &res, &size, &off);
+      float fr[3]; unsigned g[3];
+      for (int a = 0; a < 3; ++a) {
+        float p = fmaf(x01[a], scale, 0.5f), fl = floorf(p);
+        g[a] = (unsigned)(int)fl; fr[a] = p - fl;
+      }
+      for (int corner = 0; corner < 8; ++corner) {
+        float w = 1.0f; unsigned p[3];
+        for (int a = 0; a < 3; ++a) { int hi = (corner >> a) & 1; w *= hi ? fr[a] : 1.0f - fr[a]; p[a] = g[a] + (unsigned)hi; }
+        unsigned idx = hg_index(p[0], p[1], p[2], res, size);
+        for (int f = 0; f < c->n_features; ++f)
+          acc[((size_t)off + idx) * c->n_features + f] += (double)w * orc_f16_bits_to_f32(denc[s * E + l * c->n_features + f]);
+      }
+    }
+  }
+  for (long i = 0; i < np_; ++i) dtable[i] = (float)acc[i];
+  free(acc);
+}
+
+/* Frequency composite as a standalone encoder: [S][5] -> fp16 bits [S][enc_padded] */
+void orc_encode_freq(const orc_mlp_cfg* c, const float* in5, long S, uint16_t* out) {
+  int P = orc_mlp_enc_padded(c);
+#pragma omp parallel for schedule(static)
+  for (long s = 0; s < S; ++s) {
+    float tmp[256];
+    orc_freq_encode(c, in5 + 5 * s, tmp);
+    for (int j = 0; j < P; ++j) out[s * P + j] = orc_f32_to_f16_bits(tmp[j]);
+  }
+}
+
+/* ---- MLP on pre-encoded input, with saved activations ---- */
+/* enc: fp16 bits [S][E]; params: tcnn layout with first layer [W][E]; acts: fp16 bits [L][S][W]
+ * (post-ReLU, sample-major here; the HIP side keeps its own layout); out: fp16 bits [S][16]. */
+long orc_mlpe_n_params(int W, int L, int E) { return (long)W * E + (long)(L - 1) * W * W + 16L * W; }
+
+void orc_mlpe_forward(int W, int L, int E, int out_act, const uint16_t* params, const uint16_t* enc, long S,
+                      uint16_t* acts, uint16_t* out) {
+  long np_ = orc_mlpe_n_params(W, L, E);
+  float* wf = (float*)malloc(sizeof(float) * np_);
+  for (long i = 0; i < np_; ++i) wf[i] = orc_f16_bits_to_f32(params[i]);
+#pragma omp parallel for schedule(static)
+  for (long s = 0; s < S; ++s) {
+    float a[256], b[256];
+    for (int k = 0; k < E; ++k) a[k] = orc_f16_bits_to_f32(enc[s * E + k]);
+    const float* w = wf;
+    int in_w = E;
+    float *pa = a, *pb = b;
+    for (int l = 0; l < L; ++l) {
+      for (int r = 0; r < W; ++r) {
+        float acc = 0.0f;
+        for (int k = 0; k < in_w; ++k) acc = fmaf(w[(long)r * in_w + k], pa[k], acc);
+        pb[r] = rh(acc > 0.0f ? acc : 0.0f);
+        if (acts) acts[((long)l * S + s) * W + r] = orc_f32_to_f16_bits(pb[r]);
+      }
+      w += (long)W * in_w; in_w = W;
+      float* t = pa; pa = pb; pb = t;
+    }
+    for (int r = 0; r < 16; ++r) {
+      float acc = 0.0f;
+      for (int k = 0; k < W; ++k) acc = fmaf(w[(long)r * W + k], pa[k], acc);
+      float y = out_act == 1 ? 1.0f / (1.0f + expf(-acc)) : acc;
+      out[s * 16 + r] = orc_f32_to_f16_bits(y);
+    }
+  }
+  free(wf);
+}
+
+/* Backward.  dout: fp16 bits [S][4] (rows 4..15 of the output carry no gradient), the layout
+ * launch_volrender_backward_cuda writes (vol_render.cu:136-139).  dparams: fp32 [n_params] (double
+ * accumulation); denc: fp32 [S][E] or NULL.  Intermediate gradients are rounded to fp16 between layers
+ * as the fp16 backward pass does (dZ_l stored in half). */
+void orc_mlpe_backward(int W, int L, int E, int out_act, const uint16_t* params, const uint16_t* enc,
+                       const uint16_t* acts, const uint16_t* out, const uint16_t* dout, long S, float* dparams,
+                       float* denc) {
+  long np_ = orc_mlpe_n_params(W, L, E);
+  float* wf = (float*)malloc(sizeof(float) * np_);
+  for (long i = 0; i < np_; ++i) wf[i] = orc_f16_bits_to_f32(params[i]);
+  double* dp = (double*)calloc((size_t)np_, sizeof(double));
+  long* loff = (long*)malloc(sizeof(long) * (L + 1));
+  loff[0] = 0;
+  for (int l = 1; l <= L; ++l) loff[l] = loff[l - 1] + (long)W * (l == 1 ? E : W);
+  for (long s = 0; s < S; ++s) {
+    float dz[256], da[256];
+    /* output layer */
+    float dzo[16];
+    for (int r = 0; r < 16; ++r) {
+      float g = r < 4 ? orc_f16_bits_to_f32(dout[s * 4 + r]) : 0.0f;
+      if (out_act == 1) { float y = orc_f16_bits_to_f32(out[s * 16 + r]); g = g * y * (1.0f - y); }
+      dzo[r] = rh(g);
+    }
+    const uint16_t* aprev = acts + ((long)(L - 1) * S + s) * W;
+    for (int r = 0; r < 16; ++r)
+      for (int k = 0; k < W; ++k) dp[loff[L] + (long)r * W + k] += (double)dzo[r] * orc_f16_bits_to_f32(aprev[k]);
+    for (int k = 0; k < W; ++k) {
+      float acc = 0.0f;
+      for (int r = 0; r < 16; ++r) acc = fmaf(wf[loff[L] + (long)r * W + k], dzo[r], acc);
+      da[k] = acc;
+    }
+    for (int l = L - 1; l >= 0; --l) {
+      const uint16_t* al = acts + ((long)l * S + s) * W;
+      for (int r = 0; r < W; ++r) dz[r] = rh(orc_f16_bits_to_f32(al[r]) > 0.0f ? da[r] : 0.0f);
+      int in_w = l == 0 ? E : W;
+      for (int r = 0; r < W; ++r) {
+        if (dz[r] == 0.0f) continue;
+        for (int k = 0; k < in_w; ++k) {
+          float x = l == 0 ? orc_f16_bits_to_f32(enc[s * E + k]) : orc_f16_bits_to_f32(acts[((long)(l - 1) * S + s) * W + k]);
+          dp[loff[l] + (long)r * in_w + k] += (double)dz[r] * x;
+        }
+      }
+      if (l > 0 || denc) {
+        for (int k = 0; k < in_w; ++k) {
+          float acc = 0.0f;
+          for (int r = 0; r < W; ++r) acc = fmaf(wf[loff[l] + (long)r * in_w + k], dz[r], acc);
+          if (l > 0) da[k] = acc; else denc[s * E + k] = acc;
+        }
+      }
+    }
+  }
+  for (long i = 0; i < np_; ++i) dparams[i] = (float)dp[i];
+  free(dp); free(wf); free(loff);
+}
+
+/* ---- L2 loss (tcnn "L2"; main.cu:36-38,759): values = d^2/n, grads = scale*2d/n, n = B*3 ---- */
+double orc_l2_loss(const float* pred, const float* target, long n, float scale, float* values, uint16_t* grads_f16,
+                   float* grads_f32) {
+  double sum = 0.0;
+  for (long i = 0; i < n; ++i) {
+    float d = pred[i] - target[i];
+    float v = d * d / (float)n;
+    float g = scale * 2.0f * d / (float)n;
+    if (values) values[i] = v;
+    if (grads_f16) grads_f16[i] = orc_f32_to_f16_bits(g);
+    if (grads_f32) grads_f32[i] = g;
+    sum += v;
+  }
+  return sum;
+}
+
+/* ---- Adam (tcnn "Adam"; main.cu:40-46,787) ---- */
+void orc_adam_step(long n, float* master, uint16_t* params_f16, const float* grads, float* m, float* v, int step,
+                   float lr, float beta1, float beta2, float eps, float loss_scale) {
+  float lr_eff = lr * sqrtf(1.0f - powf(beta2, (float)step)) / (1.0f - powf(beta1, (float)step));
+  for (long i = 0; i < n; ++i) {
+    float g = grads[i] / loss_scale;
+    m[i] = beta1 * m[i] + (1.0f - beta1) * g;
+    v[i] = beta2 * v[i] + (1.0f - beta2) * g * g;
+    master[i] -= lr_eff * m[i] / (sqrtf(v[i]) + eps);
+    params_f16[i] = orc_f32_to_f16_bits(master[i]);
+  }
+}

@@ -55,11 +55,17 @@ class TraceParams(C.Structure):
     ]
 
 
+class HashGridConfig(C.Structure):
+    """struct rtxn_hashgrid_config (include/rtxn.h)."""
+    _fields_ = [("n_levels", C.c_int), ("n_features", C.c_int), ("log2_hashmap_size", C.c_int),
+                ("base_resolution", C.c_int), ("per_level_scale", C.c_float)]
+
+
 class MlpConfig(C.Structure):
     """struct rtxn_mlp_config (include/rtxn.h)."""
     _fields_ = [(n, C.c_int) for n in (
         "n_pos_dims", "n_pos_freqs", "n_dir_dims", "n_dir_freqs",
-        "n_neurons", "n_hidden_layers", "n_output_dims", "output_activation")]
+        "n_neurons", "n_hidden_layers", "n_output_dims", "output_activation", "encoding", "n_encoded_features")]
 
 
 # every symbol include/rtxn.h declares: name -> (restype, argtypes)
@@ -84,6 +90,19 @@ SYMBOLS = {
     "rtxn_mlp_forward": (_I, [_P, _P, _P, _L, _P]),
     "rtxn_mlp_forward_radiance": (_I, [_P, _P, _P, _L, _P]),
     "rtxn_mlp_forward_segments": (_I, [_P, _P, _P, _P, _P, _L, _P, _P, _P]),
+    "rtxn_padded_samples": (_L, [_L]),
+    "rtxn_encode_frequency": (_I, [_P, _P, _P, _L, _P]),
+    "rtxn_hashgrid_create": (_I, [C.POINTER(HashGridConfig), C.POINTER(_P)]),
+    "rtxn_hashgrid_destroy": (_I, [_P]),
+    "rtxn_hashgrid_n_params": (_L, [_P]),
+    "rtxn_hashgrid_encoded_width": (_I, [_P, _I]),
+    "rtxn_hashgrid_encode": (_I, [_P, _I, _P, _P, _P, _L, _P]),
+    "rtxn_hashgrid_backward": (_I, [_P, _P, _P, _L, _P, _P]),
+    "rtxn_mlp_train_workspace_bytes": (C.c_size_t, [_P, _L]),
+    "rtxn_mlp_train_forward": (_I, [_P, _P, _L, _P, _P, _P, _P]),
+    "rtxn_mlp_train_backward": (_I, [_P, _P, _P, _P, _L, _P, _P, _P, _P]),
+    "rtxn_l2_loss": (_I, [_P, _P, _L, _F, _P, _P, _P, _P]),
+    "rtxn_adam_step": (_I, [_L, _P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _P]),
 }
 
 _lib = None

@@ -145,9 +145,10 @@ class Network:
     """tcnn::create_from_config(n_input_dims=5, n_output_dims=4, config) (main.cu:35-69,325)."""
 
     def __init__(self, n_neurons=128, n_hidden_layers=8, n_pos_freqs=10, n_dir_freqs=12, n_pos_dims=3,
-                 n_dir_dims=2, n_output_dims=4, output_activation=ACT_SIGMOID):
+                 n_dir_dims=2, n_output_dims=4, output_activation=ACT_SIGMOID, n_encoded_features=0):
+        """n_encoded_features > 0: the model takes pre-encoded input of that width (RTXN_ENC_EXTERNAL)."""
         self.cfg = MlpConfig(n_pos_dims, n_pos_freqs, n_dir_dims, n_dir_freqs, n_neurons, n_hidden_layers,
-                             n_output_dims, output_activation)
+                             n_output_dims, output_activation, 1 if n_encoded_features else 0, n_encoded_features)
         h = C.c_void_p()
         check(_lib.lib().rtxn_mlp_create(C.byref(self.cfg), C.byref(h)), "rtxn_mlp_create")
         self._h = h
@@ -214,3 +215,103 @@ class Network:
             max_segments, _ptr(radiance, torch.float32, "radiance"), _ptr(t_vals, torch.float32, "t_vals"), _stream()),
             "rtxn_mlp_forward_segments")
         return radiance
+
+
+# --------------------------------------------------------------------------- training path
+def padded_samples(n):
+    return int(_lib.lib().rtxn_padded_samples(n))
+
+
+class HashGrid:
+    """Multiresolution hash grid for positions (+ Frequency for directions)."""
+
+    def __init__(self, n_levels=16, n_features=2, log2_hashmap_size=19, base_resolution=16, per_level_scale=1.5,
+                 n_dir_freqs=4):
+        self.cfg = _lib.HashGridConfig(n_levels, n_features, log2_hashmap_size, base_resolution, per_level_scale)
+        self.n_dir_freqs = n_dir_freqs
+        h = C.c_void_p()
+        check(_lib.lib().rtxn_hashgrid_create(C.byref(self.cfg), C.byref(h)), "rtxn_hashgrid_create")
+        self._h = h
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None and getattr(_lib, "_lib", None) is not None:
+            _lib._lib.rtxn_hashgrid_destroy(h)
+
+    def n_params(self):
+        return int(_lib.lib().rtxn_hashgrid_n_params(self._h))
+
+    def encoded_width(self):
+        return int(_lib.lib().rtxn_hashgrid_encoded_width(self._h, self.n_dir_freqs))
+
+    def encode(self, table_fp16, inputs, encT=None):
+        n = inputs.numel() // 5
+        if encT is None:
+            encT = torch.empty((self.encoded_width(), padded_samples(n)), dtype=torch.float16, device=inputs.device)
+        check(_lib.lib().rtxn_hashgrid_encode(self._h, self.n_dir_freqs, _ptr(table_fp16, torch.float16, "table"),
+                                              _ptr(inputs, torch.float32, "inputs"), _ptr(encT, torch.float16, "encT"),
+                                              n, _stream()), "rtxn_hashgrid_encode")
+        return encT
+
+    def backward(self, inputs, dencT, dtable):
+        n = inputs.numel() // 5
+        check(_lib.lib().rtxn_hashgrid_backward(self._h, _ptr(inputs, torch.float32, "inputs"),
+                                                _ptr(dencT, torch.float16, "dencT"), n,
+                                                _ptr(dtable, torch.float32, "dtable"), _stream()),
+              "rtxn_hashgrid_backward")
+        return dtable
+
+
+def _net_encode_frequency(self, inputs, encT=None):
+    n = inputs.numel() // 5
+    if encT is None:
+        encT = torch.empty((self.encoded_width(), padded_samples(n)), dtype=torch.float16, device=inputs.device)
+    check(_lib.lib().rtxn_encode_frequency(self._h, _ptr(inputs, torch.float32, "inputs"), _ptr(encT, torch.float16),
+                                           n, _stream()), "rtxn_encode_frequency")
+    return encT
+
+
+def _net_train_workspace(self, n, device="cuda"):
+    nbytes = _lib.lib().rtxn_mlp_train_workspace_bytes(self._h, n)
+    return torch.empty(nbytes // 2, dtype=torch.float16, device=device)
+
+
+def _net_train_forward(self, encT, n, workspace, output=None, radiance=None):
+    """network->forward(stream, input, &output, use_inference_params=false, prepare_input_gradients) (main.cu:721)."""
+    if output is None:
+        output = torch.empty((n, 16), dtype=torch.float16, device=encT.device)
+    check(_lib.lib().rtxn_mlp_train_forward(self._h, _ptr(encT, torch.float16, "encT"), n, _ptr(workspace, torch.float16),
+                                            _ptr(output, torch.float16), _ptr(radiance, torch.float32, "radiance"),
+                                            _stream()), "rtxn_mlp_train_forward")
+    return output
+
+
+def _net_train_backward(self, encT, output, dout, n, workspace, dparams, dencT=None):
+    """network->backward(stream, ctx, input, output, dL_doutput) (main.cu:781)."""
+    check(_lib.lib().rtxn_mlp_train_backward(self._h, _ptr(encT, torch.float16, "encT"), _ptr(output, torch.float16, "output"),
+                                             _ptr(dout, torch.float16, "dout"), n, _ptr(workspace, torch.float16),
+                                             _ptr(dparams, torch.float32, "dparams"), _ptr(dencT, torch.float16, "dencT"),
+                                             _stream()), "rtxn_mlp_train_backward")
+    return dparams
+
+
+Network.encode_frequency = _net_encode_frequency
+Network.train_workspace = _net_train_workspace
+Network.train_forward = _net_train_forward
+Network.train_backward = _net_train_backward
+
+
+def l2_loss(pred, target, loss_scale=1.0, values=None, grads=None, loss_sum=None):
+    """loss->evaluate(loss_scale, prediction, target, values, gradients) (main.cu:759)."""
+    n = pred.numel()
+    check(_lib.lib().rtxn_l2_loss(_ptr(pred, torch.float32, "pred"), _ptr(target, torch.float32, "target"), n, loss_scale,
+                                  _ptr(values, torch.float32, "values"), _ptr(grads, torch.float16, "grads"),
+                                  _ptr(loss_sum, torch.float32, "loss_sum"), _stream()), "rtxn_l2_loss")
+
+
+def adam_step(master, params_fp16, grads, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, loss_scale=1.0):
+    """optimizer->step(stream, loss_scale, params_fp32, params, gradients) (main.cu:787)."""
+    check(_lib.lib().rtxn_adam_step(master.numel(), _ptr(master, torch.float32, "master"),
+                                    _ptr(params_fp16, torch.float16, "params"), _ptr(grads, torch.float32, "grads"),
+                                    _ptr(m, torch.float32, "m"), _ptr(v, torch.float32, "v"), step, lr, beta1, beta2, eps,
+                                    loss_scale, _stream()), "rtxn_adam_step")

@@ -38,23 +38,14 @@
 #include <cstring>
 #include <vector>
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4v __attribute__((ext_vector_type(4)));
-typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-
-struct rtxn_mlp {
-  rtxn_mlp_config cfg;
-  int enc_width;    // 2*(pos_dims*pos_freqs + dir_dims*dir_freqs)
-  int enc_padded;   // multiple of 16, padding features are 1.0
-  int k0;           // first-layer K as staged (multiple of 16 covering all encode slots)
-  long n_params;
-  void* packed;     // device: packed A fragments, all layers
-  size_t packed_bytes;
-  int variant;      // index into the kernel table
-};
+#include "mlp_internal.h"
 
 namespace {
+
+using rtxn::layer_mma;
+using rtxn::out_mma;
+using rtxn::relu_pack;
+using rtxn::stage;
 
 constexpr int kTileSamples = 256;  // per block per iteration
 constexpr int kThreads = 256;
@@ -81,46 +72,65 @@ struct FwdArgs {
 // ---------------------------------------------------------------------------
 // weight packing
 // ---------------------------------------------------------------------------
-// params (tcnn layout): layer 0 [W][enc_padded], hidden [W][W] x (L-1), out [16][W], row-major fp16.
-// packed: per layer, chunks ordered [rowtile][kstep], each 64 lanes x 8 halves.
-//   layer 0  : element (lane r,h ; kstep kk ; j) = W0[32*rt + r][2*(8kk+j) + h]          (0 if >= enc_padded)
-//   others   : element = Wl[32*rt + r][16kk + 8(j>>2) + 4h + (j&3)]                       (0 if row >= rows)
-__global__ void pack_kernel(const _Float16* __restrict__ params, _Float16* __restrict__ packed, int W, int enc_padded,
-                            int k0, int n_hidden) {
+// params (tcnn layout): layer 0 [W][E], hidden [W][W] x (L-1), out [16][W], row-major fp16 (E = enc_padded).
+// A "fragment" is 1 KiB: 64 lanes x 8 halves, lane l = (r = l&31, h = l>>5) at byte 16*l.
+//
+// MODE 0 (inference): per layer chunks [rowtile][kstep];
+//   layer 0  : element (r,h ; kk ; j) = W0[32rt + r][2*(8kk+j) + h]   (sin/cos pair slots; 0 beyond E), K = k0
+//   others   : element = Wl[32rt + r][perm_feature(kk,h,j)]            (0 if row >= rows)
+// MODE 1 (training forward): as MODE 0 but layer 0 uses perm_feature too, K = E.
+// MODE 2 (training backward, TRANSPOSED layers, stored in backward order out, L-1, ..., 0):
+//   layer l  : element = Wl[perm_feature(kk,h,j)][32rt + r], rows = in_width(l) padded to 32, K = out rows
+//              (16 for the output layer: one k-step; W otherwise).
+__global__ void pack_kernel(const _Float16* __restrict__ params, _Float16* __restrict__ packed, int W, int E, int k0,
+                            int n_hidden, int mode) {
   const int RT = W / 32;
-  const long l0_elems = (long)(k0 / 16) * RT * 512;
-  const long hid_elems = (long)(W / 16) * RT * 512;
-  const long out_elems = (long)(W / 16) * 512;
-  const long total = l0_elems + (long)(n_hidden - 1) * hid_elems + out_elems;
+  const int l0_ks = mode == 0 ? k0 / 16 : E / 16;
+  const int rt_e = (E + 31) / 32;
+  auto layer_elems = [&](int l) -> long {  // l in forward numbering: 0..n_hidden (n_hidden = output layer)
+    if (mode < 2) {
+      if (l == 0) return (long)l0_ks * RT * 512;
+      if (l < n_hidden) return (long)(W / 16) * RT * 512;
+      return (long)(W / 16) * 512;
+    }
+    if (l == n_hidden) return (long)RT * 1 * 512;                 // rows W, K = 16
+    if (l == 0) return (long)rt_e * (W / 16) * 512;               // rows E (padded to 32), K = W
+    return (long)RT * (W / 16) * 512;
+  };
+  auto src_base = [&](int l) -> long {
+    if (l == 0) return 0;
+    return (long)W * E + (long)(l - 1) * W * W;
+  };
+  long total = 0;
+  for (int l = 0; l <= n_hidden; ++l) total += layer_elems(l);
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     long q = e;
-    int layer, in_w, rows;
-    long src_base;
-    if (q < l0_elems) {
-      layer = 0; in_w = enc_padded; rows = W; src_base = 0;
-    } else {
-      q -= l0_elems;
-      long hl = q / hid_elems;
-      if (hl < n_hidden - 1) {
-        layer = 1 + (int)hl; q -= hl * hid_elems; in_w = W; rows = W;
-        src_base = (long)W * enc_padded + hl * (long)W * W;
-      } else {
-        q -= (long)(n_hidden - 1) * hid_elems;
-        layer = n_hidden; in_w = W; rows = 16;
-        src_base = (long)W * enc_padded + (long)(n_hidden - 1) * W * W;
-      }
+    int layer = -1;
+    for (int i = 0; i <= n_hidden; ++i) {
+      const int l = mode < 2 ? i : n_hidden - i;  // storage order
+      const long n = layer_elems(l);
+      if (q < n) { layer = l; break; }
+      q -= n;
     }
     const int j = (int)(q & 7), lane = (int)((q >> 3) & 63);
     const long chunk = q >> 9;
-    const int ks_count = layer == 0 ? k0 / 16 : W / 16;
-    const int kk = (int)(chunk % ks_count), rt = (int)(chunk / ks_count);
     const int r = lane & 31, h = lane >> 5;
-    const int row = 32 * rt + r;
-    int feat;
-    if (layer == 0) feat = 2 * (8 * kk + j) + h;
-    else feat = 16 * kk + 8 * (j >> 2) + 4 * h + (j & 3);
+    const int in_w = layer == 0 ? E : W;
+    const int rows = layer == n_hidden ? 16 : W;
     _Float16 v = (_Float16)0.0f;
-    if (row < rows && feat < in_w) v = params[src_base + (long)row * in_w + feat];
+    if (mode < 2) {
+      const int ks_count = layer == 0 ? l0_ks : W / 16;
+      const int kk = (int)(chunk % ks_count), rt = (int)(chunk / ks_count);
+      const int row = 32 * rt + r;
+      const int feat = (mode == 0 && layer == 0) ? 2 * (8 * kk + j) + h : rtxn::perm_feature(kk, h, j);
+      if (row < rows && feat < in_w) v = params[src_base(layer) + (long)row * in_w + feat];
+    } else {
+      const int ks_count = layer == n_hidden ? 1 : W / 16;
+      const int kk = (int)(chunk % ks_count), rt = (int)(chunk / ks_count);
+      const int col = 32 * rt + r;                       // input feature of the layer = output row of W^T
+      const int row = rtxn::perm_feature(kk, h, j);      // output feature of the layer = k of W^T
+      if (row < rows && col < in_w) v = params[src_base(layer) + (long)row * in_w + col];
+    }
     packed[e] = v;
   }
 }
@@ -128,110 +138,6 @@ __global__ void pack_kernel(const _Float16* __restrict__ params, _Float16* __res
 // ---------------------------------------------------------------------------
 // forward kernel
 // ---------------------------------------------------------------------------
-template <int BYTES>
-__device__ __forceinline__ void stage(const uint8_t* __restrict__ g, uint8_t* lds_buf, int tid) {
-  static_assert(BYTES % 1024 == 0, "layer bytes must be whole 1-KiB fragments");
-#pragma unroll
-  for (int i = 0; i < BYTES / 4096; ++i) {
-    const uint8_t* src = g + i * 4096 + tid * 16;
-    uint8_t* dst = lds_buf + i * 4096 + (tid & ~63) * 16;  // wave-uniform base; HW adds lane*16
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-  }
-  constexpr int TAIL = (BYTES % 4096) / 1024;  // whole fragments left: one wave each
-  if (TAIL > 0 && (tid >> 6) < TAIL) {
-    const int off = (BYTES / 4096) * 4096;
-    const uint8_t* src = g + off + tid * 16;
-    uint8_t* dst = lds_buf + off + (tid & ~63) * 16;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-  }
-}
-
-typedef short short8 __attribute__((ext_vector_type(8)));
-
-// ReLU + f32->f16 of 8 accumulator registers = one B fragment of the next layer.
-// Convert first (v_cvt_pk_f16_f32, 2 values/op), then clamp the PACKED halves with a
-// signed-integer max against 0 (v_pk_max_i16, 2 values/op): a negative half has its
-// sign bit set, i.e. is a negative int16, and rounding is monotone, so this equals
-// fp16(max(x, 0)).  A float max would cost one op per value plus the canonicalising
-// v_max hipcc inserts in front of fmaxf on MFMA results.
-typedef float float2v __attribute__((ext_vector_type(2)));
-typedef short short2v __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ half2v relu_pack2(float a, float b) {
-  float2v f = {a, b};
-  half2v hv = __builtin_convertvector(f, half2v);           // v_cvt_pk_f16_f32
-  short2v sv = __builtin_bit_cast(short2v, hv);
-  sv = __builtin_elementwise_max(sv, (short2v)0);          // v_pk_max_i16
-  return __builtin_bit_cast(half2v, sv);
-}
-
-__device__ __forceinline__ half8 relu_pack(const floatx16& c, int s) {
-  const half2v p0 = relu_pack2(c[8 * s + 0], c[8 * s + 1]);
-  const half2v p1 = relu_pack2(c[8 * s + 2], c[8 * s + 3]);
-  const half2v p2 = relu_pack2(c[8 * s + 4], c[8 * s + 5]);
-  const half2v p3 = relu_pack2(c[8 * s + 6], c[8 * s + 7]);
-  const half4v q0 = __builtin_shufflevector(p0, p1, 0, 1, 2, 3);
-  const half4v q1 = __builtin_shufflevector(p2, p3, 0, 1, 2, 3);
-  return __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7);
-}
-
-// One layer: out rows [32*rt, 32*rt+32) for rt < RT, K = 16*KS, for the wave's two column
-// tiles.  Row-tile-outer: an accumulator is live for one row tile only, and its ReLU/convert
-// (VALU) overlaps the next row tile's MFMAs.  A fragments: chunk (rt, kk) at ((rt*KS+kk)*64+lane)*16.
-template <int RT, int KS, int NB>
-__device__ __forceinline__ void layer_mma(const uint8_t* lds_buf, const half8 (&bf)[NB][2], half8 (&nbf)[NB][2],
-                                          int lane) {
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    floatx16 acc[2];
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[ct][e] = 0.0f;
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk) {
-#ifdef RTXN_ABLATE_DSREAD
-      half8 a = bf[kk][0];
-#else
-      const half8 a = *reinterpret_cast<const half8*>(lds_buf + ((rt * KS + kk) * 64 + lane) * 16);
-#endif
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[kk][ct], acc[ct], 0, 0, 0);
-    }
-#ifdef RTXN_ABLATE_CONVERT
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
-        asm volatile("" ::"v"(acc[ct]));
-        nbf[2 * rt + s][ct] = bf[2 * rt + s][ct];
-      }
-#else
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct) nbf[2 * rt + s][ct] = relu_pack(acc[ct], s);
-#endif
-  }
-}
-
-// Output layer: 32 rows (16 real), raw accumulators returned.
-template <int KS, int NB>
-__device__ __forceinline__ void out_mma(const uint8_t* lds_buf, const half8 (&bf)[NB][2], floatx16 (&acc)[2], int lane) {
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[ct][e] = 0.0f;
-#pragma unroll
-  for (int kk = 0; kk < KS; ++kk) {
-    const half8 a = *reinterpret_cast<const half8*>(lds_buf + (kk * 64 + lane) * 16);
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[kk][ct], acc[ct], 0, 0, 0);
-  }
-}
-
 // Encoding slot p (0..): pair (dim, freq) of Composite(Frequency(PD,PF), Frequency(DD,DF)).
 template <int PD, int PF, int DD, int DF>
 struct EncSpec {
@@ -516,28 +422,46 @@ extern "C" int rtxn_mlp_create(const rtxn_mlp_config* cfg, rtxn_mlp** out) {
                cfg->n_output_dims);
   RTXN_REQUIRE(cfg->output_activation == RTXN_ACT_NONE || cfg->output_activation == RTXN_ACT_SIGMOID,
                "rtxn_mlp_create: unknown output_activation %d", cfg->output_activation);
+  RTXN_REQUIRE(cfg->encoding == RTXN_ENC_FREQUENCY || cfg->encoding == RTXN_ENC_EXTERNAL,
+               "rtxn_mlp_create: unknown encoding %d", cfg->encoding);
   int variant = -1;
   const auto& vs = variants();
-  for (size_t i = 0; i < vs.size(); ++i)
-    if (vs[i].W == cfg->n_neurons && vs[i].PD == cfg->n_pos_dims && vs[i].PF == cfg->n_pos_freqs &&
-        vs[i].DD == cfg->n_dir_dims && vs[i].DF == cfg->n_dir_freqs)
-      variant = (int)i;
-  if (variant < 0) {
-    rtxn::set_error("rtxn_mlp_create: no kernel for n_neurons=%d enc=(%d x %d, %d x %d); built: 64/128 wide, (3x10, 2x12|2x4)",
-                    cfg->n_neurons, cfg->n_pos_dims, cfg->n_pos_freqs, cfg->n_dir_dims, cfg->n_dir_freqs);
-    return RTXN_ERR_UNSUPPORTED;
+  if (cfg->encoding == RTXN_ENC_FREQUENCY) {
+    for (size_t i = 0; i < vs.size(); ++i)
+      if (vs[i].W == cfg->n_neurons && vs[i].PD == cfg->n_pos_dims && vs[i].PF == cfg->n_pos_freqs &&
+          vs[i].DD == cfg->n_dir_dims && vs[i].DF == cfg->n_dir_freqs)
+        variant = (int)i;
+    if (variant < 0) {
+      rtxn::set_error("rtxn_mlp_create: no kernel for n_neurons=%d enc=(%d x %d, %d x %d); built: 64/128 wide, (3x10, 2x12|2x4)",
+                      cfg->n_neurons, cfg->n_pos_dims, cfg->n_pos_freqs, cfg->n_dir_dims, cfg->n_dir_freqs);
+      return RTXN_ERR_UNSUPPORTED;
+    }
+  } else {
+    if (cfg->n_neurons != 64 && cfg->n_neurons != 128) {
+      rtxn::set_error("rtxn_mlp_create: n_neurons = %d; built: 64, 128", cfg->n_neurons);
+      return RTXN_ERR_UNSUPPORTED;
+    }
+    RTXN_REQUIRE(cfg->n_encoded_features >= 16 && cfg->n_encoded_features <= 256 && cfg->n_encoded_features % 16 == 0,
+                 "rtxn_mlp_create: n_encoded_features = %d must be a multiple of 16 in [16,256]", cfg->n_encoded_features);
   }
   rtxn_mlp* m = new rtxn_mlp();
   m->cfg = *cfg;
   m->variant = variant;
-  m->enc_width = 2 * (cfg->n_pos_dims * cfg->n_pos_freqs + cfg->n_dir_dims * cfg->n_dir_freqs);
-  m->enc_padded = (m->enc_width + 15) / 16 * 16;
-  m->k0 = vs[variant].k0;
-  const long W = cfg->n_neurons;
-  m->n_params = W * m->enc_padded + (long)(cfg->n_hidden_layers - 1) * W * W + 16 * W;
-  const long RT = W / 32;
-  m->packed_bytes = (size_t)((m->k0 / 16) * RT + (long)(cfg->n_hidden_layers - 1) * (W / 16) * RT + (W / 16)) * 1024;
-  m->packed = nullptr;
+  if (cfg->encoding == RTXN_ENC_FREQUENCY) {
+    m->enc_width = 2 * (cfg->n_pos_dims * cfg->n_pos_freqs + cfg->n_dir_dims * cfg->n_dir_freqs);
+    m->enc_padded = (m->enc_width + 15) / 16 * 16;
+    m->k0 = vs[variant].k0;
+  } else {
+    m->enc_width = m->enc_padded = cfg->n_encoded_features;
+    m->k0 = m->enc_padded;
+  }
+  const long W = cfg->n_neurons, E = m->enc_padded, L = cfg->n_hidden_layers;
+  m->n_params = W * E + (L - 1) * W * W + 16 * W;
+  const long RT = W / 32, KS = W / 16;
+  m->packed_bytes = variant >= 0 ? (size_t)((m->k0 / 16) * RT + (L - 1) * KS * RT + KS) * 1024 : 0;
+  m->packed_train_bytes = (size_t)((E / 16) * RT + (L - 1) * KS * RT + KS) * 1024;
+  m->packed_t_bytes = (size_t)(RT + (L - 1) * RT * KS + ((E + 31) / 32) * KS) * 1024;
+  m->packed = m->packed_train = m->packed_t = nullptr;
   *out = m;
   return RTXN_OK;
 }
@@ -545,6 +469,8 @@ extern "C" int rtxn_mlp_create(const rtxn_mlp_config* cfg, rtxn_mlp** out) {
 extern "C" int rtxn_mlp_destroy(rtxn_mlp* m) {
   if (!m) return RTXN_OK;
   if (m->packed) (void)hipFree(m->packed);
+  if (m->packed_train) (void)hipFree(m->packed_train);
+  if (m->packed_t) (void)hipFree(m->packed_t);
   delete m;
   return RTXN_OK;
 }
@@ -571,18 +497,29 @@ extern "C" int rtxn_mlp_initialize_params(const rtxn_mlp* m, uint64_t seed, floa
 extern "C" int rtxn_mlp_set_params(rtxn_mlp* m, const void* params_fp16, rtxn_stream_t stream) {
   RTXN_REQUIRE(m && params_fp16, "rtxn_mlp_set_params: NULL argument");
   RTXN_DEVICE_OR_FAIL();
-  if (!m->packed) RTXN_HIP(hipMalloc(&m->packed, m->packed_bytes));
-  const long total = (long)(m->packed_bytes / 2);
-  const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
-  pack_kernel<<<blocks, 256, 0, rtxn::as_stream(stream)>>>(static_cast<const _Float16*>(params_fp16),
-                                                           static_cast<_Float16*>(m->packed), m->cfg.n_neurons,
-                                                           m->enc_padded, m->k0, m->cfg.n_hidden_layers);
-  RTXN_LAUNCH_CHECK("pack_kernel");
+  if (m->packed_bytes && !m->packed) RTXN_HIP(hipMalloc(&m->packed, m->packed_bytes));
+  if (!m->packed_train) RTXN_HIP(hipMalloc(&m->packed_train, m->packed_train_bytes));
+  if (!m->packed_t) RTXN_HIP(hipMalloc(&m->packed_t, m->packed_t_bytes));
+  void* dst[3] = {m->packed, m->packed_train, m->packed_t};
+  const size_t bytes[3] = {m->packed_bytes, m->packed_train_bytes, m->packed_t_bytes};
+  for (int mode = 0; mode < 3; ++mode) {
+    if (!bytes[mode]) continue;
+    const long total = (long)(bytes[mode] / 2);
+    const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+    pack_kernel<<<blocks, 256, 0, rtxn::as_stream(stream)>>>(static_cast<const _Float16*>(params_fp16),
+                                                             static_cast<_Float16*>(dst[mode]), m->cfg.n_neurons,
+                                                             m->enc_padded, m->k0, m->cfg.n_hidden_layers, mode);
+    RTXN_LAUNCH_CHECK("pack_kernel");
+  }
   return RTXN_OK;
 }
 
 static int check_ready(const rtxn_mlp* m, const char* who) {
   if (!m) { rtxn::set_error("%s: NULL model", who); return RTXN_ERR_INVALID; }
+  if (m->variant < 0) {
+    rtxn::set_error("%s: this model takes pre-encoded input (RTXN_ENC_EXTERNAL); use rtxn_mlp_train_forward", who);
+    return RTXN_ERR_UNSUPPORTED;
+  }
   if (!m->packed) { rtxn::set_error("%s: rtxn_mlp_set_params has not been called", who); return RTXN_ERR_INVALID; }
   return RTXN_OK;
 }

@@ -1,0 +1,152 @@
+// Internal (non-ABI) declarations shared by mlp.hip (inference) and train.hip (training).
+#pragma once
+#include "common.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef short short2v __attribute__((ext_vector_type(2)));
+
+struct rtxn_mlp {
+  rtxn_mlp_config cfg;
+  int enc_width;    // encoded features before padding
+  int enc_padded;   // multiple of 16, padding features are 1.0 (= first-layer in_width of the params)
+  int k0;           // inference kernel: first-layer K as staged (multiple of 16 covering all encode slots)
+  long n_params;
+  int variant;      // index into the inference kernel table, -1 if this model has no fused inference kernel
+  // device buffers owned by the model, (re)built by rtxn_mlp_set_params
+  void* packed;       // inference: A fragments, layer 0 in the sin/cos-pair slot order
+  size_t packed_bytes;
+  void* packed_train; // training forward: A fragments, every layer in the accumulator-permuted k order
+  size_t packed_train_bytes;
+  void* packed_t;     // training backward: A fragments of the TRANSPOSED layers (dA = W^T dZ)
+  size_t packed_t_bytes;
+};
+
+namespace rtxn {
+
+// Stage BYTES of lane-linear A fragments from global memory into LDS with LDS-DMA
+// (global_load_lds, 16 B per lane).  All 256 threads of the block call it.
+template <int BYTES>
+__device__ __forceinline__ void stage(const uint8_t* __restrict__ g, uint8_t* lds_buf, int tid) {
+  static_assert(BYTES % 1024 == 0, "layer bytes must be whole 1-KiB fragments");
+#pragma unroll
+  for (int i = 0; i < BYTES / 4096; ++i) {
+    const uint8_t* src = g + i * 4096 + tid * 16;
+    uint8_t* dst = lds_buf + i * 4096 + (tid & ~63) * 16;  // wave-uniform base; HW adds lane*16
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  }
+  constexpr int TAIL = (BYTES % 4096) / 1024;  // whole fragments left: one wave each
+  if (TAIL > 0 && (tid >> 6) < TAIL) {
+    const int off = (BYTES / 4096) * 4096;
+    const uint8_t* src = g + off + tid * 16;
+    uint8_t* dst = lds_buf + off + (tid & ~63) * 16;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  }
+}
+
+// runtime-sized variant (bytes % 1024 == 0)
+__device__ __forceinline__ void stage_rt(const uint8_t* __restrict__ g, uint8_t* lds_buf, int bytes, int tid) {
+  for (int off = (tid >> 6) * 1024; off < bytes; off += 4096) {
+    const uint8_t* src = g + off + (tid & 63) * 16;
+    uint8_t* dst = lds_buf + off;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  }
+}
+
+// f32 pair -> packed f16 (v_cvt_pk_f16_f32), optional ReLU as a signed-integer max on the packed
+// halves (v_pk_max_i16): a negative half is a negative int16 and rounding is monotone, so this is
+// fp16(max(x,0)) at one VALU op per two values and without the canonicalising v_max hipcc puts in
+// front of fmaxf on MFMA results.
+template <bool RELU>
+__device__ __forceinline__ half2v pack2(float a, float b) {
+  float2v f = {a, b};
+  half2v hv = __builtin_convertvector(f, half2v);
+  if (RELU) {
+    short2v sv = __builtin_bit_cast(short2v, hv);
+    sv = __builtin_elementwise_max(sv, (short2v)0);
+    hv = __builtin_bit_cast(half2v, sv);
+  }
+  return hv;
+}
+
+// registers 8s..8s+7 of a 32x32 accumulator tile -> the B fragment of k-step s of the next MFMA
+template <bool RELU>
+__device__ __forceinline__ half8 pack8(const floatx16& c, int s) {
+  const half2v p0 = pack2<RELU>(c[8 * s + 0], c[8 * s + 1]);
+  const half2v p1 = pack2<RELU>(c[8 * s + 2], c[8 * s + 3]);
+  const half2v p2 = pack2<RELU>(c[8 * s + 4], c[8 * s + 5]);
+  const half2v p3 = pack2<RELU>(c[8 * s + 6], c[8 * s + 7]);
+  const half4v q0 = __builtin_shufflevector(p0, p1, 0, 1, 2, 3);
+  const half4v q1 = __builtin_shufflevector(p2, p3, 0, 1, 2, 3);
+  return __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__device__ __forceinline__ half8 relu_pack(const floatx16& c, int s) { return pack8<true>(c, s); }
+
+// feature (row) index held in element j of lane-half h of k-step kk: the order in which a
+// 32x32 accumulator tile hands its rows to the next MFMA as a B operand
+__host__ __device__ __forceinline__ int perm_feature(int kk, int h, int j) { return 16 * kk + 8 * (j >> 2) + 4 * h + (j & 3); }
+
+// One layer: out rows [32*rt, 32*rt+32) for rt < RT, K = 16*KS, for the wave's two column
+// tiles.  Row-tile-outer: an accumulator is live for one row tile only, and its ReLU/convert
+// (VALU) overlaps the next row tile's MFMAs.  A fragments: chunk (rt, kk) at ((rt*KS+kk)*64+lane)*16.
+template <int RT, int KS, int NB>
+__device__ __forceinline__ void layer_mma(const uint8_t* lds_buf, const half8 (&bf)[NB][2], half8 (&nbf)[NB][2],
+                                          int lane) {
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    floatx16 acc[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[ct][e] = 0.0f;
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+#ifdef RTXN_ABLATE_DSREAD
+      half8 a = bf[kk][0];
+#else
+      const half8 a = *reinterpret_cast<const half8*>(lds_buf + ((rt * KS + kk) * 64 + lane) * 16);
+#endif
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[kk][ct], acc[ct], 0, 0, 0);
+    }
+#ifdef RTXN_ABLATE_CONVERT
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        asm volatile("" ::"v"(acc[ct]));
+        nbf[2 * rt + s][ct] = bf[2 * rt + s][ct];
+      }
+#else
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) nbf[2 * rt + s][ct] = relu_pack(acc[ct], s);
+#endif
+  }
+}
+
+// Output layer: 32 rows (16 real), raw accumulators returned.
+template <int KS, int NB>
+__device__ __forceinline__ void out_mma(const uint8_t* lds_buf, const half8 (&bf)[NB][2], floatx16 (&acc)[2], int lane) {
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[ct][e] = 0.0f;
+#pragma unroll
+  for (int kk = 0; kk < KS; ++kk) {
+    const half8 a = *reinterpret_cast<const half8*>(lds_buf + (kk * 64 + lane) * 16);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[kk][ct], acc[ct], 0, 0, 0);
+  }
+}
+
+
+}  // namespace rtxn

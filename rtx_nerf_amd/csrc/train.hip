@@ -1,0 +1,726 @@
+// Training path: encoders (Composite-Frequency, multiresolution hash grid), MLP
+// forward with saved activations, MLP backward (dgrad fused across layers + per-layer
+// wgrad), L2 loss and Adam.  Replaces the tiny-cuda-nn calls of the reference's training
+// loop: network->forward(..., prepare_input_gradients) (main.cu:721), loss->evaluate
+// (:759), network->backward (:781), optimizer->step (:787).  tiny-cuda-nn is un-vendored
+// and unpinned; numerics follow oracle/rtxn_oracle.c (orc_mlpe_*, orc_hg_*, orc_l2_loss,
+// orc_adam_step).  PARITY UNPINNED.
+//
+// Layout.  Every per-sample training tensor is FEATURE-MAJOR fp16: X[feature][S_pad],
+// S_pad = S rounded up to 256 (one block tile), padding columns written as zeros.  That is
+// the layout both consumers want: the fused forward/backward kernels read/write one sample
+// per lane (consecutive lanes -> consecutive addresses), and the weight-gradient GEMM
+// dW[o][i] = sum_s dZ[o][s] X[i][s] contracts over samples, so each MFMA operand fragment
+// (8 consecutive samples of one feature row) is ONE 16-byte load, with no transpose.
+//
+// Kernels
+//   encode_freq_kernel / hashgrid_encode_kernel   [S][5] f32 -> encT[E][S_pad] f16
+//   mlp_train_fwd_kernel<W>   encT -> acts[L][W][S_pad] (post-ReLU), out[S][16] (+radiance)
+//   mlp_bwd_kernel<W>         dout[S][4] -> dz[L][W][S_pad], dzL[16][S_pad], dencT (optional);
+//                             dA = W^T dZ on MFMA with the transposed packed weights, activations
+//                             of the backward chain stay in registers exactly as in the forward
+//   wgrad_kernel              dW += dZ X^T : 64x64 output super-tile per wave, K = samples,
+//                             fp32 atomics into the tcnn-layout gradient buffer
+//   hashgrid_backward_kernel  scatter-add of denc into the table gradient (fp32 atomics)
+//   l2_loss_kernel, adam_kernel
+#include "mlp_internal.h"
+
+#include <cmath>
+#include <cstring>
+
+struct rtxn_hashgrid {
+  rtxn_hashgrid_config cfg;
+  long n_params;
+  float scale[32];
+  unsigned res[32], size[32], offset[32];
+};
+
+namespace {
+
+using rtxn::layer_mma;
+using rtxn::out_mma;
+using rtxn::pack8;
+using rtxn::perm_feature;
+using rtxn::stage_rt;
+
+constexpr int kThreads = 256;
+constexpr int kTile = 256;
+
+inline long padded(long S) { return (S + kTile - 1) / kTile * kTile; }
+
+// ------------------------------------------------------------------------- encoders
+__device__ __forceinline__ float sin_turns(float x, int f, int ph) {
+  // sin(pi * 2^f * x + ph*pi/2) with an exact argument reduction
+  return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(ldexpf(x, f - 1)) + 0.25f * (float)ph);
+}
+
+__global__ __launch_bounds__(kThreads) void encode_freq_kernel(const float* __restrict__ in, _Float16* __restrict__ encT,
+                                                               long S, long Sp, int PD, int PF, int DD, int DF, int E) {
+  const long s = (long)blockIdx.x * kThreads + threadIdx.x;
+  if (s >= Sp) return;
+  const bool ok = s < S;
+  float x[8];
+  for (int c = 0; c < PD + DD; ++c) x[c] = ok ? in[(PD + DD) * s + c] : 0.0f;
+  int j = 0;
+  for (int d = 0; d < PD; ++d)
+    for (int f = 0; f < PF; ++f)
+      for (int ph = 0; ph < 2; ++ph, ++j) encT[(long)j * Sp + s] = ok ? (_Float16)sin_turns(x[d], f, ph) : (_Float16)0.0f;
+  for (int d = 0; d < DD; ++d)
+    for (int f = 0; f < DF; ++f)
+      for (int ph = 0; ph < 2; ++ph, ++j) encT[(long)j * Sp + s] = ok ? (_Float16)sin_turns(x[PD + d], f, ph) : (_Float16)0.0f;
+  for (; j < E; ++j) encT[(long)j * Sp + s] = ok ? (_Float16)1.0f : (_Float16)0.0f;
+}
+
+struct HgLevels {
+  float scale[16];
+  unsigned res[16], size[16], offset[16];
+  int n_levels, n_features;
+};
+
+__device__ __forceinline__ unsigned hg_index(unsigned x, unsigned y, unsigned z, unsigned res, unsigned size) {
+  const unsigned long long dense = (unsigned long long)res * res * res;
+  if (dense <= size) return x + y * res + z * res * res;
+  return ((x * 1u) ^ (y * 2654435761u) ^ (z * 805459861u)) % size;
+}
+
+// grid.y = level (0..L-1: hash levels; L: direction frequencies + padding)
+__global__ __launch_bounds__(kThreads) void hashgrid_encode_kernel(HgLevels lv, int n_dir_freqs, const _Float16* __restrict__ table,
+                                                                   const float* __restrict__ in, _Float16* __restrict__ encT,
+                                                                   long S, long Sp, int E) {
+  const long s = (long)blockIdx.x * kThreads + threadIdx.x;
+  if (s >= Sp) return;
+  const bool ok = s < S;
+  const int l = blockIdx.y;
+  const int F = lv.n_features;
+  if (l < lv.n_levels) {
+    float fr[3];
+    unsigned g[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float x01 = fmaf(ok ? in[5 * s + a] : 0.0f, 0.5f, 0.5f);
+      const float p = fmaf(x01, lv.scale[l], 0.5f), fl = floorf(p);
+      g[a] = (unsigned)(int)fl;
+      fr[a] = p - fl;
+    }
+    for (int f = 0; f < F; ++f) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int corner = 0; corner < 8; ++corner) {
+        float w = 1.0f;
+        unsigned p[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          const int hi = (corner >> a) & 1;
+          w *= hi ? fr[a] : 1.0f - fr[a];
+          p[a] = g[a] + (unsigned)hi;
+        }
+        const unsigned idx = hg_index(p[0], p[1], p[2], lv.res[l], lv.size[l]);
+        acc = fmaf(w, (float)table[((size_t)lv.offset[l] + idx) * F + f], acc);
+      }
+      encT[(long)(l * F + f) * Sp + s] = ok ? (_Float16)acc : (_Float16)0.0f;
+    }
+  } else {
+    int j = lv.n_levels * F;
+    for (int d = 0; d < 2; ++d) {
+      const float x = ok ? in[5 * s + 3 + d] : 0.0f;
+      for (int f = 0; f < n_dir_freqs; ++f)
+        for (int ph = 0; ph < 2; ++ph, ++j) encT[(long)j * Sp + s] = ok ? (_Float16)sin_turns(x, f, ph) : (_Float16)0.0f;
+    }
+    for (; j < E; ++j) encT[(long)j * Sp + s] = ok ? (_Float16)1.0f : (_Float16)0.0f;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void hashgrid_backward_kernel(HgLevels lv, const float* __restrict__ in,
+                                                                     const _Float16* __restrict__ dencT, long S, long Sp,
+                                                                     float* __restrict__ dtable) {
+  const long s = (long)blockIdx.x * kThreads + threadIdx.x;
+  if (s >= S) return;
+  const int l = blockIdx.y;
+  const int F = lv.n_features;
+  float fr[3];
+  unsigned g[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float x01 = fmaf(in[5 * s + a], 0.5f, 0.5f);
+    const float p = fmaf(x01, lv.scale[l], 0.5f), fl = floorf(p);
+    g[a] = (unsigned)(int)fl;
+    fr[a] = p - fl;
+  }
+  float d[8];
+  for (int f = 0; f < F && f < 8; ++f) d[f] = (float)dencT[(long)(l * F + f) * Sp + s];
+#pragma unroll
+  for (int corner = 0; corner < 8; ++corner) {
+    float w = 1.0f;
+    unsigned p[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const int hi = (corner >> a) & 1;
+      w *= hi ? fr[a] : 1.0f - fr[a];
+      p[a] = g[a] + (unsigned)hi;
+    }
+    const unsigned idx = hg_index(p[0], p[1], p[2], lv.res[l], lv.size[l]);
+    for (int f = 0; f < F && f < 8; ++f) {
+      const float v = w * d[f];
+      if (v != 0.0f) atomicAdd(&dtable[((size_t)lv.offset[l] + idx) * F + f], v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------- MLP forward (training)
+struct TrainArgs {
+  const uint8_t* packed;    // packed_train (fwd) or packed_t (bwd)
+  int n_hidden, out_act, E;
+  long S, Sp;
+  const _Float16* encT;     // [E][Sp]
+  _Float16* acts;           // [L][W][Sp]
+  _Float16* out_half;       // [S][16]
+  float4* radiance;         // [S] or NULL
+  // backward
+  const _Float16* dout;     // [S][4]
+  _Float16* dz;             // [L][W][Sp]
+  _Float16* dzL;            // [16][Sp]
+  _Float16* dencT;          // [E][Sp] or NULL
+};
+
+template <int W>
+__global__ __launch_bounds__(kThreads, 2) void mlp_train_fwd_kernel(TrainArgs a) {
+  constexpr int RT = W / 32, KS = W / 16;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
+  const long tile0 = (long)blockIdx.x * kTile + wave * 64;
+  const int KS0 = a.E / 16;
+  const int L = a.n_hidden;
+  long off = 0;
+
+  // ---- layer 0: B fragments straight from encT (8 two-byte loads per k-step per column tile) ----
+  half8 bf[KS][2], bg[KS][2];
+  {
+    stage_rt(a.packed, smem, KS0 * RT * 1024, tid);
+    __syncthreads();
+    floatx16 acc[RT][2];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[rt][ct][e] = 0.0f;
+    for (int kk = 0; kk < KS0; ++kk) {
+      half8 b[2];
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const long s = tile0 + ct * 32 + col;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b[ct][j] = a.encT[(long)perm_feature(kk, h, j) * a.Sp + s];
+      }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const half8 af = *reinterpret_cast<const half8*>(smem + ((rt * KS0 + kk) * 64 + lane) * 16);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, b[ct], acc[rt][ct], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) bf[2 * rt + s2][ct] = pack8<true>(acc[rt][ct], s2);
+    off += (long)KS0 * RT * 1024;
+  }
+  auto save_acts = [&](int l, const half8 (&v)[KS][2]) {
+    _Float16* dst = a.acts + (long)l * W * a.Sp;
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const long s = tile0 + ct * 32 + col;
+        const bool ok = s < a.S;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dst[(long)perm_feature(kk, h, j) * a.Sp + s] = ok ? v[kk][ct][j] : (_Float16)0.0f;
+      }
+  };
+  save_acts(0, bf);
+  // ---- hidden layers 1..L-1 (ping-pong bf <-> bg) ----
+  int l = 1;
+  for (; l + 1 < L; l += 2) {
+    __syncthreads();
+    stage_rt(a.packed + off, smem, KS * RT * 1024, tid);
+    __syncthreads();
+    layer_mma<RT, KS, KS>(smem, bf, bg, lane);
+    save_acts(l, bg);
+    off += (long)KS * RT * 1024;
+    __syncthreads();
+    stage_rt(a.packed + off, smem, KS * RT * 1024, tid);
+    __syncthreads();
+    layer_mma<RT, KS, KS>(smem, bg, bf, lane);
+    save_acts(l + 1, bf);
+    off += (long)KS * RT * 1024;
+  }
+  if (l < L) {
+    __syncthreads();
+    stage_rt(a.packed + off, smem, KS * RT * 1024, tid);
+    __syncthreads();
+    layer_mma<RT, KS, KS>(smem, bf, bg, lane);
+    save_acts(l, bg);
+    off += (long)KS * RT * 1024;
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) bf[kk][ct] = bg[kk][ct];
+  }
+  // ---- output layer ----
+  __syncthreads();
+  stage_rt(a.packed + off, smem, KS * 1024, tid);
+  __syncthreads();
+  floatx16 acc[2];
+  out_mma<KS, KS>(smem, bf, acc, lane);
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const long s = tile0 + ct * 32 + col;
+    if (s >= a.S) continue;
+    float y[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float z = acc[ct][e];
+      y[e] = a.out_act == RTXN_ACT_SIGMOID ? 1.0f / (1.0f + __expf(-z)) : z;
+    }
+    half4v lo, hi;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { lo[e] = (_Float16)y[e]; hi[e] = (_Float16)y[4 + e]; }
+    _Float16* o = a.out_half + s * 16;
+    *reinterpret_cast<half4v*>(o + 4 * h) = lo;
+    *reinterpret_cast<half4v*>(o + 8 + 4 * h) = hi;
+    if (a.radiance && h == 0) a.radiance[s] = make_float4((float)lo[0], (float)lo[1], (float)lo[2], (float)lo[3]);
+  }
+}
+
+// ------------------------------------------------------------------------- MLP backward (dgrad)
+template <int W>
+__global__ __launch_bounds__(kThreads, 2) void mlp_bwd_kernel(TrainArgs a) {
+  constexpr int RT = W / 32, KS = W / 16;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
+  const long tile0 = (long)blockIdx.x * kTile + wave * 64;
+  const int L = a.n_hidden;
+  long off = 0;
+
+  // ---- output layer: dZ_out = dout (*) act'(out), one k-step (16 rows) ----
+  half8 bo[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const long s = tile0 + ct * 32 + col;
+    const bool ok = s < a.S;
+    half8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.0f;
+    if (ok && h == 0) {
+      const half4v g = *reinterpret_cast<const half4v*>(a.dout + s * 4);
+      const half4v y = *reinterpret_cast<const half4v*>(a.out_half + s * 16);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float gg = (float)g[j];
+        if (a.out_act == RTXN_ACT_SIGMOID) { const float yy = (float)y[j]; gg = gg * yy * (1.0f - yy); }
+        v[j] = (_Float16)gg;
+      }
+    }
+    bo[ct] = v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a.dzL[(long)perm_feature(0, h, j) * a.Sp + s] = v[j];
+  }
+  floatx16 dA[RT][2];
+  stage_rt(a.packed, smem, RT * 1024, tid);
+  __syncthreads();
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const half8 af = *reinterpret_cast<const half8*>(smem + (rt * 64 + lane) * 16);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      floatx16 z;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) z[e] = 0.0f;
+      dA[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bo[ct], z, 0, 0, 0);
+    }
+  }
+  off += (long)RT * 1024;
+
+  for (int l = L - 1; l >= 0; --l) {
+    // ---- dZ_l = relu'(act_l) (*) dA ; packed to the next MFMA's B fragments; stored feature-major ----
+    half8 bz[KS][2];
+    const _Float16* act = a.acts + (long)l * W * a.Sp;
+    _Float16* dzl = a.dz + (long)l * W * a.Sp;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const long s = tile0 + ct * 32 + col;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int feat = 32 * rt + (e & 3) + 8 * (e >> 2) + 4 * h;
+          const _Float16 av = act[(long)feat * a.Sp + s];
+          dA[rt][ct][e] = (float)av > 0.0f ? dA[rt][ct][e] : 0.0f;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const half8 v = pack8<false>(dA[rt][ct], s2);
+          bz[2 * rt + s2][ct] = v;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) dzl[(long)perm_feature(2 * rt + s2, h, j) * a.Sp + s] = v[j];
+        }
+      }
+    if (l == 0 && !a.dencT) break;
+    // ---- dA_{l-1} = W_l^T dZ_l ----
+    const int rows_t = l == 0 ? (a.E + 31) / 32 : RT;
+    __syncthreads();
+    stage_rt(a.packed + off, smem, rows_t * KS * 1024, tid);
+    __syncthreads();
+    off += (long)rows_t * KS * 1024;
+    if (l > 0) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        floatx16 acc[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[ct][e] = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+          const half8 af = *reinterpret_cast<const half8*>(smem + ((rt * KS + kk) * 64 + lane) * 16);
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bz[kk][ct], acc[ct], 0, 0, 0);
+        }
+        dA[rt][0] = acc[0];
+        dA[rt][1] = acc[1];
+      }
+    } else {
+      for (int rt = 0; rt < rows_t; ++rt) {
+        floatx16 acc[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[ct][e] = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+          const half8 af = *reinterpret_cast<const half8*>(smem + ((rt * KS + kk) * 64 + lane) * 16);
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bz[kk][ct], acc[ct], 0, 0, 0);
+        }
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          const long s = tile0 + ct * 32 + col;
+          const bool ok = s < a.S;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int feat = 32 * rt + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (feat < a.E) a.dencT[(long)feat * a.Sp + s] = ok ? (_Float16)acc[ct][e] : (_Float16)0.0f;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------- weight gradient
+// dW[o][i] += sum_s dZ[o][s] * X[i][s].  One wave = one 64x64 output super-tile over a chunk of
+// samples; grid = (super-tiles, sample chunks); block = 4 waves on 4 consecutive chunks.
+__global__ __launch_bounds__(kThreads) void wgrad_kernel(const _Float16* __restrict__ dZ, const _Float16* __restrict__ X,
+                                                         float* __restrict__ dW, int M, int N, long Sp, int tiles_n,
+                                                         long chunk) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  const long s_begin = ((long)blockIdx.y * 4 + wave) * chunk;
+  const long s_end = s_begin + chunk < Sp ? s_begin + chunk : Sp;
+  if (s_begin >= Sp) return;
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+  const int row0 = 64 * tm + r, row1 = row0 + 32, col0 = 64 * tn + r, col1 = col0 + 32;
+  const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (long s = s_begin; s < s_end; s += 16) {
+    const long so = s + 8 * h;
+    const half8 a0 = row0 < M ? *reinterpret_cast<const half8*>(dZ + (long)row0 * Sp + so) : zero;
+    const half8 a1 = row1 < M ? *reinterpret_cast<const half8*>(dZ + (long)row1 * Sp + so) : zero;
+    const half8 b0 = col0 < N ? *reinterpret_cast<const half8*>(X + (long)col0 * Sp + so) : zero;
+    const half8 b1 = col1 < N ? *reinterpret_cast<const half8*>(X + (long)col1 * Sp + so) : zero;
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int o = 64 * tm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int c = 64 * tn + 32 * j + r;
+        if (o < M && c < N) atomicAdd(&dW[(long)o * N + c], acc[i][j][e]);
+      }
+}
+
+// ------------------------------------------------------------------------- loss, optimizer
+__global__ __launch_bounds__(kThreads) void l2_loss_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                           long n, float scale, float* __restrict__ values,
+                                                           __half* __restrict__ grads, float* __restrict__ loss_sum) {
+  __shared__ float red[kThreads / 64];
+  float local = 0.0f;
+  for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
+    const float d = pred[i] - target[i];
+    const float v = d * d / (float)n;
+    const float g = scale * 2.0f * d / (float)n;
+    if (values) values[i] = v;
+    if (grads) grads[i] = __float2half(g);
+    local += v;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) local += __shfl_xor(local, d, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0 && loss_sum) {
+    float t = 0.0f;
+    for (int w = 0; w < kThreads / 64; ++w) t += red[w];
+    atomicAdd(loss_sum, t);
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void adam_kernel(long n, float* __restrict__ master, __half* __restrict__ params,
+                                                        const float* __restrict__ grads, float* __restrict__ m,
+                                                        float* __restrict__ v, float lr_eff, float beta1, float beta2,
+                                                        float eps, float inv_loss_scale) {
+  for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
+    const float g = grads[i] * inv_loss_scale;
+    const float mi = beta1 * m[i] + (1.0f - beta1) * g;
+    const float vi = beta2 * v[i] + (1.0f - beta2) * g * g;
+    m[i] = mi;
+    v[i] = vi;
+    const float w = master[i] - lr_eff * mi / (sqrtf(vi) + eps);
+    master[i] = w;
+    params[i] = __float2half(w);
+  }
+}
+
+int check_train(const rtxn_mlp* m, const char* who) {
+  if (!m) { rtxn::set_error("%s: NULL model", who); return RTXN_ERR_INVALID; }
+  if (!m->packed_train || !m->packed_t) { rtxn::set_error("%s: rtxn_mlp_set_params has not been called", who); return RTXN_ERR_INVALID; }
+  return RTXN_OK;
+}
+
+HgLevels levels_of(const rtxn_hashgrid* g) {
+  HgLevels lv;
+  memset(&lv, 0, sizeof(lv));
+  lv.n_levels = g->cfg.n_levels;
+  lv.n_features = g->cfg.n_features;
+  for (int l = 0; l < g->cfg.n_levels; ++l) { lv.scale[l] = g->scale[l]; lv.res[l] = g->res[l]; lv.size[l] = g->size[l]; lv.offset[l] = g->offset[l]; }
+  return lv;
+}
+
+}  // namespace
+
+// ============================================================================ C ABI
+extern "C" long rtxn_padded_samples(long n_samples) { return n_samples < 0 ? -1 : padded(n_samples); }
+
+extern "C" size_t rtxn_mlp_train_workspace_bytes(const rtxn_mlp* m, long n_samples) {
+  if (!m || n_samples < 0) return 0;
+  const long Sp = padded(n_samples), W = m->cfg.n_neurons, L = m->cfg.n_hidden_layers;
+  return (size_t)((2 * L * W + 16) * Sp) * sizeof(_Float16);
+}
+
+extern "C" int rtxn_encode_frequency(const rtxn_mlp* m, const float* input, void* encT, long n_samples,
+                                     rtxn_stream_t stream) {
+  RTXN_REQUIRE(m && m->cfg.encoding == RTXN_ENC_FREQUENCY, "rtxn_encode_frequency: model has no frequency encoding");
+  RTXN_REQUIRE(n_samples >= 0, "rtxn_encode_frequency: n_samples = %ld < 0", n_samples);
+  RTXN_DEVICE_OR_FAIL();
+  if (n_samples == 0) return RTXN_OK;
+  RTXN_REQUIRE(input && encT, "rtxn_encode_frequency: NULL buffer");
+  const long Sp = padded(n_samples);
+  encode_freq_kernel<<<(unsigned)(Sp / kThreads), kThreads, 0, rtxn::as_stream(stream)>>>(
+      input, static_cast<_Float16*>(encT), n_samples, Sp, m->cfg.n_pos_dims, m->cfg.n_pos_freqs, m->cfg.n_dir_dims,
+      m->cfg.n_dir_freqs, m->enc_padded);
+  RTXN_LAUNCH_CHECK("encode_freq_kernel");
+  return RTXN_OK;
+}
+
+extern "C" int rtxn_mlp_train_forward(const rtxn_mlp* m, const void* encT, long n_samples, void* workspace,
+                                      void* output_half, float* radiance, rtxn_stream_t stream) {
+  int rc = check_train(m, "rtxn_mlp_train_forward");
+  if (rc != RTXN_OK) return rc;
+  RTXN_REQUIRE(n_samples >= 0, "rtxn_mlp_train_forward: n_samples = %ld < 0", n_samples);
+  RTXN_DEVICE_OR_FAIL();
+  if (n_samples == 0) return RTXN_OK;
+  RTXN_REQUIRE(encT && workspace && output_half, "rtxn_mlp_train_forward: NULL buffer");
+  const int W = m->cfg.n_neurons;
+  const long Sp = padded(n_samples);
+  TrainArgs a;
+  memset(&a, 0, sizeof(a));
+  a.packed = static_cast<const uint8_t*>(m->packed_train);
+  a.n_hidden = m->cfg.n_hidden_layers;
+  a.out_act = m->cfg.output_activation;
+  a.E = m->enc_padded;
+  a.S = n_samples;
+  a.Sp = Sp;
+  a.encT = static_cast<const _Float16*>(encT);
+  a.acts = static_cast<_Float16*>(workspace);
+  a.out_half = static_cast<_Float16*>(output_half);
+  a.radiance = reinterpret_cast<float4*>(radiance);
+  const int RT = W / 32, KS = W / 16, KS0 = a.E / 16;
+  const size_t lds = (size_t)(KS0 > KS ? KS0 : KS) * RT * 1024;
+  hipStream_t s = rtxn::as_stream(stream);
+  if (W == 64) {
+    RTXN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_train_fwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(mlp_train_fwd_kernel<64>, dim3((unsigned)(Sp / kTile)), dim3(kThreads), lds, s, a);
+  } else {
+    RTXN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_train_fwd_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(mlp_train_fwd_kernel<128>, dim3((unsigned)(Sp / kTile)), dim3(kThreads), lds, s, a);
+  }
+  RTXN_LAUNCH_CHECK("mlp_train_fwd_kernel");
+  return RTXN_OK;
+}
+
+extern "C" int rtxn_mlp_train_backward(const rtxn_mlp* m, const void* encT, const void* output_half,
+                                       const void* dout_half4, long n_samples, void* workspace, float* dparams,
+                                       void* dencT, rtxn_stream_t stream) {
+  int rc = check_train(m, "rtxn_mlp_train_backward");
+  if (rc != RTXN_OK) return rc;
+  RTXN_REQUIRE(n_samples >= 0, "rtxn_mlp_train_backward: n_samples = %ld < 0", n_samples);
+  RTXN_DEVICE_OR_FAIL();
+  if (n_samples == 0) return RTXN_OK;
+  RTXN_REQUIRE(encT && output_half && dout_half4 && workspace && dparams, "rtxn_mlp_train_backward: NULL buffer");
+  const int W = m->cfg.n_neurons, L = m->cfg.n_hidden_layers, E = m->enc_padded;
+  const long Sp = padded(n_samples);
+  _Float16* ws = static_cast<_Float16*>(workspace);
+  TrainArgs a;
+  memset(&a, 0, sizeof(a));
+  a.packed = static_cast<const uint8_t*>(m->packed_t);
+  a.n_hidden = L;
+  a.out_act = m->cfg.output_activation;
+  a.E = E;
+  a.S = n_samples;
+  a.Sp = Sp;
+  a.encT = static_cast<const _Float16*>(encT);
+  a.acts = ws;
+  a.dz = ws + (long)L * W * Sp;
+  a.dzL = ws + 2L * L * W * Sp;
+  a.out_half = const_cast<_Float16*>(static_cast<const _Float16*>(output_half));
+  a.dout = static_cast<const _Float16*>(dout_half4);
+  a.dencT = static_cast<_Float16*>(dencT);
+  const int RT = W / 32, KS = W / 16, RTE = (E + 31) / 32;
+  const size_t lds = (size_t)(RTE > RT ? RTE : RT) * KS * 1024;
+  hipStream_t s = rtxn::as_stream(stream);
+  if (W == 64) {
+    RTXN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(mlp_bwd_kernel<64>, dim3((unsigned)(Sp / kTile)), dim3(kThreads), lds, s, a);
+  } else {
+    RTXN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(mlp_bwd_kernel<128>, dim3((unsigned)(Sp / kTile)), dim3(kThreads), lds, s, a);
+  }
+  RTXN_LAUNCH_CHECK("mlp_bwd_kernel");
+  // per-layer weight gradients: dW_l += dZ_l X_l^T, X_0 = enc, X_l = acts[l-1], X_L = acts[L-1]
+  const long chunk = 2048;
+  const unsigned kblocks = (unsigned)((Sp + 4 * chunk - 1) / (4 * chunk));
+  long poff = 0;
+  for (int l = 0; l <= L; ++l) {
+    const int M = l == L ? 16 : W, N = l == 0 ? E : W;
+    const _Float16* dz = l == L ? a.dzL : a.dz + (long)l * W * Sp;
+    const _Float16* x = l == 0 ? a.encT : a.acts + (long)(l - 1) * W * Sp;
+    const int tiles_m = (M + 63) / 64, tiles_n = (N + 63) / 64;
+    wgrad_kernel<<<dim3((unsigned)(tiles_m * tiles_n), kblocks), kThreads, 0, s>>>(dz, x, dparams + poff, M, N, Sp, tiles_n, chunk);
+    RTXN_LAUNCH_CHECK("wgrad_kernel");
+    poff += (long)M * N;
+  }
+  return RTXN_OK;
+}
+
+extern "C" int rtxn_hashgrid_create(const rtxn_hashgrid_config* cfg, rtxn_hashgrid** out) {
+  RTXN_REQUIRE(cfg && out, "rtxn_hashgrid_create: NULL argument");
+  RTXN_REQUIRE(cfg->n_levels >= 1 && cfg->n_levels <= 16, "rtxn_hashgrid_create: n_levels = %d not in [1,16]", cfg->n_levels);
+  RTXN_REQUIRE(cfg->n_features == 1 || cfg->n_features == 2 || cfg->n_features == 4 || cfg->n_features == 8,
+               "rtxn_hashgrid_create: n_features = %d not in {1,2,4,8}", cfg->n_features);
+  RTXN_REQUIRE(cfg->log2_hashmap_size >= 4 && cfg->log2_hashmap_size <= 24, "rtxn_hashgrid_create: log2_hashmap_size = %d",
+               cfg->log2_hashmap_size);
+  RTXN_REQUIRE(cfg->base_resolution >= 1 && cfg->per_level_scale >= 1.0f, "rtxn_hashgrid_create: bad resolution/scale");
+  rtxn_hashgrid* g = new rtxn_hashgrid();
+  g->cfg = *cfg;
+  unsigned off = 0;
+  for (int l = 0; l < cfg->n_levels; ++l) {
+    const float s = exp2f((float)l * log2f(cfg->per_level_scale)) * (float)cfg->base_resolution - 1.0f;
+    const unsigned r = (unsigned)ceilf(s) + 1u;
+    unsigned long long dense = (unsigned long long)r * r * r;
+    dense = (dense + 7ull) / 8ull * 8ull;
+    const unsigned long long cap = 1ull << cfg->log2_hashmap_size;
+    const unsigned sz = (unsigned)(dense < cap ? dense : cap);
+    g->scale[l] = s; g->res[l] = r; g->size[l] = sz; g->offset[l] = off;
+    off += sz;
+  }
+  g->n_params = (long)off * cfg->n_features;
+  *out = g;
+  return RTXN_OK;
+}
+
+extern "C" int rtxn_hashgrid_destroy(rtxn_hashgrid* g) { delete g; return RTXN_OK; }
+extern "C" long rtxn_hashgrid_n_params(const rtxn_hashgrid* g) { return g ? g->n_params : -1; }
+extern "C" int rtxn_hashgrid_encoded_width(const rtxn_hashgrid* g, int n_dir_freqs) {
+  if (!g || n_dir_freqs < 0) return -1;
+  return (g->cfg.n_levels * g->cfg.n_features + 4 * n_dir_freqs + 15) / 16 * 16;
+}
+
+extern "C" int rtxn_hashgrid_encode(const rtxn_hashgrid* g, int n_dir_freqs, const void* table_fp16, const float* input,
+                                    void* encT, long n_samples, rtxn_stream_t stream) {
+  RTXN_REQUIRE(g && n_dir_freqs >= 0 && n_dir_freqs <= 16, "rtxn_hashgrid_encode: bad argument");
+  RTXN_REQUIRE(n_samples >= 0, "rtxn_hashgrid_encode: n_samples = %ld < 0", n_samples);
+  RTXN_DEVICE_OR_FAIL();
+  if (n_samples == 0) return RTXN_OK;
+  RTXN_REQUIRE(table_fp16 && input && encT, "rtxn_hashgrid_encode: NULL buffer");
+  const long Sp = padded(n_samples);
+  const int E = rtxn_hashgrid_encoded_width(g, n_dir_freqs);
+  hashgrid_encode_kernel<<<dim3((unsigned)(Sp / kThreads), (unsigned)(g->cfg.n_levels + 1)), kThreads, 0, rtxn::as_stream(stream)>>>(
+      levels_of(g), n_dir_freqs, static_cast<const _Float16*>(table_fp16), input, static_cast<_Float16*>(encT), n_samples, Sp, E);
+  RTXN_LAUNCH_CHECK("hashgrid_encode_kernel");
+  return RTXN_OK;
+}
+
+extern "C" int rtxn_hashgrid_backward(const rtxn_hashgrid* g, const float* input, const void* dencT, long n_samples,
+                                      float* dtable, rtxn_stream_t stream) {
+  RTXN_REQUIRE(g, "rtxn_hashgrid_backward: NULL grid");
+  RTXN_REQUIRE(n_samples >= 0, "rtxn_hashgrid_backward: n_samples = %ld < 0", n_samples);
+  RTXN_DEVICE_OR_FAIL();
+  if (n_samples == 0) return RTXN_OK;
+  RTXN_REQUIRE(input && dencT && dtable, "rtxn_hashgrid_backward: NULL buffer");
+  const long Sp = padded(n_samples);
+  hashgrid_backward_kernel<<<dim3((unsigned)((n_samples + kThreads - 1) / kThreads), (unsigned)g->cfg.n_levels), kThreads, 0,
+                             rtxn::as_stream(stream)>>>(levels_of(g), input, static_cast<const _Float16*>(dencT), n_samples, Sp, dtable);
+  RTXN_LAUNCH_CHECK("hashgrid_backward_kernel");
+  return RTXN_OK;
+}
+
+extern "C" int rtxn_l2_loss(const float* pred, const float* target, long n, float loss_scale, float* values,
+                            void* grads_half, float* loss_sum, rtxn_stream_t stream) {
+  RTXN_REQUIRE(n >= 0, "rtxn_l2_loss: n = %ld < 0", n);
+  RTXN_DEVICE_OR_FAIL();
+  hipStream_t s = rtxn::as_stream(stream);
+  if (loss_sum) RTXN_HIP(hipMemsetAsync(loss_sum, 0, sizeof(float), s));
+  if (n == 0) return RTXN_OK;
+  RTXN_REQUIRE(pred && target, "rtxn_l2_loss: NULL buffer");
+  const unsigned blocks = (unsigned)((n + kThreads - 1) / kThreads < 1024 ? (n + kThreads - 1) / kThreads : 1024);
+  l2_loss_kernel<<<blocks, kThreads, 0, s>>>(pred, target, n, loss_scale, values, static_cast<__half*>(grads_half), loss_sum);
+  RTXN_LAUNCH_CHECK("l2_loss_kernel");
+  return RTXN_OK;
+}
+
+extern "C" int rtxn_adam_step(long n, float* master, void* params_fp16, const float* grads, float* m, float* v, int step,
+                              float lr, float beta1, float beta2, float eps, float loss_scale, rtxn_stream_t stream) {
+  RTXN_REQUIRE(n >= 0 && step >= 1, "rtxn_adam_step: n = %ld, step = %d", n, step);
+  RTXN_REQUIRE(loss_scale != 0.0f, "rtxn_adam_step: loss_scale = 0");
+  RTXN_DEVICE_OR_FAIL();
+  if (n == 0) return RTXN_OK;
+  RTXN_REQUIRE(master && params_fp16 && grads && m && v, "rtxn_adam_step: NULL buffer");
+  const float lr_eff = lr * sqrtf(1.0f - powf(beta2, (float)step)) / (1.0f - powf(beta1, (float)step));
+  const unsigned blocks = (unsigned)((n + kThreads - 1) / kThreads < 2048 ? (n + kThreads - 1) / kThreads : 2048);
+  adam_kernel<<<blocks, kThreads, 0, rtxn::as_stream(stream)>>>(n, master, static_cast<__half*>(params_fp16), grads, m, v, lr_eff,
+                                                               beta1, beta2, eps, 1.0f / loss_scale);
+  RTXN_LAUNCH_CHECK("adam_kernel");
+  return RTXN_OK;
+}

@@ -40,7 +40,7 @@ def test_struct_layouts_match_header_order():
         for part in decl.split(","):
             fields.append(re.findall(r"([A-Za-z_][A-Za-z0-9_]*)\s*$", part.strip())[0])
     assert fields == [f[0] for f in _lib.TraceParams._fields_]
-    assert C.sizeof(_lib.MlpConfig) == 32
+    assert C.sizeof(_lib.MlpConfig) == 40
 
 
 def test_no_cpu_fallback():
