@@ -53,7 +53,10 @@ const char* rtxn_last_error(void);
 enum rtxn_sampling_type {
   RTXN_SAMPLING_REGULAR = 0,
   RTXN_SAMPLING_STRATIFIED_JITTERING = 1,
-  RTXN_SAMPLING_UNIFORM = 2
+  RTXN_SAMPLING_UNIFORM = 2,
+  /* not in the reference: sample i at the MIDPOINT t = (i+0.5)/32 of its sub-interval, and t_vals = the
+   * sub-interval's world-space length |end-start|/32 -- the inputs RTXN_VR_NERF expects */
+  RTXN_SAMPLING_MIDPOINT_WORLD = 3
 };
 
 /* ---- traversal ------------------------------------------------------------ */

@@ -398,6 +398,9 @@ void orc_sample(const float* start_points, const float* end_points, const float*
           t = t_initial;
           t_initial += inc;
           tv = t_initial;
+        } else if (sample_type == 3) { /* MIDPOINT_WORLD (this build, for RTXN_VR_NERF) */
+          t = ((float)i + 0.5f) * inc;
+          tv = sqrtf(fmaf(dir[2], dir[2], fmaf(dir[0], dir[0], dir[1] * dir[1]))) * inc;
         } else if (sample_type == 2) { /* UNIFORM :67-80 */
           rng = minstd_next(rng);
           t = thrust_uniform(rng, 0.0f, 1.0f);

@@ -18,6 +18,7 @@ NUM_SAMPLES_PER_SEGMENT = 32           # sampler/sampler.h:4
 SAMPLING_REGULAR = 0                   # sampler/sampler.h:5-9
 SAMPLING_STRATIFIED_JITTERING = 1
 SAMPLING_UNIFORM = 2
+SAMPLING_MIDPOINT_WORLD = 3               # this build: midpoints + world step lengths (for VR_NERF)
 TRACE_COMPAT, TRACE_DDA = 0, 1
 VR_COMPAT, VR_NERF = 0, 1
 ACT_NONE, ACT_SIGMOID = 0, 1

@@ -61,6 +61,12 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ s
     if (TYPE == RTXN_SAMPLING_REGULAR) {
       t = (float)i * inc;  // i repeated additions of 2^-5 are exact
       tv = (float)(i + 1) * inc;
+    } else if (TYPE == RTXN_SAMPLING_MIDPOINT_WORLD) {
+      t = ((float)i + 0.5f) * inc;
+      const long g = (seg0 + min(lane >> 5, nseg - 1)) * 3;
+      const float dx = end_points[g] - start_points[g], dy = end_points[g + 1] - start_points[g + 1],
+                  dz = end_points[g + 2] - start_points[g + 2];
+      tv = sqrtf(fmaf(dz, dz, fmaf(dx, dx, dy * dy))) * inc;
     } else {
       uint32_t draw = (uint32_t)(j0 + (lane >> 5)) * K + i + 1;
       uint32_t x = minstd_pow(draw);  // seed 1
@@ -104,7 +110,7 @@ extern "C" int rtxn_sample(const float* start_points, const float* end_points, c
                            const int* num_hits, const int* indices, int sample_type, rtxn_stream_t stream) {
   (void)grid_res;
   RTXN_REQUIRE(batch_size >= 0, "rtxn_sample: batch_size = %d < 0", batch_size);
-  RTXN_REQUIRE(sample_type >= 0 && sample_type <= 2, "rtxn_sample: unknown sample_type %d", sample_type);
+  RTXN_REQUIRE(sample_type >= 0 && sample_type <= 3, "rtxn_sample: unknown sample_type %d", sample_type);
   RTXN_DEVICE_OR_FAIL();
   if (batch_size == 0) return RTXN_OK;
   RTXN_REQUIRE(start_points && end_points && view_dirs && t_vals && sampled_points && num_hits && indices,
@@ -120,9 +126,13 @@ extern "C" int rtxn_sample(const float* start_points, const float* end_points, c
       sample_kernel<RTXN_SAMPLING_STRATIFIED_JITTERING><<<grid, block, 0, s>>>(
           start_points, end_points, view_dirs, t_vals, sampled_points, batch_size, num_hits, indices);
       break;
-    default:
+    case RTXN_SAMPLING_UNIFORM:
       sample_kernel<RTXN_SAMPLING_UNIFORM><<<grid, block, 0, s>>>(start_points, end_points, view_dirs, t_vals,
                                                                    sampled_points, batch_size, num_hits, indices);
+      break;
+    default:
+      sample_kernel<RTXN_SAMPLING_MIDPOINT_WORLD><<<grid, block, 0, s>>>(start_points, end_points, view_dirs, t_vals,
+                                                                          sampled_points, batch_size, num_hits, indices);
       break;
   }
   RTXN_LAUNCH_CHECK("sample_kernel");

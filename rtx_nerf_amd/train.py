@@ -1,0 +1,172 @@
+"""Training-step orchestration on one GPU: the counterpart of the reference's
+training loop (main.cu:612-805) over the C ABI.
+
+Per step (stage order of main.cu, host round trips removed):
+  rays -> trace(count) -> scan -> trace(write packed CSR)        main.cu:463-543,631-673
+       -> sampler                                                :704
+       -> encoding + network->forward (activations kept)         :715-728
+       -> volume render forward                                  :737
+       -> L2 loss                                                :759
+       -> volume render backward                                 :767
+       -> network->backward (+ hash-grid scatter)                :781
+       -> Adam on the fp32 master copy, fp16 params re-packed    :787
+The reference's per-batch cudaMalloc/cudaFree (:667-694,794-801) and host re-pack
+(:646-673) do not exist here: every buffer is allocated once at capacity.
+
+`mode`: "compat" reproduces the reference's arithmetic (REGULAR samples,
+RTXN_VR_COMPAT forward/backward -- whose backward is not the gradient of its
+forward); "nerf" is the corrected path (midpoint samples, world-space
+steps, exact gradients) that actually converges.  All arithmetic is in librtxn.so;
+torch only owns buffers and a few trivial elementwise glue ops.
+"""
+import torch
+
+from . import api
+
+
+class Trainer:
+    def __init__(self, grid_res, occupancy=None, encoding="hash", n_neurons=64, n_hidden_layers=4,
+                 hashgrid=None, n_dir_freqs=4, batch_rays=4096, max_segments=None, lr=1e-3, loss_scale=128.0,
+                 density_scale=1.0, mode="nerf", seed=1337, device="cuda"):
+        self.R = grid_res
+        self.dev = torch.device(device)
+        self.occ = occupancy
+        self.coarse = api.build_occupancy_mip(occupancy, grid_res) if (occupancy is not None and grid_res % 4 == 0) else None
+        self.B = batch_rays
+        self.mode = mode
+        self.lr, self.loss_scale, self.density_scale = lr, loss_scale, density_scale
+        self.step_count = 0
+        d = self.dev
+        # ---- model -------------------------------------------------------------------------------
+        self.encoding = encoding
+        if encoding == "hash":
+            self.hg = api.HashGrid(n_dir_freqs=n_dir_freqs, **(hashgrid or {}))
+            E = self.hg.encoded_width()
+            self.net = api.Network(n_neurons=n_neurons, n_hidden_layers=n_hidden_layers, n_encoded_features=E)
+            g = torch.Generator().manual_seed(seed + 1)
+            self.table_master = ((torch.rand(self.hg.n_params(), generator=g) * 2 - 1) * 1e-4).to(d)   # tcnn: U(-1e-4, 1e-4)
+            self.table = self.table_master.half()
+            self.table_m = torch.zeros_like(self.table_master)
+            self.table_v = torch.zeros_like(self.table_master)
+            self.dtable = torch.zeros_like(self.table_master)
+        else:
+            self.hg = None
+            self.net = api.Network(n_neurons=n_neurons, n_hidden_layers=n_hidden_layers)
+            E = self.net.encoded_width()
+        self.E = E
+        self.master = self.net.initialize_params(seed).to(d)       # fp32 master (main.cu:328-349)
+        self.params = self.master.half()                           # fp16 params
+        self.adam_m = torch.zeros_like(self.master)
+        self.adam_v = torch.zeros_like(self.master)
+        self.dparams = torch.zeros_like(self.master)
+        self.net.set_params(self.params)
+        # ---- per-step buffers at capacity ---------------------------------------------------------
+        B = batch_rays
+        self.max_segments = int(max_segments) if max_segments else 64 * B
+        M, K = self.max_segments, api.NUM_SAMPLES_PER_SEGMENT
+        self.view_dirs = torch.empty((B, 2), device=d)
+        self.num_hits = torch.empty(B, dtype=torch.int32, device=d)
+        self.indices = torch.empty(B, dtype=torch.int32, device=d)
+        self.total = torch.zeros(1, dtype=torch.int32, device=d)
+        self.scan_ws = torch.empty((api._lib.lib().rtxn_scan_workspace_bytes(B) + 3) // 4, dtype=torch.int32, device=d)
+        self.start = torch.empty((M, 3), device=d)
+        self.end = torch.empty((M, 3), device=d)
+        self.samples = torch.empty((M * K, 5), device=d)
+        self.t_vals = torch.empty(M * K, device=d)
+        Sp = api.padded_samples(M * K)
+        self.encT = torch.empty((E, Sp), dtype=torch.float16, device=d)
+        self.dencT = torch.empty((E, Sp), dtype=torch.float16, device=d) if encoding == "hash" else None
+        self.ws = self.net.train_workspace(M * K, device=d)
+        self.out = torch.empty((M * K, 16), dtype=torch.float16, device=d)
+        self.radiance = torch.empty((M * K, 4), device=d)
+        self.dout = torch.empty((M * K, 4), dtype=torch.float16, device=d)
+        self.pixels = torch.empty((B, 3), device=d)
+        self.loss_grads = torch.empty((B, 3), dtype=torch.float16, device=d)
+        self.loss = torch.zeros(1, device=d)
+
+    # ------------------------------------------------------------------------------------------
+    def _segments(self, rays_o, rays_d, n):
+        kw = dict(grid_res=self.R, rays_o=rays_o, rays_d=rays_d, width=n, height=1, ray_begin=0, ray_count=n,
+                  occupancy=self.occ, occupancy_coarse=self.coarse, mode=api.TRACE_DDA,
+                  viewing_direction=self.view_dirs, num_hits=self.num_hits)
+        api.trace_grid(None, **kw)
+        api.scan_hits(self.num_hits[:n], self.indices[:n], self.total, self.scan_ws)
+        api.trace_grid(None, indices=self.indices, start_points=self.start, end_points=self.end,
+                       segment_capacity=self.max_segments, **kw)
+        P = int(self.total.item())            # the reference synchronises here too (thrust::reduce, main.cu:632)
+        if P > self.max_segments:
+            raise RuntimeError(f"batch needs {P} segments, capacity {self.max_segments}")
+        return P
+
+    def _sample(self, n, P):
+        stype = api.SAMPLING_MIDPOINT_WORLD if self.mode == "nerf" else api.SAMPLING_REGULAR
+        api.launchSampler(self.start, self.end, self.view_dirs, self.t_vals, self.samples, n, self.R, self.num_hits,
+                          self.indices, stype)
+        if self.mode == "nerf" and self.density_scale != 1.0:
+            self.t_vals[:P * api.NUM_SAMPLES_PER_SEGMENT].mul_(self.density_scale)
+
+    def _forward(self, S):
+        if self.encoding == "hash":
+            self.hg.encode(self.table, self.samples[:S], self.encT)
+        else:
+            self.net.encode_frequency(self.samples[:S], self.encT)
+        self.net.train_forward(self.encT, S, self.ws, self.out, self.radiance)
+
+    def render_rays(self, rays_o, rays_d, radiance_fn=None):
+        """Forward only.  radiance_fn(samples[S,5]) -> float[S,4] replaces the network (teacher rendering)."""
+        n = rays_o.shape[0]
+        P = self._segments(rays_o, rays_d, n)
+        S = P * api.NUM_SAMPLES_PER_SEGMENT
+        self._sample(n, P)
+        if S:
+            if radiance_fn is None:
+                self._forward(S)
+            else:
+                self.radiance[:S] = radiance_fn(self.samples[:S])
+        vr = api.VR_NERF if self.mode == "nerf" else api.VR_COMPAT
+        api.launch_volrender_cuda(None, self.radiance, self.num_hits, self.indices, self.t_vals, n,
+                                  api.NUM_SAMPLES_PER_SEGMENT, self.pixels[:n], mode=vr)
+        return self.pixels[:n]
+
+    def step(self, rays_o, rays_d, targets):
+        """One optimisation step on a batch of rays; returns the (device) loss scalar."""
+        n = rays_o.shape[0]
+        K = api.NUM_SAMPLES_PER_SEGMENT
+        vr = api.VR_NERF if self.mode == "nerf" else api.VR_COMPAT
+        self.step_count += 1
+        P = self._segments(rays_o, rays_d, n)
+        S = P * K
+        self._sample(n, P)
+        if S == 0:
+            return self.loss.zero_()
+        self._forward(S)
+        api.launch_volrender_cuda(None, self.radiance, self.num_hits, self.indices, self.t_vals, n, K, self.pixels[:n],
+                                  mode=vr)
+        api.l2_loss(self.pixels[:n], targets, self.loss_scale, None, self.loss_grads[:n], self.loss)
+        api.launch_volrender_backward_cuda(None, self.loss_grads, self.radiance, self.t_vals, self.num_hits,
+                                           self.indices, n, K, self.dout, mode=vr)
+        self.dparams.zero_()
+        self.net.train_backward(self.encT, self.out, self.dout, S, self.ws, self.dparams, self.dencT)
+        api.adam_step(self.master, self.params, self.dparams, self.adam_m, self.adam_v, self.step_count, lr=self.lr,
+                      loss_scale=self.loss_scale)
+        self.net.set_params(self.params)
+        if self.encoding == "hash":
+            self.dtable.zero_()
+            self.hg.backward(self.samples[:S], self.dencT, self.dtable)
+            api.adam_step(self.table_master, self.table, self.dtable, self.table_m, self.table_v, self.step_count,
+                          lr=self.lr * 10.0, eps=1e-15, loss_scale=self.loss_scale)
+        return self.loss
+
+
+def camera_rays(look_at, focal, width, height, device="cuda", origin_scale=0.1):
+    """Pinhole rays of optixPrograms.cu:43-82 as explicit (o, d) tensors (host-side helper for building
+    training batches from several poses; the arithmetic that matters happens in rtxn_trace_grid)."""
+    la = torch.as_tensor(look_at, dtype=torch.float64).reshape(4, 4)
+    xs = (2 * (torch.arange(width, dtype=torch.float64) + 0.5) / width - 1) * (width / height)
+    ys = 2 * (torch.arange(height, dtype=torch.float64) + 0.5) / height - 1
+    v, u = torch.meshgrid(ys, xs, indexing="ij")
+    dirs = torch.stack([u, v, -torch.full_like(u, focal)], dim=-1).reshape(-1, 3)
+    d = dirs @ la[:3, :3].T
+    d = d / d.norm(dim=1, keepdim=True)
+    o = (la[:3, 3] * origin_scale).expand_as(d)
+    return o.float().contiguous().to(device), d.float().contiguous().to(device)

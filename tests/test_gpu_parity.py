@@ -189,7 +189,7 @@ def _ragged_segments(rng, B, max_hits):
     return nh, idx, P, sp, ep, vd
 
 
-@pytest.mark.parametrize("sample_type", [0, 1, 2])
+@pytest.mark.parametrize("sample_type", [0, 1, 2, 3])
 @pytest.mark.parametrize("B,max_hits", [(64, 7), (1, 1), (1000, 46), (5, 0)])
 def test_sampler_bit_exact(gpu, oracle, sample_type, B, max_hits):
     torch = gpu
