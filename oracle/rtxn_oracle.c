@@ -777,7 +777,7 @@ long orc_hg_n_params(const orc_hg_cfg* c) {
 
 static inline unsigned hg_index(unsigned x, unsigned y, unsigned z, unsigned res, unsigned size) {
   unsigned long long dense = (unsigned long long)res * res * res;
-  if (dense <= size) return x + y * res + z * res * res;          /* dense level */
+  if (dense <= size) return (x + y * res + z * res * res) % size; /* dense level; the +1 corner of a boundary cell wraps (tcnn: index % hashmap_size) */
   return ((x * 1u) ^ (y * 2654435761u) ^ (z * 805459861u)) % size; /* coherent prime hash */
 }
 

@@ -79,7 +79,9 @@ struct HgLevels {
 
 __device__ __forceinline__ unsigned hg_index(unsigned x, unsigned y, unsigned z, unsigned res, unsigned size) {
   const unsigned long long dense = (unsigned long long)res * res * res;
-  if (dense <= size) return x + y * res + z * res * res;
+  // the +1 corner of a boundary cell indexes one past the level's extent; like tcnn's grid_index the
+  // result is reduced modulo the level size, so it wraps instead of leaving the level
+  if (dense <= size) return (x + y * res + z * res * res) % size;
   return ((x * 1u) ^ (y * 2654435761u) ^ (z * 805459861u)) % size;
 }
 
@@ -130,38 +132,67 @@ __global__ __launch_bounds__(kThreads) void hashgrid_encode_kernel(HgLevels lv, 
   }
 }
 
-__global__ __launch_bounds__(kThreads) void hashgrid_backward_kernel(HgLevels lv, const float* __restrict__ in,
+// Scatter-add of dL/d(encoding) into the table gradient.  Fine (hashed) levels: one fp32
+// global atomic per (sample, corner, feature) -- addresses are spread, contention is low.
+// Coarse levels (whole level <= 64 KiB of fp32) are hit by every sample of every block, and
+// global float atomics on a few hot lines run an order of magnitude below their spread-out rate
+// (MI355X_MICROARCH.md, Global float atomics: contention), so those levels are first reduced in
+// an LDS copy of the level (ds_add_f32) per 8192-sample chunk and flushed once per block.
+constexpr int kHgLdsFloats = 16384;
+constexpr int kHgChunk = 8192;
+
+template <bool LDS>
+__global__ __launch_bounds__(kThreads) void hashgrid_backward_kernel(HgLevels lv, int level0, const float* __restrict__ in,
                                                                      const _Float16* __restrict__ dencT, long S, long Sp,
                                                                      float* __restrict__ dtable) {
-  const long s = (long)blockIdx.x * kThreads + threadIdx.x;
-  if (s >= S) return;
-  const int l = blockIdx.y;
+  extern __shared__ float hist[];
+  const int l = level0 + blockIdx.y;
   const int F = lv.n_features;
-  float fr[3];
-  unsigned g[3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    const float x01 = fmaf(in[5 * s + a], 0.5f, 0.5f);
-    const float p = fmaf(x01, lv.scale[l], 0.5f), fl = floorf(p);
-    g[a] = (unsigned)(int)fl;
-    fr[a] = p - fl;
+  const int n_entries = (int)lv.size[l] * F;
+  float* gdst = dtable + (size_t)lv.offset[l] * F;
+  if (LDS) {
+    for (int i = threadIdx.x; i < n_entries; i += kThreads) hist[i] = 0.0f;
+    __syncthreads();
   }
-  float d[8];
-  for (int f = 0; f < F && f < 8; ++f) d[f] = (float)dencT[(long)(l * F + f) * Sp + s];
-#pragma unroll
-  for (int corner = 0; corner < 8; ++corner) {
-    float w = 1.0f;
-    unsigned p[3];
+  const long s_begin = LDS ? (long)blockIdx.x * kHgChunk : (long)blockIdx.x * kThreads;
+  const long s_end = LDS ? (s_begin + kHgChunk < S ? s_begin + kHgChunk : S) : (s_begin + kThreads < S ? s_begin + kThreads : S);
+  for (long s = s_begin + threadIdx.x; s < s_end; s += kThreads) {
+    float fr[3];
+    unsigned g[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      const int hi = (corner >> a) & 1;
-      w *= hi ? fr[a] : 1.0f - fr[a];
-      p[a] = g[a] + (unsigned)hi;
+      const float x01 = fmaf(in[5 * s + a], 0.5f, 0.5f);
+      const float p = fmaf(x01, lv.scale[l], 0.5f), fl = floorf(p);
+      g[a] = (unsigned)(int)fl;
+      fr[a] = p - fl;
     }
-    const unsigned idx = hg_index(p[0], p[1], p[2], lv.res[l], lv.size[l]);
-    for (int f = 0; f < F && f < 8; ++f) {
-      const float v = w * d[f];
-      if (v != 0.0f) atomicAdd(&dtable[((size_t)lv.offset[l] + idx) * F + f], v);
+    float d[8];
+    for (int f = 0; f < F && f < 8; ++f) d[f] = (float)dencT[(long)(l * F + f) * Sp + s];
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner) {
+      float w = 1.0f;
+      unsigned p[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const int hi = (corner >> a) & 1;
+        w *= hi ? fr[a] : 1.0f - fr[a];
+        p[a] = g[a] + (unsigned)hi;
+      }
+      const unsigned idx = hg_index(p[0], p[1], p[2], lv.res[l], lv.size[l]);
+      for (int f = 0; f < F && f < 8; ++f) {
+        const float v = w * d[f];
+        if (v != 0.0f) {
+          if (LDS) atomicAdd(&hist[idx * F + f], v);
+          else atomicAdd(&gdst[(size_t)idx * F + f], v);
+        }
+      }
+    }
+  }
+  if (LDS) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_entries; i += kThreads) {
+      const float v = hist[i];
+      if (v != 0.0f) atomicAdd(&gdst[i], v);
     }
   }
 }
@@ -690,8 +721,20 @@ extern "C" int rtxn_hashgrid_backward(const rtxn_hashgrid* g, const float* input
   if (n_samples == 0) return RTXN_OK;
   RTXN_REQUIRE(input && dencT && dtable, "rtxn_hashgrid_backward: NULL buffer");
   const long Sp = padded(n_samples);
-  hashgrid_backward_kernel<<<dim3((unsigned)((n_samples + kThreads - 1) / kThreads), (unsigned)g->cfg.n_levels), kThreads, 0,
-                             rtxn::as_stream(stream)>>>(levels_of(g), input, static_cast<const _Float16*>(dencT), n_samples, Sp, dtable);
+  int n_small = 0;
+  while (n_small < g->cfg.n_levels && (long)g->size[n_small] * g->cfg.n_features <= kHgLdsFloats) ++n_small;
+  hipStream_t st = rtxn::as_stream(stream);
+  const HgLevels lv = levels_of(g);
+  if (n_small > 0) {
+    hashgrid_backward_kernel<true><<<dim3((unsigned)((n_samples + kHgChunk - 1) / kHgChunk), (unsigned)n_small), kThreads,
+                                     kHgLdsFloats * sizeof(float), st>>>(lv, 0, input, static_cast<const _Float16*>(dencT),
+                                                                         n_samples, Sp, dtable);
+    RTXN_LAUNCH_CHECK("hashgrid_backward_kernel<lds>");
+  }
+  if (n_small < g->cfg.n_levels)
+    hashgrid_backward_kernel<false><<<dim3((unsigned)((n_samples + kThreads - 1) / kThreads), (unsigned)(g->cfg.n_levels - n_small)),
+                                      kThreads, 0, st>>>(lv, n_small, input, static_cast<const _Float16*>(dencT), n_samples, Sp,
+                                                         dtable);
   RTXN_LAUNCH_CHECK("hashgrid_backward_kernel");
   return RTXN_OK;
 }
