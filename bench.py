@@ -33,6 +33,21 @@ import torch.distributed as dist
 MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense
 
 
+def pmc_traffic(samples_per_launch):
+    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary
+    (profiles/rNN/mlp_fwd_pmc.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections applied as
+    MI355X_MICROARCH.md prescribes), scaled to this run's launch size; None if no summary exists."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "mlp_fwd_pmc.json")))
+    if not files or not samples_per_launch:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        return int(d["hbm_bytes_per_launch_high"] * samples_per_launch / d["samples_per_launch"])
+    except Exception:
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -189,7 +204,7 @@ def main():
             out["roofline"] = {
                 "kernel": "mlp_fwd_kernel<128,...,segments,radiance>" if args.neurons == 128 else "mlp_fwd_kernel",
                 "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(ach / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": pmc_traffic(smp),
                 "flop_per_sample": flops, "samples_per_launch": smp, "kernel_ms": round(ms, 4),
             }
         out["config"]["segments_per_frame_local_max"] = worst

@@ -324,6 +324,184 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// 256-wide variant (BASELINE config 5: 8x256)
+// ---------------------------------------------------------------------------
+// One 256x256 layer is 128 KiB of A fragments -- it cannot be double-buffered in 160 KiB of LDS.
+// The row-tile-outer loop only ever needs ONE row tile's fragments at a time, so the weights
+// stream through a ring of three 32-KiB slots in chunks of two row tiles (2 x 16 k-steps x 1 KiB),
+// two chunks ahead of the MFMAs; one barrier per chunk.  A wave owns one 32-sample column tile
+// (bf + nbf = 128 VGPRs at K = 256), a 512-thread block owns 256 samples; 8 waves share every
+// staged chunk.
+constexpr int kThreads256 = 512;
+constexpr int kSlot256 = 32 * 1024;
+
+__device__ __forceinline__ void stage512(const uint8_t* __restrict__ g, uint8_t* lds_buf, int bytes, int tid) {
+  for (int off = (tid >> 6) * 1024; off < bytes; off += 8 * 1024) {
+    const uint8_t* src = g + off + (tid & 63) * 16;
+    uint8_t* dst = lds_buf + off;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  }
+}
+
+template <int KSL>
+__device__ __forceinline__ void rowtile_pair256(const uint8_t* buf, const half8 (&bf)[16], half8& o0, half8& o1, half8& o2,
+                                                half8& o3, int lane) {
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    floatx16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+    for (int kk = 0; kk < KSL; ++kk) {
+      const half8 af = *reinterpret_cast<const half8*>(buf + ((r * KSL + kk) * 64 + lane) * 16);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf[kk], acc, 0, 0, 0);
+    }
+    if (r == 0) { o0 = relu_pack(acc, 0); o1 = relu_pack(acc, 1); }
+    else { o2 = relu_pack(acc, 0); o3 = relu_pack(acc, 1); }
+  }
+}
+
+template <int PD, int PF, int DD, int DF, int IN_MODE, int OUT_MODE>
+__global__ __launch_bounds__(kThreads256, 2) void mlp_fwd256_kernel(FwdArgs a) {
+  using ES = EncSpec<PD, PF, DD, DF>;
+  constexpr int KS = 16, KS0 = ES::k0 / 16;
+  static_assert(KS0 <= KS, "first-layer K must not exceed the width");
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 3 slots
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
+  long n_tiles, total_seg = 0;
+  if (IN_MODE == 1) {
+    total_seg = *a.total_segments;
+    if (total_seg > a.max_segments) total_seg = a.max_segments;
+    n_tiles = (total_seg + 7) / 8;
+  } else {
+    n_tiles = (a.n + 255) / 256;
+  }
+  if ((long)blockIdx.x >= n_tiles) return;
+  const long my_tiles = (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
+  const int n_chunks = 4 + 4 * (a.n_hidden - 1) + 1;
+  const long g_end = my_tiles * n_chunks;
+  long g = 0;  // chunks consumed so far by this block
+  auto issue = [&](long gi) {
+    const int i = (int)(gi % n_chunks);
+    long off;
+    int size;
+    if (i < 4) { size = 2 * KS0 * 1024; off = (long)i * size; }
+    else if (i < n_chunks - 1) { size = 2 * KS * 1024; off = 4L * 2 * KS0 * 1024 + (long)(i - 4) * size; }
+    else { size = KS * 1024; off = 4L * 2 * KS0 * 1024 + (long)(n_chunks - 5) * 2 * KS * 1024; }
+    stage512(a.packed + off, smem + (gi % 3) * kSlot256, size, tid);
+  };
+  issue(0);
+  if (g_end > 1) issue(1);
+  auto next_chunk = [&]() -> const uint8_t* {
+    __syncthreads();  // chunk g landed (vmcnt drained before the barrier); everyone is done with chunk g-1
+    if (g + 2 < g_end) issue(g + 2);
+    const uint8_t* p = smem + (g % 3) * kSlot256;
+    ++g;
+    return p;
+  };
+
+  float xin[5];
+  bool valid_n;
+  long samp_n;
+  auto load_inputs = [&](long tile) {
+    if (IN_MODE == 1) {
+      const long seg = tile * 8 + wave;
+      valid_n = seg < total_seg;
+      samp_n = seg * 32 + col;
+      const long sg = valid_n ? seg : 0;
+      const float t = (float)col * (1.0f / 32);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float og = a.start[3 * sg + c];
+        xin[c] = fmaf(t, a.end[3 * sg + c] - og, og);
+      }
+      xin[3] = a.seg_view[2 * sg];
+      xin[4] = a.seg_view[2 * sg + 1];
+    } else {
+      samp_n = tile * 256 + wave * 32 + col;
+      valid_n = samp_n < a.n;
+      const long sidx = valid_n ? samp_n : 0;
+#pragma unroll
+      for (int c = 0; c < 5; ++c) xin[c] = a.input[5 * sidx + c];
+    }
+  };
+  load_inputs(blockIdx.x);
+
+  for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    half8 bf[KS], bg[KS];
+    const bool valid = valid_n;
+    const long samp = samp_n;
+    const float phase = 0.25f * (float)h;
+#pragma unroll
+    for (int kk = 0; kk < KS0; ++kk) {
+      half8 v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = encode_slot<ES, PD, PF, DD, DF>(8 * kk + j, xin, phase);
+      bf[kk] = v;
+    }
+    if (IN_MODE == 1 && a.t_vals && valid && h == 0) a.t_vals[samp] = (float)(col + 1) * (1.0f / 32);
+    if (tile + gridDim.x < n_tiles) load_inputs(tile + gridDim.x);
+
+    // layer 0: K = 16*KS0
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const uint8_t* w = next_chunk();
+      rowtile_pair256<KS0>(w, bf, bg[4 * p], bg[4 * p + 1], bg[4 * p + 2], bg[4 * p + 3], lane);
+    }
+    // hidden layers 1..n_hidden-1, activations ping-pong bg -> bf -> bg
+    int l = 1;
+    for (; l + 1 < a.n_hidden; l += 2) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const uint8_t* w = next_chunk();
+        rowtile_pair256<KS>(w, bg, bf[4 * p], bf[4 * p + 1], bf[4 * p + 2], bf[4 * p + 3], lane);
+      }
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const uint8_t* w = next_chunk();
+        rowtile_pair256<KS>(w, bf, bg[4 * p], bg[4 * p + 1], bg[4 * p + 2], bg[4 * p + 3], lane);
+      }
+    }
+    if (l < a.n_hidden) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const uint8_t* w = next_chunk();
+        rowtile_pair256<KS>(w, bg, bf[4 * p], bf[4 * p + 1], bf[4 * p + 2], bf[4 * p + 3], lane);
+      }
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) bg[kk] = bf[kk];
+    }
+    // output layer
+    const uint8_t* w = next_chunk();
+    floatx16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      const half8 af = *reinterpret_cast<const half8*>(w + (kk * 64 + lane) * 16);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bg[kk], acc, 0, 0, 0);
+    }
+    float y[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) y[e] = a.out_act == RTXN_ACT_SIGMOID ? 1.0f / (1.0f + __expf(-acc[e])) : acc[e];
+    if (valid) {
+      if (OUT_MODE == 0) {
+        half4v lo, hi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { lo[e] = (_Float16)y[e]; hi[e] = (_Float16)y[4 + e]; }
+        _Float16* o = a.out_half + samp * 16;
+        *reinterpret_cast<half4v*>(o + 4 * h) = lo;
+        *reinterpret_cast<half4v*>(o + 8 + 4 * h) = hi;
+      } else if (h == 0) {
+        a.radiance[samp] = make_float4((float)(_Float16)y[0], (float)(_Float16)y[1], (float)(_Float16)y[2],
+                                       (float)(_Float16)y[3]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
 typedef void (*fwd_fn)(FwdArgs);
@@ -333,6 +511,8 @@ struct Variant {
   fwd_fn fn[2][2];  // [IN_MODE][OUT_MODE]
   int k0;
   size_t lds;
+  int threads;        // block size
+  int blocks_per_cu;  // persistent grid = CUs x this
 };
 
 template <int W, int PD, int PF, int DD, int DF>
@@ -348,6 +528,24 @@ Variant make_variant() {
   v.fn[1][1] = mlp_fwd_kernel<W, PD, PF, DD, DF, 1, 1>;
   v.k0 = ES::k0;
   v.lds = 2 * (size_t)(L0 > HID ? L0 : HID);
+  v.threads = kThreads;
+  v.blocks_per_cu = 2;
+  return v;
+}
+
+template <int PD, int PF, int DD, int DF>
+Variant make_variant256() {
+  using ES = EncSpec<PD, PF, DD, DF>;
+  Variant v;
+  v.W = 256; v.PD = PD; v.PF = PF; v.DD = DD; v.DF = DF;
+  v.fn[0][0] = mlp_fwd256_kernel<PD, PF, DD, DF, 0, 0>;
+  v.fn[0][1] = mlp_fwd256_kernel<PD, PF, DD, DF, 0, 1>;
+  v.fn[1][0] = mlp_fwd256_kernel<PD, PF, DD, DF, 1, 0>;
+  v.fn[1][1] = mlp_fwd256_kernel<PD, PF, DD, DF, 1, 1>;
+  v.k0 = ES::k0;
+  v.lds = 3 * (size_t)kSlot256;
+  v.threads = kThreads256;
+  v.blocks_per_cu = 1;
   return v;
 }
 
@@ -357,6 +555,7 @@ const std::vector<Variant>& variants() {
       make_variant<64, 3, 10, 2, 12>(),   // BASELINE config 1 (2x64)
       make_variant<128, 3, 10, 2, 4>(),
       make_variant<64, 3, 10, 2, 4>(),
+      make_variant256<3, 10, 2, 12>(),    // BASELINE config 5 (8x256)
   };
   return v;
 }
@@ -398,7 +597,7 @@ int launch_fwd(const rtxn_mlp* m, FwdArgs& a, int in_mode, int out_mode, long n_
     RTXN_HIP(hipGetDeviceProperties(&prop, dev));
     n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
-  long grid = n_tiles < (long)n_cu * 2 ? n_tiles : (long)n_cu * 2;  // persistent: 2 blocks per CU
+  long grid = n_tiles < (long)n_cu * v.blocks_per_cu ? n_tiles : (long)n_cu * v.blocks_per_cu;  // persistent grid
   if (grid < 1) grid = 1;
   fwd_fn fn = v.fn[in_mode][out_mode];
   static bool attr_set[16][2][2] = {};
@@ -407,7 +606,7 @@ int launch_fwd(const rtxn_mlp* m, FwdArgs& a, int in_mode, int out_mode, long n_
                                  (int)v.lds));
     attr_set[m->variant][in_mode][out_mode] = true;
   }
-  hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(kThreads), v.lds, s, a);
+  hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3((unsigned)v.threads), v.lds, s, a);
   RTXN_LAUNCH_CHECK("mlp_fwd_kernel");
   return RTXN_OK;
 }
@@ -432,7 +631,7 @@ extern "C" int rtxn_mlp_create(const rtxn_mlp_config* cfg, rtxn_mlp** out) {
           vs[i].DD == cfg->n_dir_dims && vs[i].DF == cfg->n_dir_freqs)
         variant = (int)i;
     if (variant < 0) {
-      rtxn::set_error("rtxn_mlp_create: no kernel for n_neurons=%d enc=(%d x %d, %d x %d); built: 64/128 wide, (3x10, 2x12|2x4)",
+      rtxn::set_error("rtxn_mlp_create: no kernel for n_neurons=%d enc=(%d x %d, %d x %d); built: 64/128 wide (3x10, 2x12|2x4), 256 wide (3x10, 2x12)",
                       cfg->n_neurons, cfg->n_pos_dims, cfg->n_pos_freqs, cfg->n_dir_dims, cfg->n_dir_freqs);
       return RTXN_ERR_UNSUPPORTED;
     }

@@ -302,7 +302,8 @@ def _mlp_case(oracle, W, nh, n, seed, dir_freqs=12):
 
 
 @pytest.mark.parametrize("W,nh,n,dir_freqs", [(128, 8, 1000, 12), (64, 2, 777, 12), (128, 1, 256, 12), (64, 4, 3, 12),
-                                              (128, 3, 515, 4), (64, 3, 300, 4)])
+                                              (128, 3, 515, 4), (64, 3, 300, 4), (256, 8, 900, 12), (256, 1, 33, 12),
+                                              (256, 2, 256, 12), (256, 3, 2500, 12)])
 def test_mlp_forward_half_output(gpu, oracle, W, nh, n, dir_freqs):
     torch = gpu
     from rtx_nerf_amd import api
@@ -378,15 +379,16 @@ def test_mlp_identity_weights_expose_layouts(gpu, oracle):
     assert len(set(src.tolist())) > 8 and want.std() > 0.1
 
 
-def test_mlp_forward_segments_equals_sampler_plus_forward(gpu, oracle):
+@pytest.mark.parametrize("W", [128, 256])
+def test_mlp_forward_segments_equals_sampler_plus_forward(gpu, oracle, W):
     torch = gpu
     from rtx_nerf_amd import api
     rng = np.random.default_rng(4)
     B = 700
     nh, idx, P, sp, ep, vd = _ragged_segments(rng, B, 9)
     seg_ray = np.repeat(np.arange(B, dtype=np.int32), nh)
-    cfg, params, _ = _mlp_case(oracle, 128, 8, 1, seed=9)
-    net = api.Network()
+    cfg, params, _ = _mlp_case(oracle, W, 8, 1, seed=9)
+    net = api.Network(n_neurons=W)
     net.set_params(_dev(torch, params))
     cap = P + 13
     rad = torch.full((cap * 32, 4), -3.0, device="cuda")
@@ -409,3 +411,49 @@ def test_mlp_forward_segments_equals_sampler_plus_forward(gpu, oracle):
     assert np.all(got[P * 32:] == -3.0) and np.all(tv.cpu().numpy()[P * 32:] == -3.0)   # nothing beyond *total
     want = oracle.mlp_forward(cfg, params, samples).astype(np.float32)[:, :4]
     np.testing.assert_allclose(got[:P * 32], want, rtol=0, atol=1e-2)
+
+
+# ------------------------------------------------------------------ end-to-end render (BASELINE configs)
+@pytest.mark.parametrize("variant,trace_mode", [("dense", 0), ("sphere", 0), ("sphere", 1)])
+def test_config1_render_matches_host_ray_march(gpu, oracle, variant, trace_mode):
+    """configs[0] (32^3 grid, 2x64 MLP, 1024 rays) rendered by the HIP pipeline == the host-CPU ray march."""
+    torch = gpu
+    from rtx_nerf_amd import api, render
+    R, W, H = 32, 32, 32
+    cfg = oracle.mlp_cfg(n_neurons=64, n_hidden_layers=2)
+    params = scenes.xavier_params_fp16(64, 2, oracle.mlp_enc_padded(cfg), seed=1337)
+    words = None if variant == "dense" else scenes.pack_occupancy(scenes.sphere_density(R, 0.5))
+    occ = None if words is None else _occ_dev(torch, words)
+    net = api.Network(n_neurons=64, n_hidden_layers=2)
+    net.set_params(_dev(torch, params))
+    la = scenes.pose_spherical(30.0, -30.0, origin_scale=10.0)
+    f = scenes.lego_focal_length(True)
+    pipe = render.RenderPipeline(net, R, W, H, f, occupancy=occ, max_segments=W * H * 100, trace_mode=trace_mode)
+    pipe.set_pose(la)
+    pix = pipe.render().cpu().numpy()
+    assert not pipe.overflowed()
+    want, nsamp = oracle.render(la, f, 1.0, W, H, R, words, trace_mode, cfg, params, np.arange(W * H))
+    assert nsamp == int(pipe.total.item()) * 32
+    np.testing.assert_allclose(pix, want, rtol=0, atol=2e-3)
+    mse = float(((pix - want) ** 2).mean())
+    assert 10 * np.log10(1.0 / max(mse, 1e-20)) > 60.0
+
+
+def test_render_capacity_overflow_is_safe(gpu, oracle):
+    """A segment buffer that is too small truncates rays on the device and reports it; nothing is written out of bounds."""
+    torch = gpu
+    from rtx_nerf_amd import api, render
+    R, W, H = 32, 32, 32
+    net = api.Network(n_neurons=64, n_hidden_layers=2)
+    net.set_params(_dev(torch, scenes.xavier_params_fp16(64, 2, 112, seed=1)))
+    la = scenes.pose_spherical(30.0, -30.0, origin_scale=10.0)
+    pipe = render.RenderPipeline(net, R, W, H, scenes.lego_focal_length(True), max_segments=2000)
+    guard = pipe.radiance.numel()
+    pipe.set_pose(la)
+    pix = pipe.render().cpu().numpy()
+    assert pipe.overflowed() and np.isfinite(pix).all()
+    assert pipe.radiance.numel() == guard
+    need = pipe.calibrate([la])
+    assert pipe.max_segments >= need
+    pix2 = pipe.render().cpu().numpy()
+    assert not pipe.overflowed() and np.abs(pix2).sum() > np.abs(pix).sum()

@@ -363,3 +363,26 @@ def test_render_equals_staged_pipeline(oracle):
         pix2, nsamp = oracle.render(la, f, 1.0, W, H, R, occ, mode, cfg, params, np.arange(W * H))
         assert nsamp == pk["total"] * 32 and nsamp > 0
         np.testing.assert_array_equal(pix, pix2)
+
+
+@pytest.mark.parametrize("variant", ["dense", "sphere"])
+def test_config1_host_ray_march(oracle, variant):
+    """BASELINE.json configs[0]: 32^3 grid + 2x64 MLP, 1024 rays (32x32 launch), host-CPU ray march,
+    REGULAR sampling, K=32 -- the plumbing case, no GPU."""
+    R, W, H = 32, 32, 32
+    cfg = oracle.mlp_cfg(n_neurons=64, n_hidden_layers=2)
+    params = scenes.xavier_params_fp16(64, 2, oracle.mlp_enc_padded(cfg), seed=1337)
+    occ = None if variant == "dense" else scenes.pack_occupancy(scenes.sphere_density(R, 0.5))
+    la = scenes.pose_spherical(30.0, -30.0, origin_scale=10.0)
+    f = scenes.lego_focal_length(True)
+    pix, nsamp = oracle.render(la, f, 1.0, W, H, R, occ, 0, cfg, params, np.arange(W * H))
+    assert pix.shape == (1024, 3) and np.isfinite(pix).all()
+    pk = oracle.trace_packed(look_at=la, focal=f, aspect=1.0, W=W, H=H, R=R, occ=occ, mode=0)
+    assert nsamp == pk["total"] * 32
+    hit = pk["num_hits"] > 0
+    assert hit.sum() > 100 and np.all(pix[~hit] == 0) and pix[hit].min() > 0
+    # every weight is positive and sum_i w_i <= sum_i (1 - exp(-delta sigma)) <= n * (1 - exp(-31/32)): colours stay bounded
+    assert pix.max() < 1.0
+    if variant == "sphere":
+        dense_pix, _ = oracle.render(la, f, 1.0, W, H, R, None, 0, cfg, params, np.arange(W * H))
+        assert (pk["num_hits"] <= 3 * R - 2).all() and not np.array_equal(dense_pix, pix)
