@@ -106,3 +106,35 @@ def xavier_params_fp16(n_neurons, n_hidden_layers, enc_padded, seed=1337):
         fill(n_neurons, n_neurons)
     fill(16, n_neurons)
     return np.concatenate(parts).astype(np.float16)
+
+
+def llff_standin_density(R, seed=0, n_blobs=40):
+    """bool[R,R,R] for the forward-facing config (BASELINE configs[4]): a sparse cloud of small blobs and thin
+    fronds inside a slab |z| < 0.6, ~2 % of cells occupied ("fern-like": irregular, mostly empty)."""
+    rng = np.random.default_rng(seed)
+    occ = np.zeros((R, R, R), bool)
+    ax = (np.arange(R, dtype=np.float32) + 0.5) * (2.0 / R) - 1.0
+    for _ in range(n_blobs):
+        c = rng.uniform([-0.8, -0.8, -0.55], [0.8, 0.8, 0.55])
+        rad = rng.uniform(0.03, 0.10)
+        lo = np.clip(((c - rad + 1) / 2 * R).astype(int), 0, R - 1)
+        hi = np.clip(((c + rad + 1) / 2 * R).astype(int) + 1, 1, R)
+        x, y, z = np.meshgrid(ax[lo[0]:hi[0]], ax[lo[1]:hi[1]], ax[lo[2]:hi[2]], indexing="ij")
+        occ[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]] |= ((x - c[0]) ** 2 + (y - c[1]) ** 2 + (z - c[2]) ** 2) <= rad * rad
+    for _ in range(n_blobs):                                  # fronds: thin slanted sticks
+        p0 = rng.uniform([-0.8, -0.8, -0.5], [0.8, 0.8, 0.5])
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        for t in np.linspace(0, 0.35, 4 * R // 8):
+            q = ((p0 + t * d + 1) / 2 * R).astype(int)
+            if np.all(q >= 1) and np.all(q < R - 1):
+                occ[q[0] - 1:q[0] + 1, q[1] - 1:q[1] + 1, q[2] - 1:q[2] + 1] = True
+    return occ
+
+
+def pose_forward_facing(dx=0.0, dy=0.0, dist=2.6, origin_scale=10.0):
+    """LLFF-style forward-facing camera: at (dx, dy, dist) looking down -z, +y up (row-major 4x4);
+    translation pre-multiplied by origin_scale to undo the reference's origin/10 (optixPrograms.cu:76-78)."""
+    c2w = np.eye(4, dtype=np.float32)
+    c2w[:3, 3] = np.array([dx, dy, dist], np.float32) * origin_scale
+    return c2w

@@ -457,3 +457,34 @@ def test_render_capacity_overflow_is_safe(gpu, oracle):
     assert pipe.max_segments >= need
     pix2 = pipe.render().cpu().numpy()
     assert not pipe.overflowed() and np.abs(pix2).sum() > np.abs(pix).sum()
+
+
+def test_config5_forward_facing_256_grid_8x256(gpu, oracle):
+    """BASELINE configs[4], reduced image: forward-facing frustum, 256^3 sparse grid (coarse 64^3 mip exactly
+    fills the 32-KiB LDS stage), 8x256 MLP -- HIP pipeline vs the host ray march."""
+    torch = gpu
+    from rtx_nerf_amd import api, render
+    R, W, H = 256, 64, 48
+    dense = scenes.llff_standin_density(R, seed=3)
+    assert 0.005 < dense.mean() < 0.05
+    words = scenes.pack_occupancy(dense)
+    occ = _occ_dev(torch, words)
+    cfg = oracle.mlp_cfg(n_neurons=256, n_hidden_layers=8)
+    params = scenes.xavier_params_fp16(256, 8, oracle.mlp_enc_padded(cfg), seed=5)
+    assert params.size == 491520
+    net = api.Network(n_neurons=256, n_hidden_layers=8)
+    net.set_params(_dev(torch, params))
+    la = scenes.pose_forward_facing(0.15, -0.1)
+    f = 1.6
+    pipe = render.RenderPipeline(net, R, W, H, f, occupancy=occ, max_segments=W * H * 64)
+    pipe.set_pose(la)
+    pix = pipe.render().cpu().numpy()
+    assert not pipe.overflowed()
+    want, nsamp = oracle.render(la, f, W / H, W, H, R, words, 1, cfg, params, np.arange(W * H))
+    assert nsamp == int(pipe.total.item()) * 32 and nsamp > 20000
+    np.testing.assert_allclose(pix, want, rtol=0, atol=3e-3)
+    mse = float(((pix - want) ** 2).mean())
+    assert 10 * np.log10(1.0 / max(mse, 1e-20)) > 55.0
+    # the two-level walk and the flat walk agree on this grid too (bit-exact segments)
+    tr_c = oracle.trace(look_at=la, focal=f, aspect=W / H, W=W, H=H, R=R, occ=words, mode=1, count_only=True)
+    np.testing.assert_array_equal(pipe.num_hits.cpu().numpy(), tr_c["num_hits"])
