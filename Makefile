@@ -3,7 +3,7 @@ HIPCC ?= /opt/rocm/bin/hipcc
 ARCH ?= gfx950
 CSRC := rtx_nerf_amd/csrc
 SRCS := $(wildcard $(CSRC)/*.hip)
-OBJS := $(patsubst $(CSRC)/%.hip,build/%.o,$(SRCS))
+OBJS := $(patsubst $(CSRC)/%.hip,build/%.o,$(SRCS)) build/loader.o
 HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -Iinclude -I$(CSRC) -Wall -Wno-unused-function
 
 all: rtx_nerf_amd/librtxn.so oracle examples/render_host
@@ -12,14 +12,18 @@ build/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/mlp_internal.h include/rtxn.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
+build/loader.o: $(CSRC)/loader.cpp $(CSRC)/common.h include/rtxn.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
 rtx_nerf_amd/librtxn.so: $(OBJS)
-	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJS)
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJS) -lz
 
 oracle:
 	$(MAKE) -C oracle -s
 
 # C++ host over the drop-in headers (reference-style call sites); links librtxn.so by rpath
-DROPIN := -Iinclude -Iinclude/rtxn_dropin -Iinclude/rtxn_dropin/sampler -Iinclude/rtxn_dropin/vol_render
+DROPIN := -Iinclude -Iinclude/rtxn_dropin -Iinclude/rtxn_dropin/sampler -Iinclude/rtxn_dropin/vol_render -Iinclude/rtxn_dropin/loader
 examples/render_host: examples/render_host.cpp rtx_nerf_amd/librtxn.so $(wildcard include/rtxn_dropin/*/*.h include/rtxn_dropin/rtx/include/*.h)
 	$(HIPCC) -O2 -std=c++17 --offload-arch=$(ARCH) $(DROPIN) $< -o $@ -Lrtx_nerf_amd -lrtxn -Wl,-rpath,'$$ORIGIN/../rtx_nerf_amd'
 

@@ -42,7 +42,8 @@ enum rtxn_status {
   RTXN_OK = 0,
   RTXN_ERR_INVALID = 1,     /* bad argument (null pointer, negative size, unsupported width) */
   RTXN_ERR_HIP = 2,         /* a HIP runtime call or kernel launch failed */
-  RTXN_ERR_UNSUPPORTED = 3  /* valid request this build does not implement */
+  RTXN_ERR_UNSUPPORTED = 3, /* valid request this build does not implement */
+  RTXN_ERR_IO = 4           /* loader: missing/invalid file */
 };
 
 int rtxn_version(void);
@@ -270,6 +271,25 @@ int rtxn_l2_loss(const float* pred, const float* target, long n, float loss_scal
 /* optimizer->step (tcnn "Adam", main.cu:40-46,787): fp32 master weights + fp16 copy, fp32 gradients. */
 int rtxn_adam_step(long n, float* master, void* params_fp16, const float* grads, float* m, float* v, int step,
                    float lr, float beta1, float beta2, float eps, float loss_scale, rtxn_stream_t stream);
+
+/* ---- dataset loader (host only) ------------------------------------------------------- */
+/* Replaces load_images_json (loader/data_loader.cpp:34-94; jsoncpp + stb_image's stbi_loadf).
+ * Reads <basename>/transforms_<split>.json and its PNG frames.  images: float[n][H][W][3],
+ * poses: float[n][16] row-major 4x4 (both malloc'ed, host).  flags = 0 reproduces the reference
+ * (alpha dropped without compositing, gamma-2.2 linearisation, focal = .5*800/tan(.5*camera_angle_x),
+ * SURVEY Q11/Q12); bit 0: composite alpha over white; bit 1: keep v/255 (no gamma). */
+typedef struct rtxn_image_dataset {
+  int n_images;
+  unsigned image_width, image_height, image_channels;
+  float focal;
+  float camera_angle_x;
+  float* images;
+  float* poses;
+} rtxn_image_dataset;
+int rtxn_load_images_json(const char* basename, const char* split, int flags, rtxn_image_dataset* out);
+void rtxn_free_image_dataset(rtxn_image_dataset* d);
+/* stb_image_write's role (included, never called, main.cu:19-21): 8-bit RGB PNG of a rendered frame. */
+int rtxn_write_png_rgb8(const char* path, const unsigned char* rgb, int width, int height);
 
 #ifdef __cplusplus
 }

@@ -61,6 +61,13 @@ class HashGridConfig(C.Structure):
                 ("base_resolution", C.c_int), ("per_level_scale", C.c_float)]
 
 
+class ImageDataset(C.Structure):
+    """struct rtxn_image_dataset (include/rtxn.h)."""
+    _fields_ = [("n_images", C.c_int), ("image_width", C.c_uint), ("image_height", C.c_uint), ("image_channels", C.c_uint),
+                ("focal", C.c_float), ("camera_angle_x", C.c_float), ("images", C.POINTER(C.c_float)),
+                ("poses", C.POINTER(C.c_float))]
+
+
 class MlpConfig(C.Structure):
     """struct rtxn_mlp_config (include/rtxn.h)."""
     _fields_ = [(n, C.c_int) for n in (
@@ -103,6 +110,9 @@ SYMBOLS = {
     "rtxn_mlp_train_backward": (_I, [_P, _P, _P, _P, _L, _P, _P, _P, _P]),
     "rtxn_l2_loss": (_I, [_P, _P, _L, _F, _P, _P, _P, _P]),
     "rtxn_adam_step": (_I, [_L, _P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _P]),
+    "rtxn_load_images_json": (_I, [C.c_char_p, C.c_char_p, _I, C.POINTER(ImageDataset)]),
+    "rtxn_free_image_dataset": (None, [C.POINTER(ImageDataset)]),
+    "rtxn_write_png_rgb8": (_I, [C.c_char_p, _P, _I, _I]),
 }
 
 _lib = None

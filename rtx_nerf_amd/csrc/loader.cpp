@@ -1,0 +1,405 @@
+// Dataset loader: NeRF-synthetic transforms_<split>.json + PNG frames -> linear float RGB
+// images and row-major 4x4 poses.  Replaces loader/data_loader.cpp of the reference
+// (load_images_json :34-94, load_synthetic_data :96-107, load_data :109-149) and the two
+// third-party pieces it leans on: jsoncpp 1.9.3 (only root["camera_angle_x"],
+// frames[].file_path, frames[].transform_matrix are read, :47-71) and stb_image's
+// stbi_loadf(path, &w, &h, &n, 3) (:63).  Both are re-implemented here from their published
+// behaviour: a small recursive-descent JSON reader, and a PNG decoder (zlib inflate + the
+// five PNG filters, non-interlaced, 8/16-bit, gray/gray-alpha/RGB/RGBA/palette) followed by
+// stb's conversions: channels reduced to 3 by DROPPING alpha (no compositing, quirk Q11),
+// then ldr->hdr  out = (float)pow(v/255.0f, 2.2f)  (stb_image.h v2.28 stbi__ldr_to_hdr).
+// Host-only code; no GPU involvement.
+#include <zlib.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------- JSON
+struct JVal {
+  enum Kind { Null, Bool, Num, Str, Arr, Obj } kind = Null;
+  double num = 0;
+  bool b = false;
+  std::string str;
+  std::vector<JVal> arr;
+  std::vector<std::pair<std::string, JVal>> obj;
+  const JVal* get(const char* key) const {
+    for (const auto& kv : obj)
+      if (kv.first == key) return &kv.second;
+    return nullptr;
+  }
+};
+
+struct JParser {
+  const char* p;
+  const char* end;
+  std::string err;
+  void ws() { while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p; }
+  bool fail(const char* m) { if (err.empty()) err = m; return false; }
+  bool parse_string(std::string& out) {
+    if (p >= end || *p != '"') return fail("expected string");
+    ++p;
+    while (p < end && *p != '"') {
+      if (*p == '\\') {
+        ++p;
+        if (p >= end) return fail("bad escape");
+        switch (*p) {
+          case 'n': out += '\n'; break;
+          case 't': out += '\t'; break;
+          case 'r': out += '\r'; break;
+          case 'b': out += '\b'; break;
+          case 'f': out += '\f'; break;
+          case 'u': {
+            if (end - p < 5) return fail("bad \\u escape");
+            unsigned cp = (unsigned)strtoul(std::string(p + 1, p + 5).c_str(), nullptr, 16);
+            if (cp < 0x80) out += (char)cp;
+            else if (cp < 0x800) { out += (char)(0xC0 | (cp >> 6)); out += (char)(0x80 | (cp & 0x3F)); }
+            else { out += (char)(0xE0 | (cp >> 12)); out += (char)(0x80 | ((cp >> 6) & 0x3F)); out += (char)(0x80 | (cp & 0x3F)); }
+            p += 4;
+            break;
+          }
+          default: out += *p;
+        }
+        ++p;
+      } else {
+        out += *p++;
+      }
+    }
+    if (p >= end) return fail("unterminated string");
+    ++p;
+    return true;
+  }
+  bool parse(JVal& v) {
+    ws();
+    if (p >= end) return fail("unexpected end");
+    if (*p == '{') {
+      v.kind = JVal::Obj;
+      ++p;
+      ws();
+      if (p < end && *p == '}') { ++p; return true; }
+      for (;;) {
+        ws();
+        std::string k;
+        if (!parse_string(k)) return false;
+        ws();
+        if (p >= end || *p != ':') return fail("expected ':'");
+        ++p;
+        JVal child;
+        if (!parse(child)) return false;
+        v.obj.emplace_back(std::move(k), std::move(child));
+        ws();
+        if (p < end && *p == ',') { ++p; continue; }
+        if (p < end && *p == '}') { ++p; return true; }
+        return fail("expected ',' or '}'");
+      }
+    }
+    if (*p == '[') {
+      v.kind = JVal::Arr;
+      ++p;
+      ws();
+      if (p < end && *p == ']') { ++p; return true; }
+      for (;;) {
+        JVal child;
+        if (!parse(child)) return false;
+        v.arr.push_back(std::move(child));
+        ws();
+        if (p < end && *p == ',') { ++p; continue; }
+        if (p < end && *p == ']') { ++p; return true; }
+        return fail("expected ',' or ']'");
+      }
+    }
+    if (*p == '"') { v.kind = JVal::Str; return parse_string(v.str); }
+    if (!strncmp(p, "true", 4)) { v.kind = JVal::Bool; v.b = true; p += 4; return true; }
+    if (!strncmp(p, "false", 5)) { v.kind = JVal::Bool; v.b = false; p += 5; return true; }
+    if (!strncmp(p, "null", 4)) { v.kind = JVal::Null; p += 4; return true; }
+    char* q = nullptr;
+    v.num = strtod(p, &q);
+    if (q == p) return fail("bad token");
+    v.kind = JVal::Num;
+    p = q;
+    return true;
+  }
+};
+
+bool read_file(const std::string& path, std::vector<unsigned char>& out) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  fseek(f, 0, SEEK_END);
+  long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  out.resize(n > 0 ? (size_t)n : 0);
+  size_t got = n > 0 ? fread(out.data(), 1, (size_t)n, f) : 0;
+  fclose(f);
+  return got == out.size();
+}
+
+// ------------------------------------------------------------------------- PNG
+inline uint32_t be32(const unsigned char* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
+inline int paeth(int a, int b, int c) {
+  int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+  if (pa <= pb && pa <= pc) return a;
+  return pb <= pc ? b : c;
+}
+
+// Decodes to 8 bits per channel, `channels` in {1,2,3,4} (palette expanded to RGB or RGBA).
+bool decode_png(const std::vector<unsigned char>& file, int& width, int& height, int& channels,
+                std::vector<unsigned char>& pixels, std::string& err) {
+  static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+  if (file.size() < 8 || memcmp(file.data(), sig, 8)) { err = "not a PNG"; return false; }
+  size_t pos = 8;
+  int depth = 0, ctype = -1, interlace = 0;
+  std::vector<unsigned char> idat, plte, trns;
+  bool have_ihdr = false, done = false;
+  while (!done && pos + 12 <= file.size()) {
+    uint32_t len = be32(&file[pos]);
+    const unsigned char* type = &file[pos + 4];
+    if (pos + 12 + (size_t)len > file.size()) { err = "truncated chunk"; return false; }
+    const unsigned char* data = &file[pos + 8];
+    if (!memcmp(type, "IHDR", 4)) {
+      if (len != 13) { err = "bad IHDR"; return false; }
+      width = (int)be32(data); height = (int)be32(data + 4);
+      depth = data[8]; ctype = data[9]; interlace = data[12];
+      have_ihdr = true;
+    } else if (!memcmp(type, "PLTE", 4)) {
+      plte.assign(data, data + len);
+    } else if (!memcmp(type, "tRNS", 4)) {
+      trns.assign(data, data + len);
+    } else if (!memcmp(type, "IDAT", 4)) {
+      idat.insert(idat.end(), data, data + len);
+    } else if (!memcmp(type, "IEND", 4)) {
+      done = true;
+    }
+    pos += 12 + (size_t)len;
+  }
+  if (!have_ihdr || width <= 0 || height <= 0) { err = "missing IHDR"; return false; }
+  if (interlace) { err = "interlaced PNG not supported"; return false; }
+  int src_ch;
+  switch (ctype) {
+    case 0: src_ch = 1; break;
+    case 2: src_ch = 3; break;
+    case 3: src_ch = 1; break;
+    case 4: src_ch = 2; break;
+    case 6: src_ch = 4; break;
+    default: err = "bad colour type"; return false;
+  }
+  if (!(depth == 8 || depth == 16 || ((ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4)))) {
+    err = "unsupported bit depth";
+    return false;
+  }
+  const size_t bpp_bits = (size_t)src_ch * depth;
+  const size_t stride = ((size_t)width * bpp_bits + 7) / 8;
+  const size_t fbpp = bpp_bits >= 8 ? bpp_bits / 8 : 1;  // filter byte distance
+  std::vector<unsigned char> raw((stride + 1) * (size_t)height);
+  uLongf raw_len = (uLongf)raw.size();
+  int zr = uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size());
+  if (zr != Z_OK || raw_len != raw.size()) { err = "inflate failed"; return false; }
+  std::vector<unsigned char> img(stride * (size_t)height);
+  for (int y = 0; y < height; ++y) {
+    const unsigned char* in = &raw[(stride + 1) * (size_t)y];
+    const int ft = in[0];
+    ++in;
+    unsigned char* out = &img[stride * (size_t)y];
+    const unsigned char* up = y ? out - stride : nullptr;
+    for (size_t x = 0; x < stride; ++x) {
+      const int a = x >= fbpp ? out[x - fbpp] : 0, b = up ? up[x] : 0, c = (up && x >= fbpp) ? up[x - fbpp] : 0;
+      int v = in[x];
+      switch (ft) {
+        case 0: break;
+        case 1: v += a; break;
+        case 2: v += b; break;
+        case 3: v += (a + b) >> 1; break;
+        case 4: v += paeth(a, b, c); break;
+        default: err = "bad filter"; return false;
+      }
+      out[x] = (unsigned char)v;
+    }
+  }
+  // to 8-bit samples
+  const size_t npx = (size_t)width * height;
+  std::vector<unsigned char> s8(npx * src_ch);
+  if (depth == 8) {
+    for (int y = 0; y < height; ++y) memcpy(&s8[(size_t)y * width * src_ch], &img[stride * (size_t)y], (size_t)width * src_ch);
+  } else if (depth == 16) {
+    for (int y = 0; y < height; ++y)
+      for (size_t i = 0; i < (size_t)width * src_ch; ++i) s8[(size_t)y * width * src_ch + i] = img[stride * (size_t)y + 2 * i];  // stb: high byte
+  } else {
+    const int maxv = (1 << depth) - 1;
+    for (int y = 0; y < height; ++y)
+      for (int x = 0; x < width; ++x) {
+        const size_t bit = (size_t)x * depth;
+        int v = (img[stride * (size_t)y + bit / 8] >> (8 - depth - (bit % 8))) & maxv;
+        s8[(size_t)y * width + x] = (unsigned char)(ctype == 3 ? v : v * 255 / maxv);
+      }
+  }
+  if (ctype == 3) {
+    channels = trns.empty() ? 3 : 4;
+    pixels.resize(npx * channels);
+    for (size_t i = 0; i < npx; ++i) {
+      const size_t idx = s8[i];
+      for (int k = 0; k < 3; ++k) pixels[i * channels + k] = idx * 3 + k < plte.size() ? plte[idx * 3 + k] : 0;
+      if (channels == 4) pixels[i * 4 + 3] = idx < trns.size() ? trns[idx] : 255;
+    }
+  } else {
+    channels = src_ch;
+    pixels.swap(s8);
+  }
+  return true;
+}
+
+// stbi_loadf(..., desired_channels = 3): convert to 3 channels (alpha dropped, gray replicated), then
+// ldr -> hdr with gamma 2.2 (flags bit 1 set: keep v/255; bit 0 set: composite alpha over white first).
+void to_float_rgb(const std::vector<unsigned char>& px, int channels, size_t npx, int flags, float* out) {
+  for (size_t i = 0; i < npx; ++i) {
+    float rgb[3];
+    const unsigned char* p = &px[i * channels];
+    if (channels >= 3) { rgb[0] = p[0]; rgb[1] = p[1]; rgb[2] = p[2]; }
+    else { rgb[0] = rgb[1] = rgb[2] = p[0]; }
+    const bool has_alpha = channels == 2 || channels == 4;
+    const float alpha = has_alpha ? p[channels - 1] / 255.0f : 1.0f;
+    for (int k = 0; k < 3; ++k) {
+      float v = rgb[k] / 255.0f;
+      if (!(flags & 2)) v = (float)(pow(v, 2.2f) * 1.0f);
+      if ((flags & 1) && has_alpha) v = v * alpha + (1.0f - alpha);
+      out[i * 3 + k] = v;
+    }
+  }
+}
+
+}  // namespace
+
+// ============================================================================ C ABI
+extern "C" int rtxn_load_images_json(const char* basename, const char* split, int flags, rtxn_image_dataset* out) {
+  RTXN_REQUIRE(basename && split && out, "rtxn_load_images_json: NULL argument");
+  memset(out, 0, sizeof(*out));
+  const std::string base(basename);
+  const std::string json_path = base + "/transforms_" + split + ".json";
+  std::vector<unsigned char> text;
+  if (!read_file(json_path, text)) {
+    rtxn::set_error("Failed to open transform JSON file: %s", json_path.c_str());
+    return RTXN_ERR_IO;
+  }
+  JVal root;
+  JParser jp{reinterpret_cast<const char*>(text.data()), reinterpret_cast<const char*>(text.data()) + text.size(), {}};
+  if (!jp.parse(root) || root.kind != JVal::Obj) {
+    rtxn::set_error("%s: JSON parse error: %s", json_path.c_str(), jp.err.c_str());
+    return RTXN_ERR_IO;
+  }
+  const JVal* cam = root.get("camera_angle_x");
+  const JVal* frames = root.get("frames");
+  if (!cam || cam->kind != JVal::Num || !frames || frames->kind != JVal::Arr) {
+    rtxn::set_error("%s: missing camera_angle_x / frames", json_path.c_str());
+    return RTXN_ERR_IO;
+  }
+  const float camera_angle_x = (float)cam->num;
+  const size_t n = frames->arr.size();
+  int W = 0, H = 0;
+  std::vector<float> images, poses(n * 16);
+  for (size_t i = 0; i < n; ++i) {
+    const JVal& fr = frames->arr[i];
+    const JVal* fp = fr.get("file_path");
+    const JVal* tm = fr.get("transform_matrix");
+    if (!fp || fp->kind != JVal::Str || !tm || tm->kind != JVal::Arr || tm->arr.size() != 4) {
+      rtxn::set_error("%s: frame %zu lacks file_path / transform_matrix", json_path.c_str(), i);
+      return RTXN_ERR_IO;
+    }
+    for (int r = 0; r < 4; ++r) {
+      if (tm->arr[r].kind != JVal::Arr || tm->arr[r].arr.size() != 4) {
+        rtxn::set_error("%s: frame %zu transform_matrix is not 4x4", json_path.c_str(), i);
+        return RTXN_ERR_IO;
+      }
+      for (int c = 0; c < 4; ++c) poses[i * 16 + r * 4 + c] = (float)tm->arr[r].arr[c].num;  // data_loader.cpp:66-71
+    }
+    const std::string png_path = base + "/" + fp->str + ".png";                               // :61
+    std::vector<unsigned char> file, px;
+    int w = 0, h = 0, ch = 0;
+    std::string err;
+    if (!read_file(png_path, file) || !decode_png(file, w, h, ch, px, err)) {
+      rtxn::set_error("Failed to load the image %s%s%s", png_path.c_str(), err.empty() ? "" : ": ", err.c_str());
+      return RTXN_ERR_IO;  // the reference returns an EMPTY dataset here (:74-78); the C++ wrapper mirrors that
+    }
+    if (i == 0) { W = w; H = h; images.resize(n * (size_t)W * H * 3); }
+    if (w != W || h != H) {
+      rtxn::set_error("%s: %dx%d differs from the first frame's %dx%d", png_path.c_str(), w, h, W, H);
+      return RTXN_ERR_IO;
+    }
+    to_float_rgb(px, ch, (size_t)W * H, flags, &images[i * (size_t)W * H * 3]);
+  }
+  out->n_images = (int)n;
+  out->image_width = (unsigned)W;
+  out->image_height = (unsigned)H;
+  out->image_channels = 3;                                                                    // desired_channels, :52
+  out->focal = (float)(.5 * 800 / std::tan(.5 * camera_angle_x));                             // :85 (800 hard-coded, Q12)
+  out->camera_angle_x = camera_angle_x;
+  out->images = (float*)malloc(images.size() * sizeof(float));
+  out->poses = (float*)malloc(poses.size() * sizeof(float));
+  if ((!out->images && !images.empty()) || (!out->poses && !poses.empty())) {
+    free(out->images); free(out->poses);
+    memset(out, 0, sizeof(*out));
+    rtxn::set_error("rtxn_load_images_json: out of memory");
+    return RTXN_ERR_IO;
+  }
+  if (!images.empty()) memcpy(out->images, images.data(), images.size() * sizeof(float));
+  if (!poses.empty()) memcpy(out->poses, poses.data(), poses.size() * sizeof(float));
+  return RTXN_OK;
+}
+
+extern "C" void rtxn_free_image_dataset(rtxn_image_dataset* d) {
+  if (!d) return;
+  free(d->images);
+  free(d->poses);
+  memset(d, 0, sizeof(*d));
+}
+
+// stb_image_write's role (included but never called by the reference, main.cu:19-21): 8-bit RGB PNG.
+extern "C" int rtxn_write_png_rgb8(const char* path, const unsigned char* rgb, int width, int height) {
+  RTXN_REQUIRE(path && rgb && width > 0 && height > 0, "rtxn_write_png_rgb8: bad argument");
+  const size_t stride = (size_t)width * 3;
+  std::vector<unsigned char> raw((stride + 1) * (size_t)height);
+  for (int y = 0; y < height; ++y) {
+    raw[(stride + 1) * (size_t)y] = 0;  // filter: none
+    memcpy(&raw[(stride + 1) * (size_t)y + 1], rgb + stride * (size_t)y, stride);
+  }
+  uLongf clen = compressBound((uLong)raw.size());
+  std::vector<unsigned char> comp(clen);
+  if (compress2(comp.data(), &clen, raw.data(), (uLong)raw.size(), 6) != Z_OK) {
+    rtxn::set_error("rtxn_write_png_rgb8: deflate failed");
+    return RTXN_ERR_IO;
+  }
+  FILE* f = fopen(path, "wb");
+  if (!f) { rtxn::set_error("rtxn_write_png_rgb8: cannot open %s", path); return RTXN_ERR_IO; }
+  auto put32 = [](unsigned char* p, uint32_t v) { p[0] = v >> 24; p[1] = v >> 16; p[2] = v >> 8; p[3] = v; };
+  auto chunk = [&](const char* type, const unsigned char* data, uint32_t len) {
+    unsigned char hdr[8];
+    put32(hdr, len);
+    memcpy(hdr + 4, type, 4);
+    fwrite(hdr, 1, 8, f);
+    if (len) fwrite(data, 1, len, f);
+    uLong crc = crc32(0L, reinterpret_cast<const Bytef*>(type), 4);
+    if (len) crc = crc32(crc, data, len);
+    unsigned char c[4];
+    put32(c, (uint32_t)crc);
+    fwrite(c, 1, 4, f);
+  };
+  static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+  fwrite(sig, 1, 8, f);
+  unsigned char ihdr[13];
+  put32(ihdr, (uint32_t)width);
+  put32(ihdr + 4, (uint32_t)height);
+  ihdr[8] = 8; ihdr[9] = 2; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;
+  chunk("IHDR", ihdr, 13);
+  chunk("IDAT", comp.data(), (uint32_t)clen);
+  chunk("IEND", nullptr, 0);
+  fclose(f);
+  return RTXN_OK;
+}

@@ -1,0 +1,124 @@
+"""Loader (loader/data_loader.h drop-in): transforms JSON + PNG frames, checked against an
+independent decode (Pillow) + stb_image's published ldr->hdr rule.  CPU only."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from rtx_nerf_amd import loader
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _make_scene(tmp, n=3, w=7, h=5, mode="RGBA", split="train", seed=0):
+    rng = np.random.default_rng(seed)
+    os.makedirs(tmp / split, exist_ok=True)
+    frames, imgs = [], []
+    for i in range(n):
+        ch = {"RGBA": 4, "RGB": 3, "L": 1, "LA": 2}[mode]
+        arr = rng.integers(0, 256, (h, w, ch), dtype=np.uint8)
+        Image.fromarray(arr.squeeze() if ch == 1 else arr, mode).save(tmp / split / f"r_{i}.png")
+        imgs.append(arr)
+        m = rng.standard_normal((4, 4)).round(6)
+        m[3] = [0, 0, 0, 1]
+        frames.append({"file_path": f"./{split}/r_{i}", "rotation": 0.0125, "transform_matrix": m.tolist()})
+    with open(tmp / f"transforms_{split}.json", "w") as f:
+        json.dump({"camera_angle_x": 0.6911112070083618, "frames": frames}, f, indent=2)
+    return imgs, frames
+
+
+def _stb_loadf(arr):
+    """stbi_loadf(..., 3): alpha dropped / gray replicated, then (float)pow(v/255.0f, 2.2f) (stb_image.h v2.28)."""
+    a = arr.astype(np.float32)
+    if a.shape[2] in (1, 2):
+        rgb = np.repeat(a[:, :, :1], 3, axis=2)
+    else:
+        rgb = a[:, :, :3]
+    return np.power((rgb / np.float32(255.0)).astype(np.float64), np.float64(np.float32(2.2))).astype(np.float32)
+
+
+@pytest.mark.parametrize("mode", ["RGBA", "RGB", "L", "LA"])
+def test_load_images_json_matches_stb_semantics(tmp_path, mode):
+    imgs, frames = _make_scene(tmp_path, mode=mode)
+    ds = loader.load_images_json(str(tmp_path), "train")
+    assert ds.images.shape == (3, 5, 7, 3) and ds.image_width == 7 and ds.image_height == 5 and ds.image_channels == 3
+    for i in range(3):
+        np.testing.assert_array_equal(ds.images[i], _stb_loadf(imgs[i]))               # Q11: alpha dropped, gamma 2.2
+        np.testing.assert_array_equal(ds.poses[i], np.array(frames[i]["transform_matrix"], np.float32).reshape(16))
+    # focal = .5 * 800 / tan(.5 * camera_angle_x), 800 hard-coded (data_loader.cpp:85)
+    assert abs(ds.focal - 0.5 * 800 / np.tan(0.5 * np.float32(0.6911112070083618))) < 1e-2
+    assert abs(ds.focal - 1111.111) < 0.01
+
+
+def test_flags_composite_and_no_gamma(tmp_path):
+    imgs, _ = _make_scene(tmp_path, n=1, mode="RGBA")
+    a = imgs[0].astype(np.float32) / 255.0
+    ds = loader.load_images_json(str(tmp_path), "train", flags=3)
+    want = a[:, :, :3] * a[:, :, 3:] + (1 - a[:, :, 3:])
+    np.testing.assert_allclose(ds.images[0], want, atol=1e-6)
+
+
+def test_palette_and_filters(tmp_path):
+    os.makedirs(tmp_path / "train")
+    rng = np.random.default_rng(1)
+    # a smooth gradient makes the encoder pick Sub/Up/Average/Paeth filters; a palette image exercises PLTE
+    g = np.add.outer(np.arange(40), np.arange(64)).astype(np.uint8)
+    rgb = np.stack([g, (g.astype(np.int32) * 2 % 256).astype(np.uint8), 255 - g], axis=2).astype(np.uint8)
+    Image.fromarray(rgb, "RGB").save(tmp_path / "train" / "r_0.png", optimize=True)
+    pal = Image.fromarray(rng.integers(0, 256, (40, 64, 3), dtype=np.uint8), "RGB").quantize(16)
+    pal.save(tmp_path / "train" / "r_1.png")
+    frames = [{"file_path": f"./train/r_{i}", "transform_matrix": np.eye(4).tolist()} for i in range(2)]
+    json.dump({"camera_angle_x": 0.5, "frames": frames}, open(tmp_path / "transforms_train.json", "w"))
+    ds = loader.load_images_json(str(tmp_path), "train", flags=2)
+    np.testing.assert_allclose(ds.images[0], rgb.astype(np.float32) / 255.0, atol=1e-7)
+    np.testing.assert_allclose(ds.images[1], np.asarray(pal.convert("RGB"), np.float32) / 255.0, atol=1e-7)
+
+
+def test_missing_png_gives_empty_dataset_and_train_only(tmp_path):
+    _make_scene(tmp_path, n=2)
+    _make_scene(tmp_path, n=2, split="val", seed=5)
+    sets = loader.load_synthetic_data(str(tmp_path))
+    assert len(sets) == 1 and sets[0].images.shape[0] == 2          # `break` after train (data_loader.cpp:103)
+    os.remove(tmp_path / "train" / "r_1.png")
+    ds = loader.load_images_json(str(tmp_path), "train")
+    assert ds.images.shape[0] == 0 and len(ds.poses) == 0            # data_loader.cpp:74-78
+    assert loader.load_data("LLFF", "LEGO") == []                    # :140-148
+    assert loader.SYNTHETIC_NAMES["MATERIALS"] == "fern/"            # :128-130
+
+
+def test_missing_json_exits_like_the_reference(tmp_path):
+    code = ("import sys; sys.path.insert(0, %r); from rtx_nerf_amd import loader; "
+            "loader.load_images_json(%r, 'train')" % (ROOT, str(tmp_path / "nope")))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode == 1 and "Failed to open transform JSON file" in r.stderr     # data_loader.cpp:36-39
+
+
+def test_write_png_roundtrip(tmp_path):
+    rng = np.random.default_rng(2)
+    img = rng.uniform(-0.1, 1.1, (9, 13, 3)).astype(np.float32)
+    loader.write_png(tmp_path / "out.png", img)
+    back = np.asarray(Image.open(tmp_path / "out.png").convert("RGB"))
+    np.testing.assert_array_equal(back, np.rint(np.clip(img, 0, 1) * 255).astype(np.uint8))
+
+
+def test_cpp_dropin_header_compiles_and_loads(tmp_path):
+    """A reference-style translation unit using loader/data_loader.h builds against the drop-in and returns the same data."""
+    imgs, frames = _make_scene(tmp_path, n=2)
+    src = tmp_path / "t.cpp"
+    src.write_text('#include "data_loader.h"\n#include <cstdio>\nint main(int argc, char** argv) {\n'
+                   '  ImageDataset d = load_images_json(argv[1], "train");\n'
+                   '  std::printf("%zu %u %u %u %.4f %.9g %.9g\\n", d.images.size(), d.image_width, d.image_height, d.image_channels,\n'
+                   '              d.focal, d.images[1][5], d.poses[1][7]);\n  return 0; }\n')
+    exe = tmp_path / "t"
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["g++", "-std=c++17", f"-I{inc}", f"-I{inc}/rtxn_dropin/loader", str(src), "-o", str(exe),
+                           f"-L{ROOT}/rtx_nerf_amd", "-lrtxn", f"-Wl,-rpath,{ROOT}/rtx_nerf_amd", "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.check_output([str(exe), str(tmp_path)], text=True).split()
+    assert out[:4] == ["2", "7", "5", "3"]
+    want = _stb_loadf(imgs[1]).reshape(-1)[5]
+    assert abs(float(out[5]) - want) < 1e-7
+    assert abs(float(out[6]) - np.float32(frames[1]["transform_matrix"][1][3])) < 1e-6

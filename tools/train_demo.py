@@ -25,11 +25,13 @@ def teacher_field(samples):
     return torch.cat([rgb, sigma[:, None]], dim=1).contiguous()
 
 
-def run(steps=300, encoding="hash", grid=32, res=64, batch=4096, n_poses=12, seed=0, verbose=True, neurons=64, layers=2):
+def run(steps=300, encoding="hash", grid=32, res=64, batch=4096, n_poses=12, seed=0, verbose=True, neurons=64, layers=2,
+        hash_levels=8, hash_log2=15, hash_base=8):
     torch.cuda.set_device(0)
     dense = scenes.sphere_density(grid, 0.72)
     occ = torch.from_numpy(scenes.pack_occupancy(dense).view(np.int32).copy()).cuda()
-    hashgrid = dict(n_levels=8, n_features=2, log2_hashmap_size=15, base_resolution=8, per_level_scale=1.5)
+    hashgrid = dict(n_levels=hash_levels, n_features=2, log2_hashmap_size=hash_log2, base_resolution=hash_base,
+                    per_level_scale=1.5)
     tr = Trainer(grid, occ, encoding=encoding, n_neurons=neurons, n_hidden_layers=layers, hashgrid=hashgrid,
                  batch_rays=max(batch, res * res), max_segments=max(batch, res * res) * 40, lr=1e-2 if encoding == "hash" else 2e-3,
                  loss_scale=128.0, density_scale=150.0, mode="nerf", seed=seed)
@@ -80,5 +82,9 @@ if __name__ == "__main__":
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--neurons", type=int, default=64)
     ap.add_argument("--layers", type=int, default=2)
+    ap.add_argument("--hash-levels", type=int, default=8)
+    ap.add_argument("--hash-log2", type=int, default=15)
+    ap.add_argument("--hash-base", type=int, default=8)
     a = ap.parse_args()
-    run(a.steps, a.encoding, a.grid, a.res, a.batch, neurons=a.neurons, layers=a.layers)
+    run(a.steps, a.encoding, a.grid, a.res, a.batch, neurons=a.neurons, layers=a.layers, hash_levels=a.hash_levels,
+        hash_log2=a.hash_log2, hash_base=a.hash_base)
