@@ -125,6 +125,12 @@ int rtxn_trace_grid(const rtxn_trace_params* p, rtxn_stream_t stream);
  * coarse: (R/4)^3 bits rounded up to whole uint32 words. */
 int rtxn_build_occupancy_mip(const uint32_t* occupancy, int grid_res, uint32_t* coarse, rtxn_stream_t stream);
 
+/* Occupancy maintenance (the reference only builds the dense grid once,
+ * main.cu:393-399): occupancy bit of cell i = density[i] > threshold, i = (x*R+y)*R+z.
+ * occupancy: ceil(R^3/32) words. */
+int rtxn_occupancy_from_density(const float* density, float threshold, int grid_res, uint32_t* occupancy,
+                                rtxn_stream_t stream);
+
 /* ---- CSR compaction -------------------------------------------------------- */
 /* Replaces thrust::reduce + thrust::exclusive_scan over num_hits
  * (main.cu:631-637).  indices[i] = sum_{j<i} num_hits[j]; *total = sum of all.

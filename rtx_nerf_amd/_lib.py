@@ -82,6 +82,7 @@ SYMBOLS = {
     "rtxn_last_error": (C.c_char_p, []),
     "rtxn_trace_grid": (_I, [C.POINTER(TraceParams), _P]),
     "rtxn_build_occupancy_mip": (_I, [_P, _I, _P, _P]),
+    "rtxn_occupancy_from_density": (_I, [_P, _F, _I, _P, _P]),
     "rtxn_scan_workspace_bytes": (C.c_size_t, [_I]),
     "rtxn_scan_hits": (_I, [_P, _P, _P, _I, _P, C.c_size_t, _P]),
     "rtxn_sample": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _P]),

@@ -87,6 +87,14 @@ def build_occupancy_mip(occupancy, grid_res):
     return coarse
 
 
+def occupancy_from_density(density, threshold, grid_res):
+    words = (grid_res ** 3 + 31) // 32
+    occ = torch.empty(words, dtype=torch.int32, device=density.device)
+    check(_lib.lib().rtxn_occupancy_from_density(_ptr(density, torch.float32, "density"), threshold, grid_res, _ptr(occ),
+                                                 _stream()), "rtxn_occupancy_from_density")
+    return occ
+
+
 # --------------------------------------------------------------------------- CSR compaction
 def scan_hits(num_hits, indices=None, total=None, workspace=None):
     """thrust::reduce + thrust::exclusive_scan (main.cu:631-637); total stays on the device."""

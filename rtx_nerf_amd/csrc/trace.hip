@@ -299,7 +299,30 @@ __global__ void mip_kernel(const uint32_t* __restrict__ occ, int R, uint32_t* __
   coarse[w] = word;
 }
 
+// density[R^3] (index (x*R+y)*R+z) -> occupancy bits: one wave ballot = two 32-bit words
+__global__ __launch_bounds__(256) void occupancy_kernel(const float* __restrict__ density, float threshold, long n,
+                                                        uint32_t* __restrict__ bits) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const bool on = i < n && density[i] > threshold;
+  const unsigned long long m = __ballot(on);
+  const int lane = threadIdx.x & 63;
+  const long word = i >> 5;
+  if ((lane & 31) == 0 && (i < n || (i & ~31L) < n)) bits[word] = (uint32_t)(m >> (lane & 32));
+}
+
 }  // namespace
+
+extern "C" int rtxn_occupancy_from_density(const float* density, float threshold, int grid_res, uint32_t* occupancy,
+                                           rtxn_stream_t stream) {
+  RTXN_REQUIRE(density && occupancy, "rtxn_occupancy_from_density: NULL buffer");
+  RTXN_REQUIRE(grid_res >= 1 && grid_res <= 1024, "rtxn_occupancy_from_density: grid_res = %d", grid_res);
+  RTXN_DEVICE_OR_FAIL();
+  const long n = (long)grid_res * grid_res * grid_res;
+  const long padded_n = (n + 31) / 32 * 32;
+  occupancy_kernel<<<(unsigned)((padded_n + 255) / 256), 256, 0, rtxn::as_stream(stream)>>>(density, threshold, n, occupancy);
+  RTXN_LAUNCH_CHECK("occupancy_kernel");
+  return RTXN_OK;
+}
 
 extern "C" int rtxn_trace_grid(const rtxn_trace_params* p, rtxn_stream_t stream) {
   RTXN_REQUIRE(p != nullptr, "rtxn_trace_grid: params is NULL");

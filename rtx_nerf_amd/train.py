@@ -19,7 +19,12 @@ forward); "nerf" is the corrected path (midpoint samples, world-spac
 steps, exact gradients) that actually converges.  All arithmetic is in librtxn.so;
 torch only owns buffers and a few trivial elementwise glue ops.
 """
+import json
+import struct
+
+import numpy as np
 import torch
+import torch.distributed as dist
 
 from . import api
 
@@ -147,15 +152,101 @@ class Trainer:
                                            self.indices, n, K, self.dout, mode=vr)
         self.dparams.zero_()
         self.net.train_backward(self.encT, self.out, self.dout, S, self.ws, self.dparams, self.dencT)
-        api.adam_step(self.master, self.params, self.dparams, self.adam_m, self.adam_v, self.step_count, lr=self.lr,
-                      loss_scale=self.loss_scale)
-        self.net.set_params(self.params)
+        # data parallel over the ray batch: every rank holds B_local rays of the global batch;
+        # gradients are SUMMED across ranks (RCCL all-reduce, issued async so the MLP reduction overlaps the
+        # hash-grid scatter) and the mean over ranks is folded into Adam's loss_scale divisor.
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        pending = []
+        if world > 1:
+            pending.append(dist.all_reduce(self.dparams, async_op=True))
         if self.encoding == "hash":
             self.dtable.zero_()
             self.hg.backward(self.samples[:S], self.dencT, self.dtable)
+            if world > 1:
+                pending.append(dist.all_reduce(self.dtable, async_op=True))
+        for w in pending:
+            w.wait()
+        api.adam_step(self.master, self.params, self.dparams, self.adam_m, self.adam_v, self.step_count, lr=self.lr,
+                      loss_scale=self.loss_scale * world)
+        self.net.set_params(self.params)
+        if self.encoding == "hash":
             api.adam_step(self.table_master, self.table, self.dtable, self.table_m, self.table_v, self.step_count,
-                          lr=self.lr * 10.0, eps=1e-15, loss_scale=self.loss_scale)
+                          lr=self.lr * 10.0, eps=1e-15, loss_scale=self.loss_scale * world)
         return self.loss
+
+    # ------------------------------------------------------------------------------------------ checkpoint
+    # Layout (little endian): b"RTXNCKPT", u32 version, u32 json_len, json header, then for every entry of
+    # header["arrays"] its raw bytes, 64-byte aligned.  The MLP block is the reference's params_buffer
+    # (main.cu:328-342): fp32 master | fp16 params (the fp16 gradient third is not persisted) plus Adam's
+    # moments; the hash grid adds its table the same way.
+    def state_arrays(self):
+        arrs = {"mlp_master": self.master, "mlp_params": self.params, "mlp_adam_m": self.adam_m, "mlp_adam_v": self.adam_v}
+        if self.encoding == "hash":
+            arrs.update(table_master=self.table_master, table_params=self.table, table_adam_m=self.table_m,
+                        table_adam_v=self.table_v)
+        return arrs
+
+    def save_checkpoint(self, path):
+        arrs = {k: v.detach().cpu().numpy() for k, v in self.state_arrays().items()}
+        cfg = self.net.cfg
+        header = {"step": self.step_count, "encoding": self.encoding, "grid_res": self.R, "mode": self.mode,
+                  "mlp": {f: getattr(cfg, f) for f, _ in cfg._fields_},
+                  "hashgrid": None if self.hg is None else {**{f: getattr(self.hg.cfg, f) for f, _ in self.hg.cfg._fields_},
+                                                            "n_dir_freqs": self.hg.n_dir_freqs},
+                  "arrays": [{"name": k, "dtype": str(a.dtype), "shape": list(a.shape)} for k, a in arrs.items()]}
+        blob = json.dumps(header).encode()
+        with open(path, "wb") as f:
+            f.write(b"RTXNCKPT" + struct.pack("<II", 1, len(blob)) + blob)
+            for a in arrs.values():
+                f.write(b"\0" * ((-f.tell()) % 64))
+                f.write(np.ascontiguousarray(a).tobytes())
+
+    def load_checkpoint(self, path):
+        with open(path, "rb") as f:
+            if f.read(8) != b"RTXNCKPT":
+                raise ValueError(f"{path}: not an RTXN checkpoint")
+            version, n = struct.unpack("<II", f.read(8))
+            header = json.loads(f.read(n))
+            if version != 1 or header["encoding"] != self.encoding:
+                raise ValueError(f"{path}: version {version} / encoding {header['encoding']} does not match this trainer")
+            dst = self.state_arrays()
+            for ent in header["arrays"]:
+                f.seek((-f.tell()) % 64, 1)
+                a = np.frombuffer(f.read(int(np.prod(ent["shape"])) * np.dtype(ent["dtype"]).itemsize), dtype=ent["dtype"])
+                t = dst[ent["name"]]
+                if list(t.shape) != ent["shape"]:
+                    raise ValueError(f"{path}: {ent['name']} has shape {ent['shape']}, model needs {list(t.shape)}")
+                t.copy_(torch.from_numpy(a.reshape(ent["shape"]).copy()))
+        self.step_count = header["step"]
+        self.net.set_params(self.params)
+        return header
+
+    # ------------------------------------------------------------------------------------------ occupancy maintenance
+    @torch.no_grad()
+    def update_occupancy(self, threshold=0.01, chunk=1 << 20):
+        """Density-driven refresh of the occupancy grid (the reference only ever builds the dense grid once,
+        main.cu:393-399): evaluate sigma at every cell centre and keep cells whose optical thickness over one
+        cell, sigma * density_scale * cell_size, exceeds `threshold`.  Returns the occupied fraction."""
+        R = self.R
+        n = R ** 3
+        chunk = min(chunk, self.samples.shape[0])
+        sigma = torch.empty(n, device=self.dev)
+        ax = (torch.arange(R, device=self.dev, dtype=torch.float32) + 0.5) * (2.0 / R) - 1.0
+        for s0 in range(0, n, chunk):
+            idx = torch.arange(s0, min(s0 + chunk, n), device=self.dev)
+            z, y, x = idx % R, (idx // R) % R, idx // (R * R)                  # bit index = (x*R + y)*R + z
+            pts = torch.stack([ax[x], ax[y], ax[z], torch.zeros_like(ax[x]), torch.zeros_like(ax[x])], dim=1).contiguous()
+            m = pts.shape[0]
+            if self.encoding == "hash":
+                self.hg.encode(self.table, pts, self.encT)
+            else:
+                self.net.encode_frequency(pts, self.encT)
+            self.net.train_forward(self.encT, m, self.ws, self.out, self.radiance)
+            sigma[s0:s0 + m] = self.radiance[:m, 3]
+        thick = sigma * (self.density_scale * 2.0 / R)
+        self.occ = api.occupancy_from_density(thick, threshold, R)
+        self.coarse = api.build_occupancy_mip(self.occ, R) if R % 4 == 0 else None
+        return float((thick > threshold).float().mean().item())
 
 
 def camera_rays(look_at, focal, width, height, device="cuda", origin_scale=0.1):

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Data-parallel training check: N ranks each train on 1/N of every global batch (gradients all-reduced)
+and must end with the same parameters as ONE process training on the whole batches.
+  single:  python tools/train_dp_check.py --out ref.npy
+  N ranks: RTXN_REHEARSE_ON_ONE_GPU=1 python -m torch.distributed.run --nproc-per-node 2 tools/train_dp_check.py --out dp.npy
+(the rehearsal switch puts every rank on cuda:0 with a gloo group; on a multi-GPU node omit it: one GPU per rank, RCCL)"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from rtx_nerf_amd import scenes
+from rtx_nerf_amd.train import Trainer, camera_rays
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from train_demo import teacher_field
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--out", required=True)
+ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--encoding", default="hash")
+a = ap.parse_args()
+rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+rehearse = os.environ.get("RTXN_REHEARSE_ON_ONE_GPU") == "1"
+torch.cuda.set_device(0 if rehearse else int(os.environ.get("LOCAL_RANK", "0")))
+if world > 1:
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo" if rehearse else "nccl")
+
+R, res, B = 32, 32, 2048
+occ = torch.from_numpy(scenes.pack_occupancy(scenes.sphere_density(R, 0.72)).view(np.int32).copy()).cuda()
+tr = Trainer(R, occ, encoding=a.encoding, n_neurons=64, n_hidden_layers=2,
+             hashgrid=dict(n_levels=4, n_features=2, log2_hashmap_size=12, base_resolution=8, per_level_scale=1.5),
+             batch_rays=B, max_segments=B * 40, lr=1e-2, loss_scale=128.0, density_scale=150.0, seed=0)
+focal = scenes.lego_focal_length(True)
+o, d = camera_rays(scenes.pose_spherical(20.0, -30.0, origin_scale=10.0), focal, res, res)
+tgt = tr.render_rays(o, d, radiance_fn=teacher_field).clone()
+g = torch.Generator().manual_seed(1)
+for it in range(a.steps):
+    idx = torch.randint(0, o.shape[0], (B,), generator=g).cuda()       # the same global batch on every rank
+    mine = idx[rank::world].contiguous()                                # this rank's share
+    tr.step(o[mine].contiguous(), d[mine].contiguous(), tgt[mine].contiguous())
+    if it == 0:   # gradients of the first step (summed over ranks -> mean), before Adam's normalisation amplifies noise
+        g0 = torch.cat([tr.dparams, tr.dtable if a.encoding == "hash" else tr.dparams[:0]]).cpu().numpy() / world
+torch.cuda.synchronize()
+if rank == 0:
+    np.save(a.out, np.stack([g0, np.concatenate([tr.master.cpu().numpy(),
+                                                 tr.table_master.cpu().numpy() if a.encoding == "hash" else []])]))
+if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
