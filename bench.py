@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--poses", type=int, default=4)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--fused", action="store_true", help="per-segment compositing in the MLP epilogue (measured slower: frame is MFMA-bound)")
     ap.add_argument("--kernel-steps", type=int, default=5, help="extra frames with HIP events around the MLP kernel")
     return ap.parse_args()
 
@@ -105,7 +106,7 @@ def main():
     sh = RowShard(W, H, rank, world)
     n_local, ray_begin = sh.n_local, sh.ray_begin
     pipe = render.RenderPipeline(net, R, W, H, focal, occupancy=occ, max_rays=n_local, max_segments=1024,
-                                 window=sh.window)
+                                 window=sh.window, fused=args.fused)
     worst = pipe.calibrate(poses, ray_begin=ray_begin, ray_count=n_local)
     poses_d = [torch.from_numpy(p.reshape(16)).cuda() for p in poses]
 
@@ -163,8 +164,12 @@ def main():
         pipe._trace(ray_begin, n_local, write=True)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        net.forward_segments(pipe.start, pipe.end, pipe.seg_view, pipe.total, pipe.max_segments,
-                             pipe.radiance, pipe.t_vals)
+        if pipe.fused:
+            net.forward_segments_composite(pipe.start, pipe.end, pipe.seg_view, pipe.seg_first, pipe.total,
+                                           pipe.max_segments, pipe.seg_out, pipe.vr_mode, pipe.step_scale)
+        else:
+            net.forward_segments(pipe.start, pipe.end, pipe.seg_view, pipe.total, pipe.max_segments, pipe.radiance,
+                                 pipe.t_vals)
         e1.record()
         torch.cuda.synchronize()
         kern_ms.append(e0.elapsed_time(e1))
@@ -202,7 +207,7 @@ def main():
         if ms:
             ach = flops * smp / (ms * 1e-3) / 1e12
             out["roofline"] = {
-                "kernel": "mlp_fwd_kernel<128,...,segments,radiance>" if args.neurons == 128 else "mlp_fwd_kernel",
+                "kernel": f"mlp_fwd_kernel<{args.neurons},3,10,2,12,segments,{'segment-composite' if args.fused else 'radiance'}>",
                 "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": pmc_traffic(smp),
                 "flop_per_sample": flops, "samples_per_launch": smp, "kernel_ms": round(ms, 4),

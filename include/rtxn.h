@@ -113,6 +113,7 @@ typedef struct rtxn_trace_params {
   int* seg_ray;              /* int per slot: local ray of the segment (packed layout; new) */
   float* seg_view;           /* float2 per slot: (theta, phi) of the segment's ray (packed layout; new) */
   long segment_capacity;     /* packed layout: slots >= capacity are not written (0 = unbounded) */
+  uint8_t* seg_first;        /* byte per slot: 1 if the segment is the first of its ray (packed layout; new) */
 } rtxn_trace_params;
 
 /* One launch: ray generation + grid march.  With every segment pointer NULL it
@@ -228,6 +229,22 @@ int rtxn_mlp_forward_radiance(const rtxn_mlp* m, const float* input, float* radi
 int rtxn_mlp_forward_segments(const rtxn_mlp* m, const float* start_points, const float* end_points,
                               const float* seg_view, const int* total_segments, long max_segments,
                               float* radiance, float* t_vals, rtxn_stream_t stream);
+
+/* Fused compositor, first half: as rtxn_mlp_forward_segments, but instead of per-sample radiance the kernel
+ * composites each segment's 32 samples in its epilogue and writes ONE record per segment,
+ * seg_out[s] = (C_r, C_g, C_b, X) with C = sum_i w_i c_i and X = sum_i delta_i sigma_i over the segment
+ * (16 B/segment instead of 20 B/sample).  mode RTXN_VR_COMPAT: the reference arithmetic (delta = 1/32, and 31/32
+ * at the first sample of every later segment of a ray -- seg_first from rtxn_trace_grid says which; inclusive
+ * transmittance); RTXN_VR_NERF: samples at sub-interval midpoints, delta = |end-start|/32 * step_scale, exclusive
+ * transmittance.  Second half: rtxn_composite_segments. */
+int rtxn_mlp_forward_segments_composite(const rtxn_mlp* m, const float* start_points, const float* end_points,
+                                        const float* seg_view, const uint8_t* seg_first, const int* total_segments,
+                                        long max_segments, float* seg_out, int mode, float step_scale,
+                                        rtxn_stream_t stream);
+/* pixels[r] = sum over the ray's segments of exp(-sum of earlier X) * C  (replaces launch_volrender_cuda when the
+ * first half ran; num_hits/indices as there). */
+int rtxn_composite_segments(const float* seg_out, const int* num_hits, const int* indices, int batch_size, float* pixels,
+                            rtxn_stream_t stream);
 
 /* ---- training path (tiny-cuda-nn surface of main.cu:721-787) ------------------------ */
 /* Per-sample training tensors are FEATURE-MAJOR fp16: X[feature][S_pad] with

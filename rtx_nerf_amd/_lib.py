@@ -52,6 +52,7 @@ class TraceParams(C.Structure):
         ("seg_ray", C.c_void_p),
         ("seg_view", C.c_void_p),
         ("segment_capacity", C.c_long),
+        ("seg_first", C.c_void_p),
     ]
 
 
@@ -98,6 +99,8 @@ SYMBOLS = {
     "rtxn_mlp_forward": (_I, [_P, _P, _P, _L, _P]),
     "rtxn_mlp_forward_radiance": (_I, [_P, _P, _P, _L, _P]),
     "rtxn_mlp_forward_segments": (_I, [_P, _P, _P, _P, _P, _L, _P, _P, _P]),
+    "rtxn_mlp_forward_segments_composite": (_I, [_P, _P, _P, _P, _P, _P, _L, _P, _I, _F, _P]),
+    "rtxn_composite_segments": (_I, [_P, _P, _P, _I, _P, _P]),
     "rtxn_padded_samples": (_L, [_L]),
     "rtxn_encode_frequency": (_I, [_P, _P, _P, _L, _P]),
     "rtxn_hashgrid_create": (_I, [C.POINTER(HashGridConfig), C.POINTER(_P)]),

@@ -45,7 +45,7 @@ def trace_grid(look_at=None, focal_length=1.0, aspect_ratio=1.0, width=0, height
                rays_o=None, rays_d=None, ray_begin=0, ray_count=None, occupancy=None,
                occupancy_coarse=None, mode=TRACE_COMPAT, ray_origins=None, viewing_direction=None,
                num_hits=None, intersection_arr_size=0, indices=None, start_points=None,
-               end_points=None, t_start=None, t_end=None, seg_ray=None, seg_view=None, segment_capacity=0,
+               end_points=None, t_start=None, t_end=None, seg_ray=None, seg_view=None, seg_first=None, segment_capacity=0,
                window_chunk=0, window_stride=0):
     """optixLaunch(pipeline_ray_march, ..., width, height, 1) with Params (main.cu:481-508)."""
     p = TraceParams()
@@ -73,6 +73,7 @@ def trace_grid(look_at=None, focal_length=1.0, aspect_ratio=1.0, width=0, height
     p.t_end = _ptr(t_end, torch.float32, "t_end")
     p.seg_ray = _ptr(seg_ray, torch.int32, "seg_ray")
     p.seg_view = _ptr(seg_view, torch.float32, "seg_view")
+    p.seg_first = _ptr(seg_first, torch.uint8, "seg_first")
     p.segment_capacity = segment_capacity
     p.window_chunk, p.window_stride = window_chunk, window_stride
     check(_lib.lib().rtxn_trace_grid(C.byref(p), _stream()), "rtxn_trace_grid")
@@ -224,6 +225,27 @@ class Network:
             max_segments, _ptr(radiance, torch.float32, "radiance"), _ptr(t_vals, torch.float32, "t_vals"), _stream()),
             "rtxn_mlp_forward_segments")
         return radiance
+
+
+def _net_forward_segments_composite(self, start_points, end_points, seg_view, seg_first, total_segments, max_segments,
+                                    seg_out, mode=VR_COMPAT, step_scale=1.0):
+    """sampler + forward + glue + the per-segment half of the compositor in one launch (16 B/segment out)."""
+    check(_lib.lib().rtxn_mlp_forward_segments_composite(
+        self._h, _ptr(start_points, torch.float32, "start_points"), _ptr(end_points, torch.float32, "end_points"),
+        _ptr(seg_view, torch.float32, "seg_view"), _ptr(seg_first, torch.uint8, "seg_first"),
+        _ptr(total_segments, torch.int32, "total_segments"), max_segments, _ptr(seg_out, torch.float32, "seg_out"), mode,
+        step_scale, _stream()), "rtxn_mlp_forward_segments_composite")
+    return seg_out
+
+
+Network.forward_segments_composite = _net_forward_segments_composite
+
+
+def composite_segments(seg_out, num_hits, indices, batch_size, pixels):
+    """second half of the fused compositor (replaces launch_volrender_cuda after forward_segments_composite)."""
+    check(_lib.lib().rtxn_composite_segments(_ptr(seg_out, torch.float32, "seg_out"), _ptr(num_hits, torch.int32, "num_hits"),
+                                             _ptr(indices, torch.int32, "indices"), batch_size,
+                                             _ptr(pixels, torch.float32, "pixels"), _stream()), "rtxn_composite_segments")
 
 
 # --------------------------------------------------------------------------- training path

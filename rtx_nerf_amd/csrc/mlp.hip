@@ -67,7 +67,38 @@ struct FwdArgs {
   _Float16* out_half;  // [n][16]
   float4* radiance;    // [n]
   float* t_vals;       // [n] or NULL (IN_MODE 1 only)
+  // OUT_MODE 2 (IN_MODE 1 only): per-segment partial composite instead of per-sample radiance
+  const uint8_t* seg_first;  // [segments] 1 = first segment of its ray (COMPAT only)
+  float4* seg_out;           // [segments] (C_r, C_g, C_b, optical depth of the segment)
+  int vr_mode;               // RTXN_VR_COMPAT / RTXN_VR_NERF
+  float step_scale;          // NERF: world step multiplier (density scale)
 };
+
+// Per-segment partial composite of one 32-sample column tile (one segment), lanes col = 0..31 of a half-wave.
+// The compositor factorises over segments: pixel = sum_seg exp(-T_before(seg)) * C_seg with
+//   C_seg = sum_i w_i c_i,  w_i = exp(-T_loc_i) (1 - exp(-x_i)),  x_i = delta_i sigma_i,
+// T_loc inclusive (COMPAT, vol_render.cu:60-63) or exclusive (NERF) WITHIN the segment, so only 16 bytes per
+// segment (C_seg, sum x) leave the kernel instead of 20 bytes per sample.
+__device__ __forceinline__ float4 seg_composite(float r, float g, float b, float sigma, int col, float d0, float dr,
+                                                int vr_mode) {
+  const float x = (col == 0 ? d0 : dr) * sigma;
+  float incl = x;
+#pragma unroll
+  for (int d = 1; d < 32; d <<= 1) {
+    const float t = __shfl_up(incl, d, 32);
+    if (col >= d) incl += t;
+  }
+  const float Tloc = vr_mode == RTXN_VR_COMPAT ? incl : incl - x;
+  const float w = expf(-Tloc) * (1.0f - expf(-x));
+  float cr = w * r, cg = w * g, cb = w * b;
+#pragma unroll
+  for (int d = 16; d >= 1; d >>= 1) {
+    cr += __shfl_xor(cr, d, 32);
+    cg += __shfl_xor(cg, d, 32);
+    cb += __shfl_xor(cb, d, 32);
+  }
+  return make_float4(cr, cg, cb, __shfl(incl, 31, 32));
+}
 
 // ---------------------------------------------------------------------------
 // weight packing
@@ -203,6 +234,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
   float xin[2][5];
   bool valid_n[2];
   long samp_n[2];
+  float d0_n[2], dr_n[2];  // OUT_MODE 2: step of sample 0 / of the other samples of the segment
   auto load_inputs = [&](long tile) {
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
@@ -211,14 +243,26 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
         valid_n[ct] = seg < total_seg;
         samp_n[ct] = seg * 32 + col;
         const long sg = valid_n[ct] ? seg : 0;
-        const float t = (float)col * (1.0f / 32);
+        const bool mid = OUT_MODE == 2 && a.vr_mode == RTXN_VR_NERF;   // NERF composite samples sub-interval midpoints
+        const float t = ((float)col + (mid ? 0.5f : 0.0f)) * (1.0f / 32);
+        float dd[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           const float og = a.start[3 * sg + c];
-          xin[ct][c] = fmaf(t, a.end[3 * sg + c] - og, og);   // REGULAR sample, sampler.cu:52-66
+          dd[c] = a.end[3 * sg + c] - og;
+          xin[ct][c] = fmaf(t, dd[c], og);   // REGULAR sample, sampler.cu:52-66
         }
+        const float len2 = fmaf(dd[2], dd[2], fmaf(dd[0], dd[0], dd[1] * dd[1]));   // as the MIDPOINT_WORLD sampler
         xin[ct][3] = a.seg_view[2 * sg];
         xin[ct][4] = a.seg_view[2 * sg + 1];
+        if (OUT_MODE == 2) {
+          if (a.vr_mode == RTXN_VR_COMPAT) {
+            dr_n[ct] = 1.0f / 32;
+            d0_n[ct] = a.seg_first[sg] ? 1.0f / 32 : 31.0f / 32;   // t_prev is not reset per segment (vol_render.cu:56)
+          } else {
+            d0_n[ct] = dr_n[ct] = sqrtf(len2) * (1.0f / 32) * a.step_scale;
+          }
+        }
       } else {
         samp_n[ct] = tile * kTileSamples + wave * 64 + ct * 32 + col;
         valid_n[ct] = samp_n[ct] < a.n;
@@ -235,11 +279,14 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
     half8 bf[NB][2];
     bool valid[2];
     long samp[2];
+    float d0[2], dr[2];
     const float phase = 0.25f * (float)h;
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
       valid[ct] = valid_n[ct];
       samp[ct] = samp_n[ct];
+      d0[ct] = d0_n[ct];
+      dr[ct] = dr_n[ct];
 #pragma unroll
       for (int kk = 0; kk < KS0; ++kk) {
         half8 v;
@@ -251,7 +298,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
 #endif
         bf[kk][ct] = v;
       }
-      if (IN_MODE == 1 && a.t_vals && valid[ct] && h == 0) a.t_vals[samp[ct]] = (float)(col + 1) * (1.0f / 32);
+      if (IN_MODE == 1 && OUT_MODE != 2 && a.t_vals && valid[ct] && h == 0) a.t_vals[samp[ct]] = (float)(col + 1) * (1.0f / 32);
     }
     if (tile + gridDim.x < n_tiles) load_inputs(tile + gridDim.x);
 
@@ -286,7 +333,11 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
           const float z = acc[ct][e];
           y[e] = a.out_act == RTXN_ACT_SIGMOID ? 1.0f / (1.0f + __expf(-z)) : z;
         }
-        if (valid[ct]) {
+        if (OUT_MODE == 2) {
+          const float4 c = seg_composite((float)(_Float16)y[0], (float)(_Float16)y[1], (float)(_Float16)y[2],
+                                         (float)(_Float16)y[3], col, d0[ct], dr[ct], a.vr_mode);
+          if (valid[ct] && lane == 0) a.seg_out[samp[ct] >> 5] = c;
+        } else if (valid[ct]) {
           if (OUT_MODE == 0) {
             half4v lo, hi;
 #pragma unroll
@@ -404,20 +455,32 @@ __global__ __launch_bounds__(kThreads256, 2) void mlp_fwd256_kernel(FwdArgs a) {
   float xin[5];
   bool valid_n;
   long samp_n;
+  float d0_n = 0.0f, dr_n = 0.0f;
   auto load_inputs = [&](long tile) {
     if (IN_MODE == 1) {
       const long seg = tile * 8 + wave;
       valid_n = seg < total_seg;
       samp_n = seg * 32 + col;
       const long sg = valid_n ? seg : 0;
-      const float t = (float)col * (1.0f / 32);
+      const bool mid = OUT_MODE == 2 && a.vr_mode == RTXN_VR_NERF;
+      const float t = ((float)col + (mid ? 0.5f : 0.0f)) * (1.0f / 32);
+      float dd[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const float og = a.start[3 * sg + c];
-        xin[c] = fmaf(t, a.end[3 * sg + c] - og, og);
+        dd[c] = a.end[3 * sg + c] - og;
+        xin[c] = fmaf(t, dd[c], og);
       }
       xin[3] = a.seg_view[2 * sg];
       xin[4] = a.seg_view[2 * sg + 1];
+      if (OUT_MODE == 2) {
+        if (a.vr_mode == RTXN_VR_COMPAT) {
+          dr_n = 1.0f / 32;
+          d0_n = a.seg_first[sg] ? 1.0f / 32 : 31.0f / 32;
+        } else {
+          d0_n = dr_n = sqrtf(fmaf(dd[2], dd[2], fmaf(dd[0], dd[0], dd[1] * dd[1]))) * (1.0f / 32) * a.step_scale;
+        }
+      }
     } else {
       samp_n = tile * 256 + wave * 32 + col;
       valid_n = samp_n < a.n;
@@ -432,6 +495,7 @@ __global__ __launch_bounds__(kThreads256, 2) void mlp_fwd256_kernel(FwdArgs a) {
     half8 bf[KS], bg[KS];
     const bool valid = valid_n;
     const long samp = samp_n;
+    const float d0 = d0_n, dr = dr_n;
     const float phase = 0.25f * (float)h;
 #pragma unroll
     for (int kk = 0; kk < KS0; ++kk) {
@@ -440,7 +504,7 @@ __global__ __launch_bounds__(kThreads256, 2) void mlp_fwd256_kernel(FwdArgs a) {
       for (int j = 0; j < 8; ++j) v[j] = encode_slot<ES, PD, PF, DD, DF>(8 * kk + j, xin, phase);
       bf[kk] = v;
     }
-    if (IN_MODE == 1 && a.t_vals && valid && h == 0) a.t_vals[samp] = (float)(col + 1) * (1.0f / 32);
+    if (IN_MODE == 1 && OUT_MODE != 2 && a.t_vals && valid && h == 0) a.t_vals[samp] = (float)(col + 1) * (1.0f / 32);
     if (tile + gridDim.x < n_tiles) load_inputs(tile + gridDim.x);
 
     // layer 0: K = 16*KS0
@@ -485,7 +549,11 @@ __global__ __launch_bounds__(kThreads256, 2) void mlp_fwd256_kernel(FwdArgs a) {
     float y[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) y[e] = a.out_act == RTXN_ACT_SIGMOID ? 1.0f / (1.0f + __expf(-acc[e])) : acc[e];
-    if (valid) {
+    if (OUT_MODE == 2) {
+      const float4 c = seg_composite((float)(_Float16)y[0], (float)(_Float16)y[1], (float)(_Float16)y[2],
+                                     (float)(_Float16)y[3], col, d0, dr, a.vr_mode);
+      if (valid && lane == 0) a.seg_out[samp >> 5] = c;
+    } else if (valid) {
       if (OUT_MODE == 0) {
         half4v lo, hi;
 #pragma unroll
@@ -508,7 +576,7 @@ typedef void (*fwd_fn)(FwdArgs);
 
 struct Variant {
   int W, PD, PF, DD, DF;
-  fwd_fn fn[2][2];  // [IN_MODE][OUT_MODE]
+  fwd_fn fn[2][3];  // [IN_MODE][OUT_MODE]; OUT_MODE 2 (segment composite) exists for IN_MODE 1 only
   int k0;
   size_t lds;
   int threads;        // block size
@@ -526,6 +594,8 @@ Variant make_variant() {
   v.fn[0][1] = mlp_fwd_kernel<W, PD, PF, DD, DF, 0, 1>;
   v.fn[1][0] = mlp_fwd_kernel<W, PD, PF, DD, DF, 1, 0>;
   v.fn[1][1] = mlp_fwd_kernel<W, PD, PF, DD, DF, 1, 1>;
+  v.fn[0][2] = nullptr;
+  v.fn[1][2] = mlp_fwd_kernel<W, PD, PF, DD, DF, 1, 2>;
   v.k0 = ES::k0;
   v.lds = 2 * (size_t)(L0 > HID ? L0 : HID);
   v.threads = kThreads;
@@ -542,6 +612,8 @@ Variant make_variant256() {
   v.fn[0][1] = mlp_fwd256_kernel<PD, PF, DD, DF, 0, 1>;
   v.fn[1][0] = mlp_fwd256_kernel<PD, PF, DD, DF, 1, 0>;
   v.fn[1][1] = mlp_fwd256_kernel<PD, PF, DD, DF, 1, 1>;
+  v.fn[0][2] = nullptr;
+  v.fn[1][2] = mlp_fwd256_kernel<PD, PF, DD, DF, 1, 2>;
   v.k0 = ES::k0;
   v.lds = 3 * (size_t)kSlot256;
   v.threads = kThreads256;
@@ -600,7 +672,7 @@ int launch_fwd(const rtxn_mlp* m, FwdArgs& a, int in_mode, int out_mode, long n_
   long grid = n_tiles < (long)n_cu * v.blocks_per_cu ? n_tiles : (long)n_cu * v.blocks_per_cu;  // persistent grid
   if (grid < 1) grid = 1;
   fwd_fn fn = v.fn[in_mode][out_mode];
-  static bool attr_set[16][2][2] = {};
+  static bool attr_set[16][2][3] = {};
   if (!attr_set[m->variant][in_mode][out_mode]) {
     RTXN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)v.lds));
@@ -778,4 +850,32 @@ extern "C" int rtxn_mlp_forward_segments(const rtxn_mlp* m, const float* start_p
   a.radiance = reinterpret_cast<float4*>(radiance);
   a.t_vals = t_vals;
   return launch_fwd(m, a, 1, 1, (max_segments + 7) / 8, rtxn::as_stream(stream));
+}
+
+extern "C" int rtxn_mlp_forward_segments_composite(const rtxn_mlp* m, const float* start_points, const float* end_points,
+                                                   const float* seg_view, const uint8_t* seg_first,
+                                                   const int* total_segments, long max_segments, float* seg_out, int mode,
+                                                   float step_scale, rtxn_stream_t stream) {
+  int rc = check_ready(m, "rtxn_mlp_forward_segments_composite");
+  if (rc != RTXN_OK) return rc;
+  RTXN_REQUIRE(max_segments >= 0, "rtxn_mlp_forward_segments_composite: max_segments = %ld < 0", max_segments);
+  RTXN_REQUIRE(mode == RTXN_VR_COMPAT || mode == RTXN_VR_NERF, "rtxn_mlp_forward_segments_composite: unknown mode %d", mode);
+  RTXN_DEVICE_OR_FAIL();
+  if (max_segments == 0) return RTXN_OK;
+  RTXN_REQUIRE(start_points && end_points && seg_view && total_segments && seg_out,
+               "rtxn_mlp_forward_segments_composite: NULL buffer");
+  RTXN_REQUIRE(mode != RTXN_VR_COMPAT || seg_first, "rtxn_mlp_forward_segments_composite: COMPAT mode needs seg_first");
+  RTXN_REQUIRE(((uintptr_t)seg_out & 15) == 0, "rtxn_mlp_forward_segments_composite: seg_out must be 16-byte aligned");
+  FwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.start = start_points;
+  a.end = end_points;
+  a.seg_view = seg_view;
+  a.seg_first = seg_first;
+  a.total_segments = total_segments;
+  a.max_segments = max_segments;
+  a.seg_out = reinterpret_cast<float4*>(seg_out);
+  a.vr_mode = mode;
+  a.step_scale = step_scale;
+  return launch_fwd(m, a, 1, 2, (max_segments + 7) / 8, rtxn::as_stream(stream));
 }

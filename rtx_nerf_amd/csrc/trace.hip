@@ -33,6 +33,7 @@ struct Sink {
   float* t1;
   int* seg_ray;
   float* seg_view;
+  uint8_t* seg_first;
   float view[2];
   long base;
   long limit;  // first slot this ray may not write
@@ -47,6 +48,7 @@ struct Sink {
       if (t1) t1[k] = b;
       if (seg_ray) seg_ray[k] = ray;
       if (seg_view) { seg_view[2 * k] = view[0]; seg_view[2 * k + 1] = view[1]; }
+      if (seg_first) seg_first[k] = n == 0;
     }
     ++n;
   }
@@ -266,11 +268,11 @@ __global__ __launch_bounds__(256) void trace_kernel(rtxn_trace_params p) {
   if (p.ray_origins) { p.ray_origins[3 * (size_t)r] = o[0]; p.ray_origins[3 * (size_t)r + 1] = o[1]; p.ray_origins[3 * (size_t)r + 2] = o[2]; }
   if (p.viewing_direction) { p.viewing_direction[2 * (size_t)r] = v[0]; p.viewing_direction[2 * (size_t)r + 1] = v[1]; }
   Sink s;
-  s.start = p.start_points; s.end = p.end_points; s.t0 = p.t_start; s.t1 = p.t_end; s.seg_ray = p.seg_ray; s.seg_view = p.seg_view; s.view[0] = v[0]; s.view[1] = v[1];
+  s.start = p.start_points; s.end = p.end_points; s.t0 = p.t_start; s.t1 = p.t_end; s.seg_ray = p.seg_ray; s.seg_view = p.seg_view; s.seg_first = p.seg_first; s.view[0] = v[0]; s.view[1] = v[1];
   s.ray = (int)r; s.n = 0;
   if (p.indices) { s.base = p.indices[r]; s.limit = p.segment_capacity > 0 ? p.segment_capacity : 0x7fffffffffffffffL; }
   else { s.base = (long)r * p.intersection_arr_size; s.limit = s.base + p.intersection_arr_size; }
-  if (!p.start_points && !p.end_points && !p.t_start && !p.t_end && !p.seg_ray && !p.seg_view) s.limit = 0;
+  if (!p.start_points && !p.end_points && !p.t_start && !p.t_end && !p.seg_ray && !p.seg_view && !p.seg_first) s.limit = 0;
   if (MODE == RTXN_TRACE_COMPAT) march_compat(o, d, p.grid_res, p.occupancy, s);
   else march_dda(o, d, p.grid_res, p.occupancy, coarse, s);
   p.num_hits[r] = s.n;
@@ -340,7 +342,7 @@ extern "C" int rtxn_trace_grid(const rtxn_trace_params* p, rtxn_stream_t stream)
   }
   RTXN_REQUIRE(!p->occupancy_coarse || (p->occupancy && p->grid_res % 4 == 0),
                "rtxn_trace_grid: occupancy_coarse needs occupancy and grid_res %% 4 == 0");
-  const bool wants_segments = p->start_points || p->end_points || p->t_start || p->t_end || p->seg_ray || p->seg_view;
+  const bool wants_segments = p->start_points || p->end_points || p->t_start || p->t_end || p->seg_ray || p->seg_view || p->seg_first;
   RTXN_REQUIRE(!wants_segments || p->indices || p->intersection_arr_size > 0,
                "rtxn_trace_grid: segment outputs need indices (packed) or intersection_arr_size > 0 (strided)");
   RTXN_DEVICE_OR_FAIL();

@@ -212,7 +212,51 @@ __global__ __launch_bounds__(256) void volrender_bwd_nerf_kernel(const __half* _
   }
 }
 
+// Second half of the fused compositor: per ray, pixel = sum_seg exp(-T_before(seg)) * C_seg over the
+// (C_r, C_g, C_b, X) records rtxn_mlp_forward_segments_composite wrote (16 B/segment instead of 640 B).
+__global__ __launch_bounds__(256) void composite_segments_kernel(const float4* __restrict__ seg, const int* __restrict__ num_hits,
+                                                                 const int* __restrict__ indices, int batch_size,
+                                                                 float* __restrict__ pixels) {
+  const int lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= batch_size) return;
+  const long base = indices[ray];
+  const int n = num_hits[ray];
+  float T_carry = 0.0f, ar = 0.0f, ag = 0.0f, ab = 0.0f;
+  for (int s0 = 0; s0 < n; s0 += 64) {
+    const bool act = s0 + lane < n;
+    const float4 c = act ? seg[base + s0 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float incl = wave_incl_scan_f(c.w, lane);
+    const float w = act ? expf(-(T_carry + incl - c.w)) : 0.0f;
+    ar = fmaf(w, c.x, ar);
+    ag = fmaf(w, c.y, ag);
+    ab = fmaf(w, c.z, ab);
+    T_carry += __shfl(incl, 63, 64);
+  }
+  ar = wave_sum(ar);
+  ag = wave_sum(ag);
+  ab = wave_sum(ab);
+  if (lane == 0) {
+    pixels[3 * (long)ray] = ar;
+    pixels[3 * (long)ray + 1] = ag;
+    pixels[3 * (long)ray + 2] = ab;
+  }
+}
+
 }  // namespace
+
+extern "C" int rtxn_composite_segments(const float* seg_out, const int* num_hits, const int* indices, int batch_size,
+                                       float* pixels, rtxn_stream_t stream) {
+  RTXN_REQUIRE(batch_size >= 0, "rtxn_composite_segments: batch_size = %d < 0", batch_size);
+  RTXN_DEVICE_OR_FAIL();
+  if (batch_size == 0) return RTXN_OK;
+  RTXN_REQUIRE(seg_out && num_hits && indices && pixels, "rtxn_composite_segments: NULL buffer");
+  RTXN_REQUIRE(((uintptr_t)seg_out & 15) == 0, "rtxn_composite_segments: seg_out must be 16-byte aligned");
+  composite_segments_kernel<<<(batch_size + 3) / 4, 256, 0, rtxn::as_stream(stream)>>>(
+      reinterpret_cast<const float4*>(seg_out), num_hits, indices, batch_size, pixels);
+  RTXN_LAUNCH_CHECK("composite_segments_kernel");
+  return RTXN_OK;
+}
 
 extern "C" int rtxn_volrender_fwd(const float* network_inputs, const float* network_outputs, const int* num_hits,
                                   const int* indices, const float* ray_hit, int batch_size,

@@ -18,6 +18,7 @@ ap.add_argument("--segments", type=int, default=3_000_000)
 ap.add_argument("--neurons", type=int, default=128)
 ap.add_argument("--layers", type=int, default=8)
 ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--composite", action="store_true", help="time the fused per-segment composite epilogue variant")
 args = ap.parse_args()
 
 torch.cuda.set_device(0)
@@ -32,16 +33,26 @@ sv = vd[seg_ray.long()].contiguous()
 total = torch.tensor([P], dtype=torch.int32, device="cuda")
 net = api.Network(n_neurons=args.neurons, n_hidden_layers=args.layers)
 net.set_params(torch.from_numpy(scenes.xavier_params_fp16(args.neurons, args.layers, net.encoded_width())).cuda())
-rad = torch.empty((P * 32, 4), device="cuda")
-tv = torch.empty(P * 32, device="cuda")
+if args.composite:
+    seg_first = (torch.arange(P, device="cuda") % 5 == 0).to(torch.uint8)
+    seg_out = torch.empty((P, 4), device="cuda")
+
+    def run():
+        net.forward_segments_composite(sp, ep, sv, seg_first, total, P, seg_out)
+else:
+    rad = torch.empty((P * 32, 4), device="cuda")
+    tv = torch.empty(P * 32, device="cuda")
+
+    def run():
+        net.forward_segments(sp, ep, sv, total, P, rad, tv)
 for _ in range(2):
-    net.forward_segments(sp, ep, sv, total, P, rad, tv)
+    run()
 torch.cuda.synchronize()
 ms = []
 for _ in range(args.iters):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    net.forward_segments(sp, ep, sv, total, P, rad, tv)
+    run()
     e1.record()
     torch.cuda.synchronize()
     ms.append(e0.elapsed_time(e1))
