@@ -96,6 +96,69 @@ __host__ __device__ __forceinline__ int perm_feature(int kk, int h, int j) { ret
 // One layer: out rows [32*rt, 32*rt+32) for rt < RT, K = 16*KS, for the wave's two column
 // tiles.  Row-tile-outer: an accumulator is live for one row tile only, and its ReLU/convert
 // (VALU) overlaps the next row tile's MFMAs.  A fragments: chunk (rt, kk) at ((rt*KS+kk)*64+lane)*16.
+#ifdef RTXN_PIPE_A
+// Variant with a hand-placed software pipeline (cdna_hip_programming.md 5.7 form (iii)): hipcc sinks every plain LDS
+// load down to its consumer (ds_read; s_waitcnt lgkmcnt(0); mfma), exposing the LDS latency once per k-step.  Here the
+// A fragments are fetched with inline-asm ds_read_b128 RTXN_PIPE_A steps ahead into a register ring, each consumer is
+// preceded by a counted s_waitcnt lgkmcnt(N) + sched_barrier, and nothing else in the loop touches LDS or SMEM.
+template <int OFF>
+__device__ __forceinline__ void lds_read_frag(half8& dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N));
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int RT, int KS, int NB, int I>
+struct LayerStep {
+  static constexpr int D = RTXN_PIPE_A, N = RT * KS;
+  __device__ static __forceinline__ void run(unsigned addr, const half8 (&bf)[NB][2], half8 (&nbf)[NB][2], half8 (&ring)[D],
+                                             floatx16 (&acc)[2]) {
+    constexpr int rt = I / KS, kk = I % KS;
+    constexpr int outstanding = (N - 1 - I) < (D - 1) ? (N - 1 - I) : (D - 1);   // reads issued after fragment I
+    lds_wait<outstanding>();
+    const half8 a = ring[I % D];
+    if (kk == 0) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[ct][e] = 0.0f;
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[kk][ct], acc[ct], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (I + D < N) lds_read_frag<(I + D < N ? (I + D) * 1024 : 0)>(ring[I % D], addr);
+    if (kk == KS - 1) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) nbf[2 * rt + s][ct] = relu_pack(acc[ct], s);
+    }
+    if constexpr (I + 1 < N) LayerStep<RT, KS, NB, I + 1>::run(addr, bf, nbf, ring, acc);
+  }
+};
+
+template <int RT, int KS, int NB>
+__device__ __forceinline__ void layer_mma(const uint8_t* lds_buf, const half8 (&bf)[NB][2], half8 (&nbf)[NB][2],
+                                          int lane) {
+  constexpr int D = RTXN_PIPE_A, N = RT * KS;
+  static_assert(N * 1024 <= 65535 + 1024, "fragment offsets must fit the 16-bit ds offset");
+  half8 ring[D];
+  const unsigned addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) uint8_t*)lds_buf + lane * 16;
+  // prologue: the first D fragments
+  lds_read_frag<0>(ring[0], addr);
+  if (D > 1 && N > 1) lds_read_frag<1024>(ring[1 % D], addr);
+  if (D > 2 && N > 2) lds_read_frag<2048>(ring[2 % D], addr);
+  if (D > 3 && N > 3) lds_read_frag<3072>(ring[3 % D], addr);
+  floatx16 acc[2];
+  LayerStep<RT, KS, NB, 0>::run(addr, bf, nbf, ring, acc);
+}
+#else
+// One layer: out rows [32*rt, 32*rt+32) for rt < RT, K = 16*KS, for the wave's two column
+// tiles.  Row-tile-outer: an accumulator is live for one row tile only, and its ReLU/convert
+// (VALU) overlaps the next row tile's MFMAs.  A fragments: chunk (rt, kk) at ((rt*KS+kk)*64+lane)*16.
 template <int RT, int KS, int NB>
 __device__ __forceinline__ void layer_mma(const uint8_t* lds_buf, const half8 (&bf)[NB][2], half8 (&nbf)[NB][2],
                                           int lane) {
@@ -108,30 +171,17 @@ __device__ __forceinline__ void layer_mma(const uint8_t* lds_buf, const half8 (&
       for (int e = 0; e < 16; ++e) acc[ct][e] = 0.0f;
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
-#ifdef RTXN_ABLATE_DSREAD
-      half8 a = bf[kk][0];
-#else
       const half8 a = *reinterpret_cast<const half8*>(lds_buf + ((rt * KS + kk) * 64 + lane) * 16);
-#endif
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[kk][ct], acc[ct], 0, 0, 0);
     }
-#ifdef RTXN_ABLATE_CONVERT
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
-        asm volatile("" ::"v"(acc[ct]));
-        nbf[2 * rt + s][ct] = bf[2 * rt + s][ct];
-      }
-#else
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) nbf[2 * rt + s][ct] = relu_pack(acc[ct], s);
-#endif
   }
 }
+#endif
 
 // Output layer: 32 rows (16 real), raw accumulators returned.
 template <int KS, int NB>
