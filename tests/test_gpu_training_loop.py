@@ -17,3 +17,73 @@ def test_training_converges(gpu, encoding, steps, gain):
     p0, p1, losses = train_demo.run(steps=steps, encoding=encoding, grid=32, res=64, batch=4096, n_poses=12, verbose=False)
     assert losses[-1] < 0.1 * losses[0], losses
     assert p1 > p0 + gain, (p0, p1)          # held-out pose, measured: hash +10.5 dB, freq +7.7 dB
+
+
+def test_config3_training_step_matches_oracle_chain(gpu, oracle):
+    """BASELINE configs[2] in miniature (hash-grid encoding + 4x64 MLP, one ray batch): every stage of one
+    optimisation step on the GPU against the same step chained from oracle functions."""
+    import numpy as np
+    torch = gpu
+    from rtx_nerf_amd import api, scenes
+    from rtx_nerf_amd.train import Trainer, camera_rays
+    R, B, scale, ls = 16, 900, 120.0, 128.0
+    dense = scenes.sphere_density(R, 0.75)
+    words = scenes.pack_occupancy(dense)
+    occ = torch.from_numpy(words.view(np.int32).copy()).cuda()
+    hgd = dict(n_levels=4, n_features=2, log2_hashmap_size=11, base_resolution=4, per_level_scale=1.6)
+    tr = Trainer(R, occ, encoding="hash", n_neurons=64, n_hidden_layers=4, hashgrid=hgd, n_dir_freqs=4, batch_rays=B,
+                 max_segments=B * 30, lr=1e-2, loss_scale=ls, density_scale=scale, mode="nerf", seed=3)
+    # give the table non-trivial values so the encoding is not ~0
+    g = torch.Generator().manual_seed(5)
+    tr.table_master.copy_(((torch.rand(tr.hg.n_params(), generator=g) * 2 - 1) * 0.5).cuda())
+    tr.table.copy_(tr.table_master.half())
+    o, d = camera_rays(scenes.pose_spherical(40.0, -30.0, origin_scale=10.0), scenes.lego_focal_length(True), 30, 30)
+    rng = np.random.default_rng(0)
+    tgt = torch.from_numpy(rng.uniform(0, 1, (B, 3)).astype(np.float32)).cuda()
+    params0 = tr.params.cpu().numpy().copy()
+    table0 = tr.table.cpu().numpy().copy()
+    master0, tmaster0 = tr.master.cpu().numpy().copy(), tr.table_master.cpu().numpy().copy()
+    loss = float(tr.step(o, d, tgt).item())
+    P = int(tr.total.item())
+    S = P * 32
+
+    # ---- the same step from oracle pieces -------------------------------------------------------
+    O = oracle
+    on, dn = o.cpu().numpy(), d.cpu().numpy()
+    pk = O.trace_packed(rays_o=on, rays_d=dn, R=R, occ=words, mode=1)
+    assert pk["total"] == P
+    samples, steps = O.sample(pk["start"], pk["end"], pk["view_dirs"], pk["num_hits"], pk["indices"], 3)
+    np.testing.assert_array_equal(tr.samples[:S].cpu().numpy()[:, :3], samples[:, :3])
+    steps = steps * np.float32(scale)
+    ocfg = O.hg_cfg(**hgd)
+    # view angles come from the device's atan2f; use the GPU's own (theta, phi) so the encodings are comparable
+    samples[:, 3:] = tr.samples[:S].cpu().numpy()[:, 3:]
+    enc = O.encode_hg(ocfg, 4, table0, samples)
+    acts, out = O.mlpe_forward(64, 4, 1, params0, enc)
+    rad = out[:, :4].astype(np.float32)
+    pix = O.volrender_fwd_nerf(rad, pk["num_hits"], pk["indices"], steps)
+    np.testing.assert_allclose(tr.pixels.cpu().numpy(), pix, rtol=0, atol=3e-3)
+    o_loss, _, g16, _ = O.l2_loss(pix, tgt.cpu().numpy(), ls)
+    assert abs(loss - o_loss) < 2e-3 * o_loss
+    # continue the oracle chain from the GPU's forward state (radiance, loss gradients) so that the backward
+    # comparison is not dominated by forward rounding differences
+    rad_g = tr.radiance[:S].cpu().numpy()
+    lg = tr.loss_grads.cpu().numpy()
+    dout = O.volrender_bwd_nerf(lg, rad_g, steps, pk["num_hits"], pk["indices"]).astype(np.float16)
+    np.testing.assert_allclose(tr.dout[:S].cpu().numpy().astype(np.float32), dout.astype(np.float32), rtol=2e-3, atol=1e-6)
+    Sp = api.padded_samples(S)
+    acts_g = tr.ws[:4 * 64 * Sp].reshape(4, 64, Sp)[:, :, :S].permute(0, 2, 1).contiguous().cpu().numpy()
+    enc_g = tr.encT.reshape(-1)[:tr.E * Sp].reshape(tr.E, Sp)[:, :S].t().contiguous().cpu().numpy()
+    dp, denc = O.mlpe_backward(64, 4, 1, params0, enc_g, acts_g, tr.out[:S].cpu().numpy(), tr.dout[:S].cpu().numpy())
+    got_dp = tr.dparams.cpu().numpy()
+    assert np.linalg.norm(got_dp - dp) < 2e-2 * np.linalg.norm(dp) and np.abs(dp).max() > 0
+    dt = O.hg_backward(ocfg, samples, tr.dencT.reshape(-1)[:tr.E * Sp].reshape(tr.E, Sp)[:, :S].t().contiguous().cpu().numpy())
+    got_dt = tr.dtable.cpu().numpy()
+    assert np.abs(got_dt - dt).max() < 1e-3 * max(1e-6, np.abs(dt).max())
+    # Adam from the GPU's gradients reproduces the GPU's new parameters
+    m, v = np.zeros_like(master0), np.zeros_like(master0)
+    O.adam_step(master0, got_dp, m, v, 1, lr=1e-2, loss_scale=ls)
+    np.testing.assert_allclose(tr.master.cpu().numpy(), master0, rtol=0, atol=2e-6)
+    m, v = np.zeros_like(tmaster0), np.zeros_like(tmaster0)
+    O.adam_step(tmaster0, got_dt, m, v, 1, lr=1e-1, eps=1e-15, loss_scale=ls)
+    np.testing.assert_allclose(tr.table_master.cpu().numpy(), tmaster0, rtol=0, atol=2e-6)
