@@ -291,11 +291,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
       for (int kk = 0; kk < KS0; ++kk) {
         half8 v;
 #pragma unroll
-#ifdef RTXN_ABLATE_ENCODE
-        for (int j = 0; j < 8; ++j) v[j] = (_Float16)(xin[ct][j % 5] + phase);
-#else
         for (int j = 0; j < 8; ++j) v[j] = encode_slot<ES, PD, PF, DD, DF>(8 * kk + j, xin[ct], phase);
-#endif
         bf[kk][ct] = v;
       }
       if (IN_MODE == 1 && OUT_MODE != 2 && a.t_vals && valid[ct] && h == 0) a.t_vals[samp[ct]] = (float)(col + 1) * (1.0f / 32);
@@ -308,9 +304,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
     auto begin_stage = [&](int l) -> const uint8_t* {
       const uint8_t* cur = smem + (q & 1) * BUF;
       uint8_t* nxt = smem + ((q + 1) & 1) * BUF;
-#ifndef RTXN_ABLATE_BARRIER
       __syncthreads();  // stage q landed (hipcc drains vmcnt before the barrier); buffer nxt is free
-#endif
       if (l + 1 < n_layers) {
         if (l + 1 == n_layers - 1) stage<OUT_BYTES>(a.packed + layer_off(l + 1), nxt, tid);
         else stage<HID_BYTES>(a.packed + layer_off(l + 1), nxt, tid);
