@@ -114,6 +114,8 @@ typedef struct rtxn_trace_params {
   float* seg_view;           /* float2 per slot: (theta, phi) of the segment's ray (packed layout; new) */
   long segment_capacity;     /* packed layout: slots >= capacity are not written (0 = unbounded) */
   uint8_t* seg_first;        /* byte per slot: 1 if the segment is the first of its ray (packed layout; new) */
+  int* num_stored;           /* int[ray_count] or NULL: segments actually WRITTEN for the ray (< num_hits when
+                              * intersection_arr_size / segment_capacity cut it off): the count downstream stages may read */
 } rtxn_trace_params;
 
 /* One launch: ray generation + grid march.  With every segment pointer NULL it

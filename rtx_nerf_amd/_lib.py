@@ -53,6 +53,7 @@ class TraceParams(C.Structure):
         ("seg_view", C.c_void_p),
         ("segment_capacity", C.c_long),
         ("seg_first", C.c_void_p),
+        ("num_stored", C.c_void_p),
     ]
 
 

@@ -45,7 +45,7 @@ def trace_grid(look_at=None, focal_length=1.0, aspect_ratio=1.0, width=0, height
                rays_o=None, rays_d=None, ray_begin=0, ray_count=None, occupancy=None,
                occupancy_coarse=None, mode=TRACE_COMPAT, ray_origins=None, viewing_direction=None,
                num_hits=None, intersection_arr_size=0, indices=None, start_points=None,
-               end_points=None, t_start=None, t_end=None, seg_ray=None, seg_view=None, seg_first=None, segment_capacity=0,
+               end_points=None, t_start=None, t_end=None, seg_ray=None, seg_view=None, seg_first=None, num_stored=None, segment_capacity=0,
                window_chunk=0, window_stride=0):
     """optixLaunch(pipeline_ray_march, ..., width, height, 1) with Params (main.cu:481-508)."""
     p = TraceParams()
@@ -74,6 +74,7 @@ def trace_grid(look_at=None, focal_length=1.0, aspect_ratio=1.0, width=0, height
     p.seg_ray = _ptr(seg_ray, torch.int32, "seg_ray")
     p.seg_view = _ptr(seg_view, torch.float32, "seg_view")
     p.seg_first = _ptr(seg_first, torch.uint8, "seg_first")
+    p.num_stored = _ptr(num_stored, torch.int32, "num_stored")
     p.segment_capacity = segment_capacity
     p.window_chunk, p.window_stride = window_chunk, window_stride
     check(_lib.lib().rtxn_trace_grid(C.byref(p), _stream()), "rtxn_trace_grid")

@@ -276,6 +276,10 @@ __global__ __launch_bounds__(256) void trace_kernel(rtxn_trace_params p) {
   if (MODE == RTXN_TRACE_COMPAT) march_compat(o, d, p.grid_res, p.occupancy, s);
   else march_dda(o, d, p.grid_res, p.occupancy, coarse, s);
   p.num_hits[r] = s.n;
+  if (p.num_stored) {
+    const long room = s.limit - s.base;
+    p.num_stored[r] = (int)(room <= 0 ? 0 : (room < s.n ? room : s.n));
+  }
 }
 
 // one thread per coarse WORD (32 coarse cells), deterministic, no pre-zeroing

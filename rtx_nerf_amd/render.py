@@ -81,7 +81,7 @@ class RenderPipeline:
                   num_hits=self.num_hits, window_chunk=self.window[0], window_stride=self.window[1])
         if write:
             kw.update(indices=self.indices, start_points=self.start, end_points=self.end, seg_view=self.seg_view,
-                      seg_first=self.seg_first, segment_capacity=self.max_segments)
+                      seg_first=self.seg_first, num_stored=self.num_hits_c, segment_capacity=self.max_segments)
         api.trace_grid(self.look_at, self.focal, self.aspect, self.W, self.H, **kw)
 
     def count_segments(self, ray_begin=0, ray_count=None):
@@ -112,9 +112,9 @@ class RenderPipeline:
         self._trace(ray_begin, n, write=False)
         api.scan_hits(nh, idx, self.total, self.scan_ws)
         self._trace(ray_begin, n, write=True)
-        # rays whose segments would overflow the capacity are truncated on the device (never out of bounds)
+        # rays whose segments would overflow the capacity are truncated on the device (never out of bounds):
+        # the write pass reports how many segments it actually stored per ray
         nhc = self.num_hits_c[:n]
-        torch.minimum(nh, (self.max_segments - idx).clamp_(min=0), out=nhc)
         if self.fused:
             self.net.forward_segments_composite(self.start, self.end, self.seg_view, self.seg_first, self.total,
                                                 self.max_segments, self.seg_out, self.vr_mode, self.step_scale)
