@@ -126,5 +126,14 @@ class RenderPipeline:
                                       pixels, mode=self.vr_mode)
         return pixels
 
+    def capture(self, ray_begin=0, ray_count=None, out=None):
+        """Capture one frame into a hipGraph (torch.cuda.CUDAGraph over the C-ABI launches: none of them
+        allocates, synchronises or touches the host).  Returns (graph, pixels): update the pose with set_pose()
+        and call graph.replay().  The frame must have been rendered once eagerly (module/attribute setup)."""
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            pixels = self.render(ray_begin, ray_count, out)
+        return g, pixels
+
     def overflowed(self):
         return int(self.total.item()) > self.max_segments

@@ -105,3 +105,23 @@ def test_oracle_spot_check_on_a_strided_sample(frame, oracle):
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-3)
     mse = float(((got - want) ** 2).mean())
     assert 10 * np.log10(1.0 / max(mse, 1e-20)) > 80.0
+
+
+def test_frame_is_hipgraph_capturable(frame):
+    """include/rtxn.h promises that no entry point allocates or synchronises: the whole frame
+    (2 traversal passes, scan, fused sampler+MLP, compositor) replays from one hipGraph, for any pose."""
+    torch, pipe = frame["torch"], frame["pipe"]
+    la2 = scenes.pose_spherical(200.0, -25.0, origin_scale=10.0)
+    pipe.calibrate([frame["la"], la2])        # buffers are sized for both poses BEFORE the capture pins their addresses
+    pipe.set_pose(frame["la"])
+    pipe.render()
+    g, pix = pipe.capture()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(pix, frame["pix"])
+    pipe.set_pose(la2)
+    g.replay()
+    a = pix.clone()
+    b = pipe.render().clone()
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and not torch.equal(a, frame["pix"])
