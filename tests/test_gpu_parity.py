@@ -534,3 +534,20 @@ def test_fused_compositor_equals_staged_and_oracle(gpu, oracle, W):
     api.launch_volrender_cuda(None, rad, fn.num_hits, fn.indices, tv, n, 32, pix, mode=api.VR_NERF)
     np.testing.assert_allclose(c, pix.cpu().numpy(), rtol=0, atol=3e-6)
     assert c.std() > 0.01
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_trace_maximum_grid_resolution(gpu, oracle, mode):
+    """R = 1024 (the largest grid the ABI accepts), dense: up to 3R-2 = 3070 segments per ray, strided layout."""
+    torch = gpu
+    from rtx_nerf_amd import api
+    R = 1024
+    rng = np.random.default_rng(77)
+    ro = rng.uniform(-2.5, 2.5, (48, 3)).astype(np.float32)
+    tgt = rng.uniform(-0.9, 0.9, (48, 3)).astype(np.float32)
+    rd = tgt - ro
+    rd = (rd / np.linalg.norm(rd, axis=1, keepdims=True)).astype(np.float32)
+    want = oracle.trace(rays_o=ro, rays_d=rd, R=R, mode=mode)
+    got = _trace_gpu(torch, api, R=R, mode=mode, rays_o=ro, rays_d=rd)
+    assert want["num_hits"].max() > R and want["num_hits"].max() <= 3 * R - 2
+    _assert_trace_equal(got, want)
