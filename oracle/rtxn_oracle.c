@@ -157,6 +157,13 @@ static inline int slab_box(const float* o, const float* d, const float* lo, cons
                            float* t_rep, float* t_far) {
   float tmin = -INFINITY, tmax = INFINITY;
   for (int a = 0; a < 3; ++a) {
+    if (d[a] == 0.0f) {
+      /* ray parallel to this slab.  The reference divides by zero here (+-inf, or NaN when the origin lies on
+       * the plane, and -inf exit times for d = -0.0): its result is undefined.  This build defines it: the slab
+       * constrains nothing if the origin is inside it and rejects the box otherwise. */
+      if (!(o[a] >= lo[a] && o[a] <= hi[a])) { tmin = INFINITY; }
+      continue;
+    }
     float t1 = (lo[a] - o[a]) / d[a];
     float t2 = (hi[a] - o[a]) / d[a];
     tmin = fmaxf(tmin, fminf(t1, t2));
@@ -209,6 +216,10 @@ static int grid_entry(const float* o, const float* d, int R, float L, int* cell,
   if (!inside) {
     float tmin = -INFINITY, tmax = INFINITY;
     for (int a = 0; a < 3; ++a) {
+      if (d[a] == 0.0f) { /* parallel to this slab of the grid: inside it or a miss */
+        if (!(o[a] >= -1.0f && o[a] <= 1.0f)) return 0;
+        continue;
+      }
       float t1 = (-1.0f - o[a]) / d[a];
       float t2 = (1.0f - o[a]) / d[a];
       float tn = fminf(t1, t2), tf = fmaxf(t1, t2);
@@ -253,7 +264,7 @@ static void march_compat(const float* o0, const float* d, int R, const uint32_t*
     float te[3];
     for (int a = 0; a < 3; ++a) {
       float plane = d[a] < 0 ? lo[a] : hi[a];
-      te[a] = (plane - o[a]) / d[a];
+      te[a] = d[a] == 0.0f ? INFINITY : (plane - o[a]) / d[a];   /* a parallel axis is never the exit axis */
     }
     float t_e = fminf(fminf(te[0], te[1]), te[2]);
     float p0[3], p1[3];

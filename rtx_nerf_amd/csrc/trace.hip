@@ -97,6 +97,10 @@ __device__ __forceinline__ bool grid_entry(const float (&o)[3], const float (&d)
     float tmin = -INFINITY, tmax = INFINITY;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
+      if (d[a] == 0.0f) {  // parallel to this slab of the grid: inside it or a miss
+        if (!(o[a] >= -1.0f && o[a] <= 1.0f)) return false;
+        continue;
+      }
       const float t1 = (-1.0f - o[a]) / d[a];
       const float t2 = (1.0f - o[a]) / d[a];
       const float tn = fminf(t1, t2), tf = fmaxf(t1, t2);
@@ -133,6 +137,12 @@ __device__ void march_compat(const float (&o0)[3], const float (&d)[3], int R, c
     float tmin = -INFINITY, tmax = INFINITY;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
+      if (d[a] == 0.0f) {
+        // parallel to this slab: the reference divides by zero (undefined result); defined here as
+        // "no constraint if the origin is inside the slab, no hit otherwise"
+        if (!(o[a] >= lo[a] && o[a] <= hi[a])) tmin = INFINITY;
+        continue;
+      }
       const float t1 = (lo[a] - o[a]) / d[a];
       const float t2 = (hi[a] - o[a]) / d[a];
       tmin = fmaxf(tmin, fminf(t1, t2));
@@ -146,7 +156,7 @@ __device__ void march_compat(const float (&o0)[3], const float (&d)[3], int R, c
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       const float plane = d[a] < 0 ? lo[a] : hi[a];
-      te[a] = (plane - o[a]) / d[a];
+      te[a] = d[a] == 0.0f ? INFINITY : (plane - o[a]) / d[a];  // a parallel axis is never the exit axis
     }
     const float t_e = fminf(fminf(te[0], te[1]), te[2]);
     float p0[3], p1[3];

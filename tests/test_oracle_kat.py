@@ -386,3 +386,24 @@ def test_config1_host_ray_march(oracle, variant):
     if variant == "sphere":
         dense_pix, _ = oracle.render(la, f, 1.0, W, H, R, None, 0, cfg, params, np.arange(W * H))
         assert (pk["num_hits"] <= 3 * R - 2).all() and not np.array_equal(dense_pix, pix)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_axis_parallel_poses_are_well_defined(oracle, mode):
+    """Poses whose rays have an exactly zero (even -0.0) direction component: the reference divides by zero
+    there (NaN points, -inf exit times); this build defines the result -- finite points, <= 3R-2 segments."""
+    R = 4
+    for th, ph in [(0.0, -90.0), (90.0, 0.0), (180.0, -90.0), (270.0, 0.0)]:
+        la = scenes.pose_spherical(th, ph, radius=2.236169, origin_scale=10.0)
+        r = oracle.trace(look_at=la, focal=1.7, aspect=13 / 39, W=13, H=39, R=R, mode=mode)
+        nh = r["num_hits"]
+        assert nh.max() <= 3 * R - 2 and nh.max() >= R
+        S = 3 * R
+        for ray in np.nonzero(nh)[0]:
+            seg = slice(ray * S, ray * S + nh[ray])
+            assert np.isfinite(r["start"][seg]).all() and np.isfinite(r["end"][seg]).all() and np.isfinite(r["t_end"][seg]).all()
+            assert np.all(np.abs(r["end"][seg]) <= 1 + 1e-5)
+    o = np.array([[0.0, 2.0, 0.0], [0.25, 0.0, -3.0]], np.float32)          # on a cell plane, zero components
+    d = np.array([[-0.0, -1.0, 0.0], [0.0, -0.0, 1.0]], np.float32)
+    r = oracle.trace(rays_o=o, rays_d=d, R=R, mode=mode)
+    assert list(r["num_hits"]) == [R, R] and np.isfinite(r["start"][:R]).all() and np.isfinite(r["end"][3 * R:4 * R]).all()
