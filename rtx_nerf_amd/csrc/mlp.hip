@@ -48,7 +48,6 @@ using rtxn::relu_pack;
 using rtxn::stage;
 
 constexpr int kTileSamples = 256;  // per block per iteration
-constexpr int kThreads = 256;
 
 struct FwdArgs {
   const uint8_t* packed;
@@ -197,8 +196,12 @@ __device__ __forceinline__ _Float16 encode_slot(int p, const float (&x)[5], floa
   return (_Float16)0.0f;
 }
 
-template <int W, int PD, int PF, int DD, int DF, int IN_MODE, int OUT_MODE>
-__global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
+// CT = 32-sample column tiles per wave.  CT = 2: 4 waves x 64 samples, 2 blocks/CU (2 waves/SIMD, ~244 VGPRs), every
+// A fragment feeds two MFMAs.  CT = 1: 8 waves x 32 samples, 2 blocks/CU (4 waves/SIMD, <= 128 VGPRs): more waves to
+// cover each other's encode/convert phases, one LDS read per MFMA.
+template <int W, int PD, int PF, int DD, int DF, int IN_MODE, int OUT_MODE, int CT>
+__global__ __launch_bounds__(CT == 2 ? 256 : 512, CT == 2 ? 2 : 4) void mlp_fwd_kernel(FwdArgs a) {
+  constexpr int THREADS = CT == 2 ? 256 : 512;
   using ES = EncSpec<PD, PF, DD, DF>;
   constexpr int RT = W / 32, KS = W / 16, KS0 = ES::k0 / 16;
   constexpr int NB = KS0 > KS ? KS0 : KS;
@@ -226,20 +229,20 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
   };
 
   // prologue: layer 0 of the first tile
-  stage<L0_BYTES>(a.packed, smem, tid);
+  stage<L0_BYTES, THREADS>(a.packed, smem, tid);
   int q = 0;  // global stage counter: buffer = q & 1
 
   // Inputs are fetched ONE TILE AHEAD: the loads for tile t+1 are issued right after tile t's
   // encoding and have the whole layer stack of tile t to land (the first barrier drains them).
-  float xin[2][5];
-  bool valid_n[2];
-  long samp_n[2];
-  float d0_n[2], dr_n[2];  // OUT_MODE 2: step of sample 0 / of the other samples of the segment
+  float xin[CT][5];
+  bool valid_n[CT];
+  long samp_n[CT];
+  float d0_n[CT], dr_n[CT];  // OUT_MODE 2: step of sample 0 / of the other samples of the segment
   auto load_inputs = [&](long tile) {
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
+    for (int ct = 0; ct < CT; ++ct) {
       if (IN_MODE == 1) {
-        const long seg = tile * 8 + wave * 2 + ct;
+        const long seg = tile * 8 + wave * CT + ct;
         valid_n[ct] = seg < total_seg;
         samp_n[ct] = seg * 32 + col;
         const long sg = valid_n[ct] ? seg : 0;
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
           }
         }
       } else {
-        samp_n[ct] = tile * kTileSamples + wave * 64 + ct * 32 + col;
+        samp_n[ct] = tile * kTileSamples + wave * (32 * CT) + ct * 32 + col;
         valid_n[ct] = samp_n[ct] < a.n;
         const long sidx = valid_n[ct] ? samp_n[ct] : 0;
 #pragma unroll
@@ -276,13 +279,13 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
 
   for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     // ---- this wave's two column tiles -> first-layer B fragments ----
-    half8 bf[NB][2];
-    bool valid[2];
-    long samp[2];
-    float d0[2], dr[2];
+    half8 bf[NB][CT];
+    bool valid[CT];
+    long samp[CT];
+    float d0[CT], dr[CT];
     const float phase = 0.25f * (float)h;
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
+    for (int ct = 0; ct < CT; ++ct) {
       valid[ct] = valid_n[ct];
       samp[ct] = samp_n[ct];
       d0[ct] = d0_n[ct];
@@ -299,28 +302,28 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs a) {
     if (tile + gridDim.x < n_tiles) load_inputs(tile + gridDim.x);
 
     // ---- layers ----  (two fragment sets used ping-pong: no register copies between layers)
-    half8 bg[NB][2];
+    half8 bg[NB][CT];
     // barrier + prefetch of the following stage; returns the LDS buffer holding layer l
     auto begin_stage = [&](int l) -> const uint8_t* {
       const uint8_t* cur = smem + (q & 1) * BUF;
       uint8_t* nxt = smem + ((q + 1) & 1) * BUF;
       __syncthreads();  // stage q landed (hipcc drains vmcnt before the barrier); buffer nxt is free
       if (l + 1 < n_layers) {
-        if (l + 1 == n_layers - 1) stage<OUT_BYTES>(a.packed + layer_off(l + 1), nxt, tid);
-        else stage<HID_BYTES>(a.packed + layer_off(l + 1), nxt, tid);
+        if (l + 1 == n_layers - 1) stage<OUT_BYTES, THREADS>(a.packed + layer_off(l + 1), nxt, tid);
+        else stage<HID_BYTES, THREADS>(a.packed + layer_off(l + 1), nxt, tid);
       } else if (tile + gridDim.x < n_tiles) {
-        stage<L0_BYTES>(a.packed, nxt, tid);
+        stage<L0_BYTES, THREADS>(a.packed, nxt, tid);
       }
       ++q;
       return cur;
     };
-    auto finish = [&](const half8 (&in)[NB][2]) {
+    auto finish = [&](const half8 (&in)[NB][CT]) {
       const uint8_t* w = begin_stage(n_layers - 1);
-      floatx16 acc[2];
+      floatx16 acc[CT];
       out_mma<KS, NB>(w, in, acc, lane);
       // rows 4h..4h+3 are regs 0..3, rows 8+4h..8+4h+3 are regs 4..7 of this lane
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
+      for (int ct = 0; ct < CT; ++ct) {
         float y[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -577,22 +580,22 @@ struct Variant {
   int blocks_per_cu;  // persistent grid = CUs x this
 };
 
-template <int W, int PD, int PF, int DD, int DF>
+template <int W, int PD, int PF, int DD, int DF, int CT = 2>
 Variant make_variant() {
   using ES = EncSpec<PD, PF, DD, DF>;
   constexpr int RT = W / 32, KS = W / 16, KS0 = ES::k0 / 16;
   constexpr int L0 = KS0 * RT * 1024, HID = KS * RT * 1024;
   Variant v;
   v.W = W; v.PD = PD; v.PF = PF; v.DD = DD; v.DF = DF;
-  v.fn[0][0] = mlp_fwd_kernel<W, PD, PF, DD, DF, 0, 0>;
-  v.fn[0][1] = mlp_fwd_kernel<W, PD, PF, DD, DF, 0, 1>;
-  v.fn[1][0] = mlp_fwd_kernel<W, PD, PF, DD, DF, 1, 0>;
-  v.fn[1][1] = mlp_fwd_kernel<W, PD, PF, DD, DF, 1, 1>;
+  v.fn[0][0] = mlp_fwd_kernel<W, PD, PF, DD, DF, 0, 0, CT>;
+  v.fn[0][1] = mlp_fwd_kernel<W, PD, PF, DD, DF, 0, 1, CT>;
+  v.fn[1][0] = mlp_fwd_kernel<W, PD, PF, DD, DF, 1, 0, CT>;
+  v.fn[1][1] = mlp_fwd_kernel<W, PD, PF, DD, DF, 1, 1, CT>;
   v.fn[0][2] = nullptr;
-  v.fn[1][2] = mlp_fwd_kernel<W, PD, PF, DD, DF, 1, 2>;
+  v.fn[1][2] = mlp_fwd_kernel<W, PD, PF, DD, DF, 1, 2, CT>;
   v.k0 = ES::k0;
   v.lds = 2 * (size_t)(L0 > HID ? L0 : HID);
-  v.threads = kThreads;
+  v.threads = CT == 2 ? 256 : 512;
   v.blocks_per_cu = 2;
   return v;
 }

@@ -29,19 +29,20 @@ namespace rtxn {
 
 // Stage BYTES of lane-linear A fragments from global memory into LDS with LDS-DMA
 // (global_load_lds, 16 B per lane).  All 256 threads of the block call it.
-template <int BYTES>
+template <int BYTES, int THREADS = 256>
 __device__ __forceinline__ void stage(const uint8_t* __restrict__ g, uint8_t* lds_buf, int tid) {
   static_assert(BYTES % 1024 == 0, "layer bytes must be whole 1-KiB fragments");
+  constexpr int ROUND = THREADS * 16;  // bytes per round: one 1-KiB fragment per wave
 #pragma unroll
-  for (int i = 0; i < BYTES / 4096; ++i) {
-    const uint8_t* src = g + i * 4096 + tid * 16;
-    uint8_t* dst = lds_buf + i * 4096 + (tid & ~63) * 16;  // wave-uniform base; HW adds lane*16
+  for (int i = 0; i < BYTES / ROUND; ++i) {
+    const uint8_t* src = g + i * ROUND + tid * 16;
+    uint8_t* dst = lds_buf + i * ROUND + (tid & ~63) * 16;  // wave-uniform base; HW adds lane*16
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   }
-  constexpr int TAIL = (BYTES % 4096) / 1024;  // whole fragments left: one wave each
+  constexpr int TAIL = (BYTES % ROUND) / 1024;  // whole fragments left: one wave each
   if (TAIL > 0 && (tid >> 6) < TAIL) {
-    const int off = (BYTES / 4096) * 4096;
+    const int off = (BYTES / ROUND) * ROUND;
     const uint8_t* src = g + off + tid * 16;
     uint8_t* dst = lds_buf + off + (tid & ~63) * 16;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -159,42 +160,42 @@ __device__ __forceinline__ void layer_mma(const uint8_t* lds_buf, const half8 (&
 // One layer: out rows [32*rt, 32*rt+32) for rt < RT, K = 16*KS, for the wave's two column
 // tiles.  Row-tile-outer: an accumulator is live for one row tile only, and its ReLU/convert
 // (VALU) overlaps the next row tile's MFMAs.  A fragments: chunk (rt, kk) at ((rt*KS+kk)*64+lane)*16.
-template <int RT, int KS, int NB>
-__device__ __forceinline__ void layer_mma(const uint8_t* lds_buf, const half8 (&bf)[NB][2], half8 (&nbf)[NB][2],
+template <int RT, int KS, int NB, int CT>
+__device__ __forceinline__ void layer_mma(const uint8_t* lds_buf, const half8 (&bf)[NB][CT], half8 (&nbf)[NB][CT],
                                           int lane) {
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
-    floatx16 acc[2];
+    floatx16 acc[CT];
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+    for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[ct][e] = 0.0f;
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
       const half8 a = *reinterpret_cast<const half8*>(lds_buf + ((rt * KS + kk) * 64 + lane) * 16);
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[kk][ct], acc[ct], 0, 0, 0);
+      for (int ct = 0; ct < CT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[kk][ct], acc[ct], 0, 0, 0);
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) nbf[2 * rt + s][ct] = relu_pack(acc[ct], s);
+      for (int ct = 0; ct < CT; ++ct) nbf[2 * rt + s][ct] = relu_pack(acc[ct], s);
   }
 }
 #endif
 
 // Output layer: 32 rows (16 real), raw accumulators returned.
-template <int KS, int NB>
-__device__ __forceinline__ void out_mma(const uint8_t* lds_buf, const half8 (&bf)[NB][2], floatx16 (&acc)[2], int lane) {
+template <int KS, int NB, int CT>
+__device__ __forceinline__ void out_mma(const uint8_t* lds_buf, const half8 (&bf)[NB][CT], floatx16 (&acc)[CT], int lane) {
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct)
+  for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[ct][e] = 0.0f;
 #pragma unroll
   for (int kk = 0; kk < KS; ++kk) {
     const half8 a = *reinterpret_cast<const half8*>(lds_buf + (kk * 64 + lane) * 16);
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[kk][ct], acc[ct], 0, 0, 0);
+    for (int ct = 0; ct < CT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[kk][ct], acc[ct], 0, 0, 0);
   }
 }
 
