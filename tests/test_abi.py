@@ -87,3 +87,14 @@ def test_initialize_params_is_seeded_xavier():
     lim0 = (6.0 / (64 + 112)) ** 0.5
     assert np.abs(a[:64 * 112]).max() <= lim0 and np.abs(a[:64 * 112]).max() > 0.95 * lim0
     assert abs(a.mean()) < 5e-3
+
+
+def test_header_is_plain_c99(tmp_path):
+    """The boundary is a C ABI: include/rtxn.h must compile as C99 with no C++ or torch types."""
+    import subprocess
+    src = tmp_path / "c99.c"
+    src.write_text('#include "rtxn.h"\nint main(void) { rtxn_trace_params p; rtxn_mlp_config c; rtxn_hashgrid_config h; '
+                   'rtxn_image_dataset d; (void)p; (void)c; (void)h; (void)d; return RTXN_VERSION == 100 ? 0 : 1; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", f"-I{ROOT}/include", "-fsyntax-only", str(src)])
+    text = open(os.path.join(ROOT, "include", "rtxn.h")).read()
+    assert "torch" not in text and "at::" not in text and "std::" not in text
