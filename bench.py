@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--neurons", type=int, default=128)
     ap.add_argument("--layers", type=int, default=8)
     ap.add_argument("--poses", type=int, default=4)
+    ap.add_argument("--scene", default="lego", choices=["lego", "llff"], help="lego: hemisphere poses around the Lego stand-in (configs[1]); "
+                    "llff: forward-facing frustum over a sparse fern-like grid (configs[4], with --grid 256 --neurons 256)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--fused", action="store_true", help="per-segment compositing in the MLP epilogue (measured slower: frame is MFMA-bound)")
@@ -93,14 +95,18 @@ def main():
     from rtx_nerf_amd.shard import RowShard
 
     W, H, R = args.width, args.height, args.grid
-    dense = scenes.lego_standin_density(R, seed=0)
+    dense = scenes.lego_standin_density(R, seed=0) if args.scene == "lego" else scenes.llff_standin_density(R, seed=3)
     words = scenes.pack_occupancy(dense)
     occ = torch.from_numpy(words.view(np.int32).copy()).cuda()
     net = api.Network(n_neurons=args.neurons, n_hidden_layers=args.layers)
     params = scenes.xavier_params_fp16(args.neurons, args.layers, net.encoded_width(), seed=1337)
     net.set_params(torch.from_numpy(params).cuda())
-    focal = scenes.lego_focal_length(True)
-    poses = [scenes.pose_spherical(360.0 * i / args.poses + 15.0, -30.0, origin_scale=10.0) for i in range(args.poses)]
+    if args.scene == "lego":
+        focal = scenes.lego_focal_length(True)
+        poses = [scenes.pose_spherical(360.0 * i / args.poses + 15.0, -30.0, origin_scale=10.0) for i in range(args.poses)]
+    else:
+        focal = 1.6
+        poses = [scenes.pose_forward_facing(0.3 * np.cos(i), 0.2 * np.sin(i)) for i in range(args.poses)]
 
     # ray shard of this rank: image rows rank, rank+world, ... (rtx_nerf_amd/shard.py)
     sh = RowShard(W, H, rank, world)
@@ -191,7 +197,7 @@ def main():
         "dtype": "f16",
         "data": "synthetic",
         "config": {
-            "workload": f"{W}x{H} inference render, {R}^3 grid (procedural Lego stand-in occupancy, "
+            "workload": f"{W}x{H} inference render, {R}^3 grid (procedural {'Lego' if args.scene == 'lego' else 'LLFF-fern'} stand-in occupancy, "
                         f"{100.0 * dense.mean():.1f}% cells), {args.layers}x{args.neurons} ReLU MLP + Composite-Frequency "
                         f"encoding, 32 samples/segment, {args.poses} hemisphere poses, seeded random fp16 weights",
             "rays_per_step": rays_per_step,

@@ -114,6 +114,10 @@ typedef struct rtxn_trace_params {
   float* seg_view;           /* float2 per slot: (theta, phi) of the segment's ray (packed layout; new) */
   long segment_capacity;     /* packed layout: slots >= capacity are not written (0 = unbounded) */
   uint8_t* seg_first;        /* byte per slot: 1 if the segment is the first of its ray (packed layout; new) */
+  const uint64_t* occupancy_bricks; /* (R/4)^3 words from rtxn_build_occupancy_bricks, or NULL: the 64 fine bits of each 4^3 block
+                                     * (RTXN_TRACE_DDA + occupancy_coarse only; same segments, one load per block instead of per cell) */
+  const uint32_t* occupancy_super;  /* (R/16)^3 bits = rtxn_build_occupancy_mip(occupancy_coarse, R/4, .), or NULL: third level of the
+                                     * empty-space hierarchy (needs occupancy_coarse, R % 16 == 0) */
   int* num_stored;           /* int[ray_count] or NULL: segments actually WRITTEN for the ray (< num_hits when
                               * intersection_arr_size / segment_capacity cut it off): the count downstream stages may read */
 } rtxn_trace_params;
@@ -127,6 +131,10 @@ int rtxn_trace_grid(const rtxn_trace_params* p, rtxn_stream_t stream);
  * (R/4)^3 grid = OR over its 4^3 fine cells.  R must be a multiple of 4.
  * coarse: (R/4)^3 bits rounded up to whole uint32 words. */
 int rtxn_build_occupancy_mip(const uint32_t* occupancy, int grid_res, uint32_t* coarse, rtxn_stream_t stream);
+
+/* Brick copy of the occupancy for RTXN_TRACE_DDA: bricks[(X*Rc+Y)*Rc+Z] (Rc = R/4) holds the 64 fine bits of block
+ * (X,Y,Z), bit ((x&3)<<4 | (y&3)<<2 | (z&3)). */
+int rtxn_build_occupancy_bricks(const uint32_t* occupancy, int grid_res, uint64_t* bricks, rtxn_stream_t stream);
 
 /* Occupancy maintenance (the reference only builds the dense grid once,
  * main.cu:393-399): occupancy bit of cell i = density[i] > threshold, i = (x*R+y)*R+z.

@@ -53,6 +53,8 @@ class TraceParams(C.Structure):
         ("seg_view", C.c_void_p),
         ("segment_capacity", C.c_long),
         ("seg_first", C.c_void_p),
+        ("occupancy_bricks", C.c_void_p),
+        ("occupancy_super", C.c_void_p),
         ("num_stored", C.c_void_p),
     ]
 
@@ -85,6 +87,7 @@ SYMBOLS = {
     "rtxn_trace_grid": (_I, [C.POINTER(TraceParams), _P]),
     "rtxn_build_occupancy_mip": (_I, [_P, _I, _P, _P]),
     "rtxn_occupancy_from_density": (_I, [_P, _F, _I, _P, _P]),
+    "rtxn_build_occupancy_bricks": (_I, [_P, _I, _P, _P]),
     "rtxn_scan_workspace_bytes": (C.c_size_t, [_I]),
     "rtxn_scan_hits": (_I, [_P, _P, _P, _I, _P, C.c_size_t, _P]),
     "rtxn_sample": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _P]),

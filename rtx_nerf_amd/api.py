@@ -43,7 +43,7 @@ def _ptr(t, dtype=None, name="tensor"):
 # --------------------------------------------------------------------------- traversal
 def trace_grid(look_at=None, focal_length=1.0, aspect_ratio=1.0, width=0, height=0, *, grid_res,
                rays_o=None, rays_d=None, ray_begin=0, ray_count=None, occupancy=None,
-               occupancy_coarse=None, mode=TRACE_COMPAT, ray_origins=None, viewing_direction=None,
+               occupancy_coarse=None, occupancy_bricks=None, occupancy_super=None, mode=TRACE_COMPAT, ray_origins=None, viewing_direction=None,
                num_hits=None, intersection_arr_size=0, indices=None, start_points=None,
                end_points=None, t_start=None, t_end=None, seg_ray=None, seg_view=None, seg_first=None, num_stored=None, segment_capacity=0,
                window_chunk=0, window_stride=0):
@@ -61,6 +61,8 @@ def trace_grid(look_at=None, focal_length=1.0, aspect_ratio=1.0, width=0, height
     p.grid_res = grid_res
     p.occupancy = _ptr(occupancy, torch.int32, "occupancy")
     p.occupancy_coarse = _ptr(occupancy_coarse, torch.int32, "occupancy_coarse")
+    p.occupancy_bricks = _ptr(occupancy_bricks, torch.int64, "occupancy_bricks")
+    p.occupancy_super = _ptr(occupancy_super, torch.int32, "occupancy_super")
     p.mode = mode
     p.ray_origins = _ptr(ray_origins, torch.float32, "ray_origins")
     p.viewing_direction = _ptr(viewing_direction, torch.float32, "viewing_direction")
@@ -87,6 +89,14 @@ def build_occupancy_mip(occupancy, grid_res):
     check(_lib.lib().rtxn_build_occupancy_mip(_ptr(occupancy, torch.int32), grid_res, _ptr(coarse), _stream()),
           "rtxn_build_occupancy_mip")
     return coarse
+
+
+def build_occupancy_bricks(occupancy, grid_res):
+    rc = grid_res // 4
+    bricks = torch.empty(rc ** 3, dtype=torch.int64, device=occupancy.device)
+    check(_lib.lib().rtxn_build_occupancy_bricks(_ptr(occupancy, torch.int32), grid_res, _ptr(bricks), _stream()),
+          "rtxn_build_occupancy_bricks")
+    return bricks
 
 
 def occupancy_from_density(density, threshold, grid_res):

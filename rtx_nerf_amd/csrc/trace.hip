@@ -183,7 +183,8 @@ __device__ __forceinline__ float plane_t(int i, float L, float o, float inv) { r
 // while its exit plane's t is <= the block's exit t, which is exactly the state
 // the flat walk reaches (plane_t depends only on the cell index).
 __device__ void march_dda(const float (&o)[3], const float (&d)[3], int R, const uint32_t* __restrict__ occ,
-                          const uint32_t* coarse, Sink& s) {
+                          const uint32_t* coarse, const uint32_t* super, const unsigned long long* __restrict__ bricks,
+                          Sink& s) {
   const float L = 2.0f / (float)R;
   int c[3];
   float t_in;
@@ -197,23 +198,52 @@ __device__ void march_dda(const float (&o)[3], const float (&d)[3], int R, const
     up[a] = d[a] < 0 ? 0 : 1;
   }
   const int Rc = R >> 2;
+  // brick cache: the 64 fine bits of the occupied 4^3 block the walk is currently in (one 8-byte load per block
+  // instead of one dependent 4-byte load per fine cell)
+  uint32_t brick_id = 0xffffffffu;
+  unsigned long long brick = 0;
   for (int guard = 0; guard < 3 * R + 8; ++guard) {
     bool out = false;
     if (coarse) {
-      const uint32_t ci = ((uint32_t)(c[0] >> 2) * Rc + (uint32_t)(c[1] >> 2)) * Rc + (uint32_t)(c[2] >> 2);
-      if (!((coarse[ci >> 5] >> (ci & 31)) & 1u)) {
+      // empty-space skipping, coarsest level first: a 16^3 (super) or 4^3 (coarse) block without occupied cells is
+      // crossed in one step -- every axis advances while its exit plane's t <= the block's exit t, which is exactly
+      // the state the flat walk reaches (plane_t depends only on the integer cell index)
+      int shift = 0;
+      if (super) {
+        const int Rs = R >> 4;
+        const uint32_t si = ((uint32_t)(c[0] >> 4) * Rs + (uint32_t)(c[1] >> 4)) * Rs + (uint32_t)(c[2] >> 4);
+        if (!((super[si >> 5] >> (si & 31)) & 1u)) shift = 4;
+      }
+      if (!shift) {
+        const uint32_t ci = ((uint32_t)(c[0] >> 2) * Rc + (uint32_t)(c[1] >> 2)) * Rc + (uint32_t)(c[2] >> 2);
+        const bool block_on = (coarse[ci >> 5] >> (ci & 31)) & 1u;
+        if (block_on && bricks && ci != brick_id) {
+          brick_id = ci;
+          brick = bricks[ci];
+        }
+        if (!block_on) shift = 2;
+      }
+      if (shift) {
         float tc = INFINITY;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-          if (d[a] != 0.0f) tc = fminf(tc, plane_t(((c[a] >> 2) + up[a]) << 2, L, o[a], inv[a]));
+          if (d[a] != 0.0f) tc = fminf(tc, plane_t(((c[a] >> shift) + up[a]) << shift, L, o[a], inv[a]));
         }
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
           if (d[a] != 0.0f) {
-            while (plane_t(c[a] + up[a], L, o[a], inv[a]) <= tc) {
-              c[a] += step[a];
-              if (c[a] < 0 || c[a] >= R) { out = true; break; }
+            // land directly in the cell the flat walk would be in at tc: estimate it from the position, then fix the
+            // estimate with the walk's own exact comparisons (exit plane of cell i is plane i + up; crossed iff <= tc)
+            const int c0 = c[a];
+            int est = (int)floorf((fmaf(tc, d[a], o[a]) + 1.0f) / L);
+            est = step[a] > 0 ? max(est, c0) : min(est, c0);
+            est = min(max(est, 0), R - 1);
+            while (est != c0 && plane_t(est - step[a] + up[a], L, o[a], inv[a]) > tc) est -= step[a];
+            while (plane_t(est + up[a], L, o[a], inv[a]) <= tc) {
+              est += step[a];
+              if (est < 0 || est >= R) { out = true; break; }
             }
+            c[a] = est;
           }
         }
         if (out) break;
@@ -225,7 +255,10 @@ __device__ void march_dda(const float (&o)[3], const float (&d)[3], int R, const
 #pragma unroll
     for (int a = 0; a < 3; ++a) te[a] = d[a] == 0.0f ? INFINITY : plane_t(c[a] + up[a], L, o[a], inv[a]);
     const float t_out = fminf(fminf(te[0], te[1]), te[2]);
-    if (t_out > t_in && occ_test(occ, R, c[0], c[1], c[2])) {
+    bool on;
+    if (coarse && bricks) on = (brick >> (((c[0] & 3) << 4) | ((c[1] & 3) << 2) | (c[2] & 3))) & 1ull;
+    else on = occ_test(occ, R, c[0], c[1], c[2]);
+    if (t_out > t_in && on) {
       float p0[3], p1[3];
 #pragma unroll
       for (int a = 0; a < 3; ++a) { p0[a] = fmaf(t_in, d[a], o[a]); p1[a] = fmaf(t_out, d[a], o[a]); }
@@ -244,21 +277,27 @@ __device__ void march_dda(const float (&o)[3], const float (&d)[3], int R, const
 }
 
 constexpr int kCoarseLdsWords = 8192;  // 32 KiB: coarse mip of up to 256^3 (64^3 bits)
+constexpr int kSuperLdsWords = 512;    // 2 KiB: super mip (16^3-cell blocks) of up to 400^3
 
 template <int MODE>
 __global__ __launch_bounds__(256) void trace_kernel(rtxn_trace_params p) {
   __shared__ uint32_t coarse_lds[MODE == RTXN_TRACE_DDA ? kCoarseLdsWords : 1];
+  __shared__ uint32_t super_lds[MODE == RTXN_TRACE_DDA ? kSuperLdsWords : 1];
   const uint32_t* coarse = nullptr;
+  const uint32_t* super = nullptr;
   if (MODE == RTXN_TRACE_DDA && p.occupancy_coarse) {
     const int Rc = p.grid_res >> 2;
     const int words = (Rc * Rc * Rc + 31) >> 5;
-    if (words <= kCoarseLdsWords) {
+    const int Rs = p.grid_res >> 4;
+    const int swords = p.occupancy_super ? (Rs * Rs * Rs + 31) >> 5 : 0;
+    const bool c_lds = words <= kCoarseLdsWords, s_lds = swords > 0 && swords <= kSuperLdsWords;
+    if (c_lds)
       for (int i = threadIdx.x; i < words; i += blockDim.x) coarse_lds[i] = p.occupancy_coarse[i];
-      __syncthreads();
-      coarse = coarse_lds;
-    } else {
-      coarse = p.occupancy_coarse;
-    }
+    if (s_lds)
+      for (int i = threadIdx.x; i < swords; i += blockDim.x) super_lds[i] = p.occupancy_super[i];
+    if (c_lds || s_lds) __syncthreads();
+    coarse = c_lds ? coarse_lds : p.occupancy_coarse;
+    if (swords) super = s_lds ? super_lds : p.occupancy_super;
   }
   // 16x16 pixel tiles per block keep a block's rays on neighbouring cells (shared
   // occupancy words); a ray window that is not tile-aligned falls back to linear order.
@@ -284,7 +323,7 @@ __global__ __launch_bounds__(256) void trace_kernel(rtxn_trace_params p) {
   else { s.base = (long)r * p.intersection_arr_size; s.limit = s.base + p.intersection_arr_size; }
   if (!p.start_points && !p.end_points && !p.t_start && !p.t_end && !p.seg_ray && !p.seg_view && !p.seg_first) s.limit = 0;
   if (MODE == RTXN_TRACE_COMPAT) march_compat(o, d, p.grid_res, p.occupancy, s);
-  else march_dda(o, d, p.grid_res, p.occupancy, coarse, s);
+  else march_dda(o, d, p.grid_res, p.occupancy, coarse, super, reinterpret_cast<const unsigned long long*>(p.occupancy_bricks), s);
   p.num_hits[r] = s.n;
   if (p.num_stored) {
     const long room = s.limit - s.base;
@@ -315,6 +354,23 @@ __global__ void mip_kernel(const uint32_t* __restrict__ occ, int R, uint32_t* __
   coarse[w] = word;
 }
 
+// one thread per 4^3 block: its 64 fine bits, bit ((x&3)<<4 | (y&3)<<2 | (z&3)), gathered from 16 four-bit z-runs
+__global__ void brick_kernel(const uint32_t* __restrict__ occ, int R, unsigned long long* __restrict__ bricks) {
+  const int Rc = R >> 2;
+  const int ci = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ci >= Rc * Rc * Rc) return;
+  const int Z = ci % Rc, Y = (ci / Rc) % Rc, X = ci / (Rc * Rc);
+  unsigned long long m = 0;
+  for (int dx = 0; dx < 4; ++dx)
+    for (int dy = 0; dy < 4; ++dy) {
+      const uint32_t idx = ((uint32_t)(4 * X + dx) * R + (uint32_t)(4 * Y + dy)) * R + (uint32_t)(4 * Z);
+      const unsigned long long run = (occ[idx >> 5] >> (idx & 31)) & 0xfu;   // z = 4Z..4Z+3, bit z&3
+      // run bit k is cell z = 4Z+k -> brick bit (dx<<4 | dy<<2 | k)
+      m |= run << ((dx << 4) | (dy << 2));
+    }
+  bricks[ci] = m;
+}
+
 // density[R^3] (index (x*R+y)*R+z) -> occupancy bits: one wave ballot = two 32-bit words
 __global__ __launch_bounds__(256) void occupancy_kernel(const float* __restrict__ density, float threshold, long n,
                                                         uint32_t* __restrict__ bits) {
@@ -327,6 +383,19 @@ __global__ __launch_bounds__(256) void occupancy_kernel(const float* __restrict_
 }
 
 }  // namespace
+
+extern "C" int rtxn_build_occupancy_bricks(const uint32_t* occupancy, int grid_res, uint64_t* bricks, rtxn_stream_t stream) {
+  RTXN_REQUIRE(occupancy && bricks, "rtxn_build_occupancy_bricks: NULL buffer");
+  RTXN_REQUIRE(grid_res >= 4 && grid_res % 4 == 0 && grid_res <= 1024,
+               "rtxn_build_occupancy_bricks: grid_res = %d must be a multiple of 4 in [4,1024]", grid_res);
+  RTXN_DEVICE_OR_FAIL();
+  const int Rc = grid_res / 4;
+  const int n = Rc * Rc * Rc;
+  brick_kernel<<<(n + 255) / 256, 256, 0, rtxn::as_stream(stream)>>>(occupancy, grid_res,
+                                                                      reinterpret_cast<unsigned long long*>(bricks));
+  RTXN_LAUNCH_CHECK("brick_kernel");
+  return RTXN_OK;
+}
 
 extern "C" int rtxn_occupancy_from_density(const float* density, float threshold, int grid_res, uint32_t* occupancy,
                                            rtxn_stream_t stream) {
@@ -356,6 +425,9 @@ extern "C" int rtxn_trace_grid(const rtxn_trace_params* p, rtxn_stream_t stream)
   }
   RTXN_REQUIRE(!p->occupancy_coarse || (p->occupancy && p->grid_res % 4 == 0),
                "rtxn_trace_grid: occupancy_coarse needs occupancy and grid_res %% 4 == 0");
+  RTXN_REQUIRE(!p->occupancy_bricks || p->occupancy_coarse, "rtxn_trace_grid: occupancy_bricks needs occupancy_coarse");
+  RTXN_REQUIRE(!p->occupancy_super || (p->occupancy_coarse && p->grid_res % 16 == 0),
+               "rtxn_trace_grid: occupancy_super needs occupancy_coarse and grid_res %% 16 == 0");
   const bool wants_segments = p->start_points || p->end_points || p->t_start || p->t_end || p->seg_ray || p->seg_view || p->seg_first;
   RTXN_REQUIRE(!wants_segments || p->indices || p->intersection_arr_size > 0,
                "rtxn_trace_grid: segment outputs need indices (packed) or intersection_arr_size > 0 (strided)");

@@ -37,9 +37,12 @@ class RenderPipeline:
         self.fused, self.step_scale = fused, step_scale
         self.dev = torch.device(device)
         self.occ = occupancy
-        self.coarse = None
+        self.coarse = self.bricks = self.super_mip = None
         if occupancy is not None and trace_mode == api.TRACE_DDA and grid_res % 4 == 0:
             self.coarse = api.build_occupancy_mip(occupancy, grid_res)
+            self.bricks = api.build_occupancy_bricks(occupancy, grid_res)
+            if grid_res % 16 == 0:
+                self.super_mip = api.build_occupancy_mip(self.coarse, grid_res // 4)
         n = width * height if max_rays is None else max_rays
         self.max_rays = n
         # default capacity: every ray crossing a full grid diagonal's worth of occupied cells is far too
@@ -77,7 +80,8 @@ class RenderPipeline:
 
     def _trace(self, ray_begin, ray_count, write):
         kw = dict(grid_res=self.R, ray_begin=ray_begin, ray_count=ray_count, occupancy=self.occ,
-                  occupancy_coarse=self.coarse, mode=self.trace_mode, viewing_direction=self.view_dirs,
+                  occupancy_coarse=self.coarse, occupancy_bricks=self.bricks, occupancy_super=self.super_mip, mode=self.trace_mode,
+                  viewing_direction=self.view_dirs,
                   num_hits=self.num_hits, window_chunk=self.window[0], window_stride=self.window[1])
         if write:
             kw.update(indices=self.indices, start_points=self.start, end_points=self.end, seg_view=self.seg_view,

@@ -37,6 +37,8 @@ class Trainer:
         self.dev = torch.device(device)
         self.occ = occupancy
         self.coarse = api.build_occupancy_mip(occupancy, grid_res) if (occupancy is not None and grid_res % 4 == 0) else None
+        self.bricks = api.build_occupancy_bricks(occupancy, grid_res) if self.coarse is not None else None
+        self.super_mip = api.build_occupancy_mip(self.coarse, grid_res // 4) if (self.coarse is not None and grid_res % 16 == 0) else None
         self.B = batch_rays
         self.mode = mode
         self.lr, self.loss_scale, self.density_scale = lr, loss_scale, density_scale
@@ -92,7 +94,7 @@ class Trainer:
     # ------------------------------------------------------------------------------------------
     def _segments(self, rays_o, rays_d, n):
         kw = dict(grid_res=self.R, rays_o=rays_o, rays_d=rays_d, width=n, height=1, ray_begin=0, ray_count=n,
-                  occupancy=self.occ, occupancy_coarse=self.coarse, mode=api.TRACE_DDA,
+                  occupancy=self.occ, occupancy_coarse=self.coarse, occupancy_bricks=self.bricks, occupancy_super=self.super_mip, mode=api.TRACE_DDA,
                   viewing_direction=self.view_dirs, num_hits=self.num_hits)
         api.trace_grid(None, **kw)
         api.scan_hits(self.num_hits[:n], self.indices[:n], self.total, self.scan_ws)
@@ -246,6 +248,8 @@ class Trainer:
         thick = sigma * (self.density_scale * 2.0 / R)
         self.occ = api.occupancy_from_density(thick, threshold, R)
         self.coarse = api.build_occupancy_mip(self.occ, R) if R % 4 == 0 else None
+        self.bricks = api.build_occupancy_bricks(self.occ, R) if R % 4 == 0 else None
+        self.super_mip = api.build_occupancy_mip(self.coarse, R // 4) if R % 16 == 0 else None
         return float((thick > threshold).float().mean().item())
 
 

@@ -43,7 +43,7 @@ def test_scan_hits(gpu, oracle, n):
 
 # ------------------------------------------------------------------ traversal
 def _trace_gpu(torch, api, *, R, mode, look_at=None, f=1.0, W=0, H=0, rays_o=None, rays_d=None, occ=None,
-               coarse=None, ray_begin=0, ray_count=None, S=None):
+               coarse=None, ray_begin=0, ray_count=None, S=None, bricks=None):
     n_all = W * H if look_at is not None else rays_o.shape[0]
     n = n_all - ray_begin if ray_count is None else ray_count
     S = 3 * R if S is None else S
@@ -55,7 +55,7 @@ def _trace_gpu(torch, api, *, R, mode, look_at=None, f=1.0, W=0, H=0, rays_o=Non
     api.trace_grid(None if look_at is None else _dev(torch, look_at.reshape(16)), f, 1.0, W, H, grid_res=R,
                    rays_o=None if rays_o is None else _dev(torch, rays_o),
                    rays_d=None if rays_d is None else _dev(torch, rays_d),
-                   ray_begin=ray_begin, ray_count=n, occupancy=occ, occupancy_coarse=coarse, mode=mode,
+                   ray_begin=ray_begin, ray_count=n, occupancy=occ, occupancy_coarse=coarse, occupancy_bricks=bricks, mode=mode,
                    ray_origins=out["origins"], viewing_direction=out["view_dirs"], num_hits=out["num_hits"],
                    intersection_arr_size=S, start_points=out["start"], end_points=out["end"],
                    t_start=out["t_start"], t_end=out["t_end"])
@@ -124,9 +124,15 @@ def test_trace_occupancy_and_hierarchical_skip(gpu, oracle, R, use_coarse):
     words = scenes.pack_occupancy(dense)
     occ = _occ_dev(torch, words)
     coarse = api.build_occupancy_mip(occ, R) if use_coarse else None
+    bricks = None
     if use_coarse:
         want_c = scenes.pack_occupancy(scenes.coarse_occupancy(dense))
         np.testing.assert_array_equal(coarse.cpu().numpy().view(np.uint32), want_c)
+        bricks = api.build_occupancy_bricks(occ, R)
+        rc = R // 4
+        b = dense.reshape(rc, 4, rc, 4, rc, 4).transpose(0, 2, 4, 1, 3, 5).reshape(rc ** 3, 64)   # [block][x&3, y&3, z&3]
+        want_b = (b.astype(np.uint64) << np.arange(64, dtype=np.uint64)).sum(axis=1, dtype=np.uint64)
+        np.testing.assert_array_equal(bricks.cpu().numpy().view(np.uint64), want_b)
     la = scenes.pose_spherical(50.0, -35.0, origin_scale=10.0)
     f = scenes.lego_focal_length(True)
     for mode in ([1] if use_coarse else [0, 1]):
@@ -134,6 +140,9 @@ def test_trace_occupancy_and_hierarchical_skip(gpu, oracle, R, use_coarse):
         got = _trace_gpu(torch, api, R=R, mode=mode, look_at=la, f=f, W=48, H=40, occ=occ, coarse=coarse, S=R)
         assert 0 < want["num_hits"].sum()
         _assert_trace_equal(got, want)
+        if bricks is not None:
+            got = _trace_gpu(torch, api, R=R, mode=mode, look_at=la, f=f, W=48, H=40, occ=occ, coarse=coarse, S=R, bricks=bricks)
+            _assert_trace_equal(got, want)
 
 
 def test_trace_window_and_packed_two_pass(gpu, oracle):

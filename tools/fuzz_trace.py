@@ -42,6 +42,8 @@ for it in range(a.iters):
     n = W * H
     occ = None if words is None else torch.from_numpy(words.view(np.int32).copy()).cuda()
     coarse = api.build_occupancy_mip(occ, R) if use_coarse else None
+    bricks = api.build_occupancy_bricks(occ, R) if (use_coarse and rng.random() < 0.7) else None
+    sup = api.build_occupancy_mip(coarse, R // 4) if (use_coarse and R % 16 == 0 and rng.random() < 0.8) else None
     nh = torch.zeros(n, dtype=torch.int32, device="cuda")
     vd = torch.zeros((n, 2), device="cuda")
     og = torch.zeros((n, 3), device="cuda")
@@ -49,7 +51,7 @@ for it in range(a.iters):
     ep = torch.full((n * S, 3), -2.0, device="cuda")
     t0 = torch.full((n * S,), -2.0, device="cuda")
     t1 = torch.full((n * S,), -2.0, device="cuda")
-    api.trace_grid(torch.from_numpy(la.reshape(16)).cuda(), f, W / H, W, H, grid_res=R, occupancy=occ, occupancy_coarse=coarse,
+    api.trace_grid(torch.from_numpy(la.reshape(16)).cuda(), f, W / H, W, H, grid_res=R, occupancy=occ, occupancy_coarse=coarse, occupancy_bricks=bricks, occupancy_super=sup,
                    mode=mode, ray_origins=og, viewing_direction=vd, num_hits=nh, intersection_arr_size=S, start_points=sp,
                    end_points=ep, t_start=t0, t_end=t1)
     torch.cuda.synchronize()
