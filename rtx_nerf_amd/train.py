@@ -265,3 +265,42 @@ def camera_rays(look_at, focal, width, height, device="cuda", origin_scale=0.1):
     d = d / d.norm(dim=1, keepdim=True)
     o = (la[:3, 3] * origin_scale).expand_as(d)
     return o.float().contiguous().to(device), d.float().contiguous().to(device)
+
+
+class RayDataset:
+    """Dataset of rays resident on the device: the counterpart of the reference's dataset build (main.cu:463-543: one
+    traversal launch per training image, every buffer copied to the host and four mallocs per ray) and of its
+    std::random_shuffle + host batch gather (:612-629).  Here the rays (origin, direction) and their ground-truth pixels
+    stay in HBM as three flat tensors and a batch is an on-device random gather; traversal happens per batch inside
+    Trainer.step, so nothing per-ray is ever materialised on the host."""
+
+    def __init__(self, rays_o, rays_d, pixels):
+        self.rays_o, self.rays_d, self.pixels = rays_o, rays_d, pixels
+        self.n = rays_o.shape[0]
+
+    @classmethod
+    def from_images(cls, dataset, corrected_focal=True, origin_scale=0.1, device="cuda"):
+        """dataset: rtx_nerf_amd.loader.ImageDataset.  corrected_focal: 1/tan(camera_angle_x/2) in image half-widths
+        instead of the reference's 1/tan(0.5*focal_px) (quirk Q1); origin_scale 0.1 is the reference's origin/10 (Q2)."""
+        import math
+        W, H = dataset.image_width, dataset.image_height
+        if corrected_focal:
+            focal = 1.0 / math.tan(0.5 * dataset.camera_angle_x)
+        else:
+            focal = float(np.float32(1.0) / np.tan(np.float32(0.5) * np.float32(dataset.focal)))
+        ro, rd = [], []
+        for pose in dataset.poses:
+            o, d = camera_rays(pose, focal, W, H, device=device, origin_scale=origin_scale)
+            ro.append(o)
+            rd.append(d)
+        pix = torch.from_numpy(np.ascontiguousarray(dataset.images, dtype=np.float32).reshape(-1, 3)).to(device)
+        return cls(torch.cat(ro), torch.cat(rd), pix), focal
+
+    def sample_batch(self, batch, generator=None):
+        idx = torch.randint(0, self.n, (batch,), device=self.rays_o.device, generator=generator)
+        return self.rays_o[idx].contiguous(), self.rays_d[idx].contiguous(), self.pixels[idx].contiguous()
+
+
+def psnr(pred, target):
+    mse = float(((pred - target) ** 2).mean())
+    return 10.0 * np.log10(1.0 / max(mse, 1e-12))

@@ -79,3 +79,27 @@ def test_rowshard_partition_is_exact():
             assert sh.n_local <= sh.n_max
             seen += [sh.local_to_global(i) for i in range(sh.n_local)]
         assert sorted(seen) == list(range(W * H))
+
+
+def test_ray_dataset_matches_oracle_raygen(oracle):
+    """RayDataset (device-resident counterpart of main.cu:463-543) must hold exactly the rays the traversal's own
+    ray generation would produce for each pose, in pose-major pixel order, with the frames' pixels alongside."""
+    import numpy as np
+    from rtx_nerf_amd import loader, scenes
+    from rtx_nerf_amd.train import RayDataset
+    W, H = 12, 8
+    poses = np.stack([scenes.pose_spherical(40.0 * i, -25.0, origin_scale=10.0) for i in range(3)]).astype(np.float32)
+    imgs = np.random.default_rng(0).random((3, H, W, 3), dtype=np.float32)
+    ds = loader.ImageDataset(imgs, poses, 100.0, W, H, 3, scenes.LEGO_CAMERA_ANGLE_X)
+    rays, focal = RayDataset.from_images(ds, device="cpu")
+    assert rays.n == 3 * W * H
+    for i in range(3):
+        r = oracle.trace(look_at=poses[i], focal=focal, aspect=W / H, W=W, H=H, R=4, mode=1)
+        sl = slice(i * W * H, (i + 1) * W * H)
+        np.testing.assert_allclose(rays.rays_o[sl].numpy(), r["origins"], rtol=0, atol=1e-7)
+        d = rays.rays_d[sl].numpy()
+        theta_phi = np.stack([np.arccos(np.clip(d[:, 2], -1, 1)), np.arctan2(d[:, 1], d[:, 0])], 1)
+        np.testing.assert_allclose(theta_phi, r["view_dirs"], rtol=0, atol=2e-6)
+        np.testing.assert_array_equal(rays.pixels[sl].numpy(), imgs[i].reshape(-1, 3))
+    o, d, p = rays.sample_batch(64)
+    assert o.shape == (64, 3) and d.shape == (64, 3) and p.shape == (64, 3)
