@@ -42,8 +42,7 @@
 
 namespace {
 
-using rtxn::layer_mma;
-using rtxn::out_mma;
+using rtxn::pipe_layer;
 using rtxn::relu_pack;
 using rtxn::stage;
 
@@ -303,6 +302,7 @@ __global__ __launch_bounds__(CT == 2 ? 256 : 512, CT == 2 ? 2 : 4) void mlp_fwd_
 
     // ---- layers ----  (two fragment sets used ping-pong: no register copies between layers)
     half8 bg[NB][CT];
+    floatx16 acc2[2][CT];
     // barrier + prefetch of the following stage; returns the LDS buffer holding layer l
     auto begin_stage = [&](int l) -> const uint8_t* {
       const uint8_t* cur = smem + (q & 1) * BUF;
@@ -317,10 +317,10 @@ __global__ __launch_bounds__(CT == 2 ? 256 : 512, CT == 2 ? 2 : 4) void mlp_fwd_
       ++q;
       return cur;
     };
-    auto finish = [&](const half8 (&in)[NB][CT]) {
+    auto finish = [&](half8 (&in)[NB][CT], half8 (&other)[NB][CT]) {
       const uint8_t* w = begin_stage(n_layers - 1);
-      floatx16 acc[CT];
-      out_mma<KS, NB>(w, in, acc, lane);
+      pipe_layer<0, KS, NB, CT, true>(w, in, other, acc2, lane);
+      floatx16 (&acc)[CT] = acc2[0];
       // rows 4h..4h+3 are regs 0..3, rows 8+4h..8+4h+3 are regs 4..7 of this lane
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
@@ -350,23 +350,24 @@ __global__ __launch_bounds__(CT == 2 ? 256 : 512, CT == 2 ? 2 : 4) void mlp_fwd_
         }
       }
     };
+    // every layer leaves its last row tile pending in acc2[1]; the next one converts it under its first MFMAs
     {
       const uint8_t* w = begin_stage(0);
-      layer_mma<RT, KS0, NB>(w, bf, bg, lane);
+      pipe_layer<RT, KS0, NB, CT, false>(w, bf, bg, acc2, lane);
     }
     int l = 1;
     for (; l + 1 < n_layers - 1; l += 2) {  // activations in bg at the top
       const uint8_t* w = begin_stage(l);
-      layer_mma<RT, KS, NB>(w, bg, bf, lane);
+      pipe_layer<RT, KS, NB, CT, true>(w, bg, bf, acc2, lane);
       w = begin_stage(l + 1);
-      layer_mma<RT, KS, NB>(w, bf, bg, lane);
+      pipe_layer<RT, KS, NB, CT, true>(w, bf, bg, acc2, lane);
     }
     if (l < n_layers - 1) {
       const uint8_t* w = begin_stage(l);
-      layer_mma<RT, KS, NB>(w, bg, bf, lane);
-      finish(bf);
+      pipe_layer<RT, KS, NB, CT, true>(w, bg, bf, acc2, lane);
+      finish(bf, bg);
     } else {
-      finish(bg);
+      finish(bg, bf);
     }
   }
 }

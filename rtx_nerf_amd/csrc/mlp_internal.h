@@ -97,11 +97,29 @@ __host__ __device__ __forceinline__ int perm_feature(int kk, int h, int j) { ret
 // One layer: out rows [32*rt, 32*rt+32) for rt < RT, K = 16*KS, for the wave's two column
 // tiles.  Row-tile-outer: an accumulator is live for one row tile only, and its ReLU/convert
 // (VALU) overlaps the next row tile's MFMAs.  A fragments: chunk (rt, kk) at ((rt*KS+kk)*64+lane)*16.
-#ifdef RTXN_PIPE_A
-// Variant with a hand-placed software pipeline (cdna_hip_programming.md 5.7 form (iii)): hipcc sinks every plain LDS
-// load down to its consumer (ds_read; s_waitcnt lgkmcnt(0); mfma), exposing the LDS latency once per k-step.  Here the
-// A fragments are fetched with inline-asm ds_read_b128 RTXN_PIPE_A steps ahead into a register ring, each consumer is
-// preceded by a counted s_waitcnt lgkmcnt(N) + sched_barrier, and nothing else in the loop touches LDS or SMEM.
+// ---------------------------------------------------------------------------------------------------------------
+// Software-pipelined layers for the inference kernel (cdna_hip_programming.md 5.7 form (iii)).
+// Left to itself hipcc (a) sinks every A-fragment LDS load down to its consumer (ds_read; s_waitcnt lgkmcnt(0); mfma)
+// and (b) keeps all RT accumulator tiles live and converts them after the layer's last MFMA, so inside one wave
+// neither the LDS latency nor the ReLU/convert VALU work runs in the shadow of an MFMA.  Here the order is fixed by
+// hand:
+//   * A fragments come through a register ring of RTXN_PIPE slots filled with inline-asm ds_read_b128 that many
+//     k-steps ahead, with a counted s_waitcnt lgkmcnt(N) in front of each consumer (nothing else in these functions
+//     may touch LDS or SMEM);
+//   * accumulators are double-buffered by row-tile parity: acc[rt & 1] collects row tile rt while the finished tile
+//     rt-1 in acc[~rt & 1] is converted in slices of a few pack2 units issued right behind each k-step's MFMAs;
+//   * the LAST row tile of a layer stays pending in acc[1] and is converted during the first k-steps of the NEXT
+//     layer's (or the output layer's) row tile 0, which needs those two B fragments only at k-steps KS-2, KS-1;
+//   * sched_barrier(0) between k-steps keeps hipcc from regrouping them.
+// The converts are asm volatile: as plain code they are pure value computations and instruction selection places them
+// after the layer's last MFMA wherever they are written.  hipcc's hazard recogniser cannot see into asm, so the
+// MFMA-result -> VALU-read wait states are guaranteed by construction instead: a unit only ever reads an accumulator
+// whose last MFMA is followed by at least one full k-step of MFMAs on the same (in-order, one matrix core) SIMD.
+#ifndef RTXN_PIPE
+#define RTXN_PIPE 3
+#endif
+typedef int int4v __attribute__((ext_vector_type(4)));
+
 template <int OFF>
 __device__ __forceinline__ void lds_read_frag(half8& dst, unsigned addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
@@ -112,51 +130,82 @@ __device__ __forceinline__ void lds_wait() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int RT, int KS, int NB, int I>
-struct LayerStep {
-  static constexpr int D = RTXN_PIPE_A, N = RT * KS;
-  __device__ static __forceinline__ void run(unsigned addr, const half8 (&bf)[NB][2], half8 (&nbf)[NB][2], half8 (&ring)[D],
-                                             floatx16 (&acc)[2]) {
-    constexpr int rt = I / KS, kk = I % KS;
+// pack2 unit P (0 .. 8*CT-1) of a finished accumulator tile -> dword (P%4) of B fragment dst[k0 + (P%8)/4][P/8]
+template <int NB, int CT, int P>
+__device__ __forceinline__ void convert_unit(const floatx16 (&acc)[CT], half8 (&dst)[NB][CT], int k0) {
+  constexpr int ct = P / 8, q = P % 8, s = q / 4, e = q % 4;
+  int4v t = __builtin_bit_cast(int4v, dst[k0 + s][ct]);
+  int r;
+  asm volatile("v_cvt_pk_f16_f32 %0, %1, %2\n\tv_pk_max_i16 %0, %0, 0"
+               : "=v"(r)
+               : "v"(acc[ct][8 * s + 2 * e]), "v"(acc[ct][8 * s + 2 * e + 1]));
+  t[e] = r;
+  dst[k0 + s][ct] = __builtin_bit_cast(half8, t);
+}
+template <int NB, int CT, int P0, int P1>
+__device__ __forceinline__ void convert_units(const floatx16 (&acc)[CT], half8 (&dst)[NB][CT], int k0) {
+  if constexpr (P0 < P1) {
+    convert_unit<NB, CT, P0>(acc, dst, k0);
+    convert_units<NB, CT, P0 + 1, P1>(acc, dst, k0);
+  }
+}
+// units [kk*U, (kk+1)*U) clipped to 8*CT
+template <int NB, int CT, int U, int KK>
+__device__ __forceinline__ void convert_slice(const floatx16 (&acc)[CT], half8 (&dst)[NB][CT], int k0) {
+  constexpr int p0 = KK * U < 8 * CT ? KK * U : 8 * CT, p1 = (KK + 1) * U < 8 * CT ? (KK + 1) * U : 8 * CT;
+  convert_units<NB, CT, p0, p1>(acc, dst, k0);
+}
+
+// RT row tiles (RT == 0: the output layer's single tile, accumulated in acc[0] and left there unconverted).
+// PEND: acc[1] holds the previous layer's last row tile, to be converted into bf[KS-2], bf[KS-1].
+template <int RT, int KS, int NB, int CT, bool PEND, int I>
+struct PipeStep {
+  static constexpr int D = RTXN_PIPE, N = (RT ? RT : 1) * KS;
+  static constexpr int U = (8 * CT + KS - 1) / KS;                 // units per k-step, row tiles 1..
+  static constexpr int WIN = KS - 3 > 1 ? KS - 3 : 1;              // k-steps of row tile 0 the pending tile is spread over
+  static constexpr int UP = (8 * CT + WIN - 1) / WIN;
+  __device__ static __forceinline__ void run(unsigned addr, half8 (&bf)[NB][CT], half8 (&nbf)[NB][CT], half8 (&ring)[D],
+                                             floatx16 (&acc)[2][CT]) {
+    constexpr int rt = I / KS, kk = I % KS, cur = rt & 1;
     constexpr int outstanding = (N - 1 - I) < (D - 1) ? (N - 1 - I) : (D - 1);   // reads issued after fragment I
     lds_wait<outstanding>();
     const half8 a = ring[I % D];
     if (kk == 0) {
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
+      for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[ct][e] = 0.0f;
+        for (int e = 0; e < 16; ++e) acc[cur][ct][e] = 0.0f;
     }
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[kk][ct], acc[ct], 0, 0, 0);
+    for (int ct = 0; ct < CT; ++ct) acc[cur][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[kk][ct], acc[cur][ct], 0, 0, 0);
+    if constexpr (rt > 0) convert_slice<NB, CT, U, kk>(acc[cur ^ 1], nbf, 2 * (rt - 1));
+    else if constexpr (PEND && kk < WIN) convert_slice<NB, CT, UP, kk>(acc[1], bf, KS - 2);
     __builtin_amdgcn_sched_barrier(0);
-    if (I + D < N) lds_read_frag<(I + D < N ? (I + D) * 1024 : 0)>(ring[I % D], addr);
-    if (kk == KS - 1) {
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) nbf[2 * rt + s][ct] = relu_pack(acc[ct], s);
-    }
-    if constexpr (I + 1 < N) LayerStep<RT, KS, NB, I + 1>::run(addr, bf, nbf, ring, acc);
+    if constexpr (I + D < N) lds_read_frag<(I + D) * 1024>(ring[I % D], addr);
+    if constexpr (I + 1 < N) PipeStep<RT, KS, NB, CT, PEND, I + 1>::run(addr, bf, nbf, ring, acc);
   }
 };
 
-template <int RT, int KS, int NB>
-__device__ __forceinline__ void layer_mma(const uint8_t* lds_buf, const half8 (&bf)[NB][2], half8 (&nbf)[NB][2],
-                                          int lane) {
-  constexpr int D = RTXN_PIPE_A, N = RT * KS;
+template <int RT, int KS, int NB, int CT, bool PEND>
+__device__ __forceinline__ void pipe_layer(const uint8_t* lds_buf, half8 (&bf)[NB][CT], half8 (&nbf)[NB][CT], floatx16 (&acc)[2][CT],
+                                           int lane) {
+  constexpr int D = RTXN_PIPE, N = (RT ? RT : 1) * KS;
+  static_assert(D >= 1 && D <= 4, "ring depth");
+  static_assert(RT % 2 == 0, "the pending row tile must land in acc[1]");
+  static_assert(CT >= 2, "a unit must never read the accumulator of the MFMA issued just before it");
+  static_assert(!PEND || KS >= 4, "pending tile needs k-steps to hide in");
   static_assert(N * 1024 <= 65535 + 1024, "fragment offsets must fit the 16-bit ds offset");
   half8 ring[D];
   const unsigned addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) uint8_t*)lds_buf + lane * 16;
-  // prologue: the first D fragments
   lds_read_frag<0>(ring[0], addr);
-  if (D > 1 && N > 1) lds_read_frag<1024>(ring[1 % D], addr);
-  if (D > 2 && N > 2) lds_read_frag<2048>(ring[2 % D], addr);
-  if (D > 3 && N > 3) lds_read_frag<3072>(ring[3 % D], addr);
-  floatx16 acc[2];
-  LayerStep<RT, KS, NB, 0>::run(addr, bf, nbf, ring, acc);
+  if constexpr (D > 1 && N > 1) lds_read_frag<1024>(ring[1 % D], addr);
+  if constexpr (D > 2 && N > 2) lds_read_frag<2048>(ring[2 % D], addr);
+  if constexpr (D > 3 && N > 3) lds_read_frag<3072>(ring[3 % D], addr);
+  PipeStep<RT, KS, NB, CT, PEND, 0>::run(addr, bf, nbf, ring, acc);
 }
-#else
+
+// ---------------------------------------------------------------------------------------------------------------
+// Compiler-scheduled layers (training kernels)
 // One layer: out rows [32*rt, 32*rt+32) for rt < RT, K = 16*KS, for the wave's two column
 // tiles.  Row-tile-outer: an accumulator is live for one row tile only, and its ReLU/convert
 // (VALU) overlaps the next row tile's MFMAs.  A fragments: chunk (rt, kk) at ((rt*KS+kk)*64+lane)*16.
@@ -182,8 +231,6 @@ __device__ __forceinline__ void layer_mma(const uint8_t* lds_buf, const half8 (&
       for (int ct = 0; ct < CT; ++ct) nbf[2 * rt + s][ct] = relu_pack(acc[ct], s);
   }
 }
-#endif
-
 // Output layer: 32 rows (16 real), raw accumulators returned.
 template <int KS, int NB, int CT>
 __device__ __forceinline__ void out_mma(const uint8_t* lds_buf, const half8 (&bf)[NB][CT], floatx16 (&acc)[CT], int lane) {
