@@ -43,6 +43,9 @@
 namespace {
 
 using rtxn::pipe_layer;
+#ifndef RTXN_ABLATE
+#define RTXN_ABLATE 0   // timing experiments (tools/ablate.sh): 1 no encode, 2 no barrier, 4 no weight staging -- results are wrong
+#endif
 using rtxn::relu_pack;
 using rtxn::stage;
 
@@ -182,12 +185,12 @@ __device__ __forceinline__ _Float16 encode_slot(int p, const float (&x)[5], floa
   // p is a compile-time constant after unrolling
   if (p < PD * PF) {
     const int dim = p / PF, f = p % PF;
-    const float rev = __builtin_amdgcn_fractf(x[dim] * (float)(1u << f) * 0.5f) + phase;
+    const float rev = __builtin_amdgcn_fractf(x[dim] * (0.5f * (float)(1u << f))) + phase;
     return (_Float16)__builtin_amdgcn_sinf(rev);
   } else if (p < ES::n_pairs) {
     const int q = p - PD * PF;
     const int dim = PD + q / DF, f = q % DF;
-    const float rev = __builtin_amdgcn_fractf(x[dim] * (float)(1u << f) * 0.5f) + phase;
+    const float rev = __builtin_amdgcn_fractf(x[dim] * (0.5f * (float)(1u << f))) + phase;
     return (_Float16)__builtin_amdgcn_sinf(rev);
   } else if (p < ES::n_slots) {
     return (_Float16)1.0f;
@@ -209,6 +212,8 @@ __global__ __launch_bounds__(CT == 2 ? 256 : 512, CT == 2 ? 2 : 4) void mlp_fwd_
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 2 * BUF
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // the same number, known to hipcc as wave-uniform
+  static_assert(CT == 2, "pipe_layer: 4 waves x 2 column tiles");
   long n_tiles;
   long total_seg = 0;
   if (IN_MODE == 1) {
@@ -234,17 +239,26 @@ __global__ __launch_bounds__(CT == 2 ? 256 : 512, CT == 2 ? 2 : 4) void mlp_fwd_
   // Inputs are fetched ONE TILE AHEAD: the loads for tile t+1 are issued right after tile t's
   // encoding and have the whole layer stack of tile t to land (the first barrier drains them).
   float xin[CT][5];
-  bool valid_n[CT];
-  long samp_n[CT];
   float d0_n[CT], dr_n[CT];  // OUT_MODE 2: step of sample 0 / of the other samples of the segment
+  // sample index / validity of this lane's column in column tile ct of a tile: recomputed where needed (the epilogue)
+  // rather than carried through the layer stack in registers
+  auto sample_of = [&](long tile, int ct, bool& valid) -> long {
+    if (IN_MODE == 1) {
+      const long seg = tile * 8 + wave_u * CT + ct;
+      valid = seg < total_seg;
+      return seg * 32 + col;
+    }
+    const long sidx = tile * kTileSamples + wave_u * (32 * CT) + ct * 32 + col;
+    valid = sidx < a.n;
+    return sidx;
+  };
   auto load_inputs = [&](long tile) {
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
+      bool valid_in;
+      const long samp_in = sample_of(tile, ct, valid_in);
       if (IN_MODE == 1) {
-        const long seg = tile * 8 + wave * CT + ct;
-        valid_n[ct] = seg < total_seg;
-        samp_n[ct] = seg * 32 + col;
-        const long sg = valid_n[ct] ? seg : 0;
+        const long sg = valid_in ? (samp_in >> 5) : 0;
         const bool mid = OUT_MODE == 2 && a.vr_mode == RTXN_VR_NERF;   // NERF composite samples sub-interval midpoints
         const float t = ((float)col + (mid ? 0.5f : 0.0f)) * (1.0f / 32);
         float dd[3];
@@ -266,9 +280,7 @@ __global__ __launch_bounds__(CT == 2 ? 256 : 512, CT == 2 ? 2 : 4) void mlp_fwd_
           }
         }
       } else {
-        samp_n[ct] = tile * kTileSamples + wave * (32 * CT) + ct * 32 + col;
-        valid_n[ct] = samp_n[ct] < a.n;
-        const long sidx = valid_n[ct] ? samp_n[ct] : 0;
+        const long sidx = valid_in ? samp_in : 0;
 #pragma unroll
         for (int c = 0; c < 5; ++c) xin[ct][c] = a.input[5 * sidx + c];
       }
@@ -279,47 +291,57 @@ __global__ __launch_bounds__(CT == 2 ? 256 : 512, CT == 2 ? 2 : 4) void mlp_fwd_
   for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     // ---- this wave's two column tiles -> first-layer B fragments ----
     half8 bf[NB][CT];
-    bool valid[CT];
-    long samp[CT];
     float d0[CT], dr[CT];
     const float phase = 0.25f * (float)h;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
-      valid[ct] = valid_n[ct];
-      samp[ct] = samp_n[ct];
       d0[ct] = d0_n[ct];
       dr[ct] = dr_n[ct];
 #pragma unroll
       for (int kk = 0; kk < KS0; ++kk) {
         half8 v;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = encode_slot<ES, PD, PF, DD, DF>(8 * kk + j, xin[ct], phase);
+        for (int j = 0; j < 8; ++j) {
+#if RTXN_ABLATE & 1
+          v[j] = (_Float16)(xin[ct][j % 5] + phase);   // timing experiment only
+#else
+          v[j] = encode_slot<ES, PD, PF, DD, DF>(8 * kk + j, xin[ct], phase);
+#endif
+        }
         bf[kk][ct] = v;
       }
-      if (IN_MODE == 1 && OUT_MODE != 2 && a.t_vals && valid[ct] && h == 0) a.t_vals[samp[ct]] = (float)(col + 1) * (1.0f / 32);
+      if (IN_MODE == 1 && OUT_MODE != 2 && a.t_vals && h == 0) {
+        bool valid;
+        const long samp = sample_of(tile, ct, valid);
+        if (valid) a.t_vals[samp] = (float)(col + 1) * (1.0f / 32);
+      }
     }
     if (tile + gridDim.x < n_tiles) load_inputs(tile + gridDim.x);
 
     // ---- layers ----  (two fragment sets used ping-pong: no register copies between layers)
     half8 bg[NB][CT];
     floatx16 acc2[2][CT];
-    // barrier + prefetch of the following stage; returns the LDS buffer holding layer l
+    // barrier, then: the LDS buffer holding layer l and the job that fetches the following stage into the other one
+    rtxn::StageJob sj;
     auto begin_stage = [&](int l) -> const uint8_t* {
       const uint8_t* cur = smem + (q & 1) * BUF;
-      uint8_t* nxt = smem + ((q + 1) & 1) * BUF;
-      __syncthreads();  // stage q landed (hipcc drains vmcnt before the barrier); buffer nxt is free
-      if (l + 1 < n_layers) {
-        if (l + 1 == n_layers - 1) stage<OUT_BYTES, THREADS>(a.packed + layer_off(l + 1), nxt, tid);
-        else stage<HID_BYTES, THREADS>(a.packed + layer_off(l + 1), nxt, tid);
-      } else if (tile + gridDim.x < n_tiles) {
-        stage<L0_BYTES, THREADS>(a.packed, nxt, tid);
+      sj.lds = smem + ((q + 1) & 1) * BUF;
+#if !(RTXN_ABLATE & 2)
+      __syncthreads();  // stage q landed (hipcc drains vmcnt before the barrier); the other buffer is free
+#endif
+      if (RTXN_ABLATE & 4) {
+        sj.g = a.packed, sj.nfrags = 0;
+      } else if (l + 1 < n_layers) {
+        sj.g = a.packed + layer_off(l + 1), sj.nfrags = (l + 1 == n_layers - 1 ? OUT_BYTES : HID_BYTES) / 1024;
+      } else {
+        sj.g = a.packed, sj.nfrags = tile + gridDim.x < n_tiles ? L0_BYTES / 1024 : 0;
       }
       ++q;
       return cur;
     };
     auto finish = [&](half8 (&in)[NB][CT], half8 (&other)[NB][CT]) {
       const uint8_t* w = begin_stage(n_layers - 1);
-      pipe_layer<0, KS, NB, CT, true>(w, in, other, acc2, lane);
+      pipe_layer<0, KS, NB, CT, true>(w, sj, in, other, acc2, wave_u, lane);
       floatx16 (&acc)[CT] = acc2[0];
       // rows 4h..4h+3 are regs 0..3, rows 8+4h..8+4h+3 are regs 4..7 of this lane
 #pragma unroll
@@ -330,21 +352,23 @@ __global__ __launch_bounds__(CT == 2 ? 256 : 512, CT == 2 ? 2 : 4) void mlp_fwd_
           const float z = acc[ct][e];
           y[e] = a.out_act == RTXN_ACT_SIGMOID ? 1.0f / (1.0f + __expf(-z)) : z;
         }
+        bool valid;
+        const long samp = sample_of(tile, ct, valid);
         if (OUT_MODE == 2) {
           const float4 c = seg_composite((float)(_Float16)y[0], (float)(_Float16)y[1], (float)(_Float16)y[2],
                                          (float)(_Float16)y[3], col, d0[ct], dr[ct], a.vr_mode);
-          if (valid[ct] && lane == 0) a.seg_out[samp[ct] >> 5] = c;
-        } else if (valid[ct]) {
+          if (valid && lane == 0) a.seg_out[samp >> 5] = c;
+        } else if (valid) {
           if (OUT_MODE == 0) {
             half4v lo, hi;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { lo[e] = (_Float16)y[e]; hi[e] = (_Float16)y[4 + e]; }
-            _Float16* o = a.out_half + samp[ct] * 16;
+            _Float16* o = a.out_half + samp * 16;
             *reinterpret_cast<half4v*>(o + 4 * h) = lo;
             *reinterpret_cast<half4v*>(o + 8 + 4 * h) = hi;
           } else if (h == 0) {
             // radiance = fp32(fp16(y)): the half output of network->forward, then convertHalfToFloat
-            a.radiance[samp[ct]] = make_float4((float)(_Float16)y[0], (float)(_Float16)y[1],
+            a.radiance[samp] = make_float4((float)(_Float16)y[0], (float)(_Float16)y[1],
                                                (float)(_Float16)y[2], (float)(_Float16)y[3]);
           }
         }
@@ -353,18 +377,18 @@ __global__ __launch_bounds__(CT == 2 ? 256 : 512, CT == 2 ? 2 : 4) void mlp_fwd_
     // every layer leaves its last row tile pending in acc2[1]; the next one converts it under its first MFMAs
     {
       const uint8_t* w = begin_stage(0);
-      pipe_layer<RT, KS0, NB, CT, false>(w, bf, bg, acc2, lane);
+      pipe_layer<RT, KS0, NB, CT, false>(w, sj, bf, bg, acc2, wave_u, lane);
     }
     int l = 1;
     for (; l + 1 < n_layers - 1; l += 2) {  // activations in bg at the top
       const uint8_t* w = begin_stage(l);
-      pipe_layer<RT, KS, NB, CT, true>(w, bg, bf, acc2, lane);
+      pipe_layer<RT, KS, NB, CT, true>(w, sj, bg, bf, acc2, wave_u, lane);
       w = begin_stage(l + 1);
-      pipe_layer<RT, KS, NB, CT, true>(w, bf, bg, acc2, lane);
+      pipe_layer<RT, KS, NB, CT, true>(w, sj, bf, bg, acc2, wave_u, lane);
     }
     if (l < n_layers - 1) {
       const uint8_t* w = begin_stage(l);
-      pipe_layer<RT, KS, NB, CT, true>(w, bg, bf, acc2, lane);
+      pipe_layer<RT, KS, NB, CT, true>(w, sj, bg, bf, acc2, wave_u, lane);
       finish(bf, bg);
     } else {
       finish(bg, bf);

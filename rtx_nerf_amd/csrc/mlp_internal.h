@@ -156,6 +156,24 @@ __device__ __forceinline__ void convert_slice(const floatx16 (&acc)[CT], half8 (
   convert_units<NB, CT, p0, p1>(acc, dst, k0);
 }
 
+// The weights of the FOLLOWING stage are fetched while this one computes: one 1-KiB fragment per wave per k-step
+// (LDS-DMA), issued behind that k-step's MFMAs so that neither the address arithmetic nor the M0 set-up costs a slot in
+// which the matrix core idles.  Everything in a StageJob is wave-uniform.
+struct StageJob {
+  const uint8_t* g;   // fragments of the next stage in the packed buffer
+  uint8_t* lds;       // the LDS buffer that is free during this stage
+  int nfrags;         // 0: nothing to fetch
+};
+template <int C, int WAVES>
+__device__ __forceinline__ void stage_chunk(const StageJob& sj, int wave_u, int lane) {
+  const int frag = C * WAVES + wave_u;
+  if (frag < sj.nfrags) {
+    const uint8_t* base = sj.g + (size_t)frag * 1024;   // SGPR pair; the lane part stays a 32-bit VGPR offset (saddr form)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (unsigned)(lane << 4)),
+                                     (__attribute__((address_space(3))) void*)(sj.lds + frag * 1024), 16, 0, 0);
+  }
+}
+
 // RT row tiles (RT == 0: the output layer's single tile, accumulated in acc[0] and left there unconverted).
 // PEND: acc[1] holds the previous layer's last row tile, to be converted into bf[KS-2], bf[KS-1].
 template <int RT, int KS, int NB, int CT, bool PEND, int I>
@@ -164,8 +182,10 @@ struct PipeStep {
   static constexpr int U = (8 * CT + KS - 1) / KS;                 // units per k-step, row tiles 1..
   static constexpr int WIN = KS - 3 > 1 ? KS - 3 : 1;              // k-steps of row tile 0 the pending tile is spread over
   static constexpr int UP = (8 * CT + WIN - 1) / WIN;
+  static constexpr int WAVES = 4;
+  static constexpr int CHUNKS = N < 8 ? N : 8;                     // k-steps that carry a staging chunk: up to 32 KiB
   __device__ static __forceinline__ void run(unsigned addr, half8 (&bf)[NB][CT], half8 (&nbf)[NB][CT], half8 (&ring)[D],
-                                             floatx16 (&acc)[2][CT]) {
+                                             floatx16 (&acc)[2][CT], const StageJob& sj, int wave_u, int lane) {
     constexpr int rt = I / KS, kk = I % KS, cur = rt & 1;
     constexpr int outstanding = (N - 1 - I) < (D - 1) ? (N - 1 - I) : (D - 1);   // reads issued after fragment I
     lds_wait<outstanding>();
@@ -182,13 +202,17 @@ struct PipeStep {
     else if constexpr (PEND && kk < WIN) convert_slice<NB, CT, UP, kk>(acc[1], bf, KS - 2);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (I + D < N) lds_read_frag<(I + D) * 1024>(ring[I % D], addr);
-    if constexpr (I + 1 < N) PipeStep<RT, KS, NB, CT, PEND, I + 1>::run(addr, bf, nbf, ring, acc);
+    if constexpr (I < CHUNKS) {
+      stage_chunk<I, WAVES>(sj, wave_u, lane);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (I + 1 < N) PipeStep<RT, KS, NB, CT, PEND, I + 1>::run(addr, bf, nbf, ring, acc, sj, wave_u, lane);
   }
 };
 
 template <int RT, int KS, int NB, int CT, bool PEND>
-__device__ __forceinline__ void pipe_layer(const uint8_t* lds_buf, half8 (&bf)[NB][CT], half8 (&nbf)[NB][CT], floatx16 (&acc)[2][CT],
-                                           int lane) {
+__device__ __forceinline__ void pipe_layer(const uint8_t* lds_buf, const StageJob& sj, half8 (&bf)[NB][CT], half8 (&nbf)[NB][CT],
+                                           floatx16 (&acc)[2][CT], int wave_u, int lane) {
   constexpr int D = RTXN_PIPE, N = (RT ? RT : 1) * KS;
   static_assert(D >= 1 && D <= 4, "ring depth");
   static_assert(RT % 2 == 0, "the pending row tile must land in acc[1]");
@@ -201,7 +225,7 @@ __device__ __forceinline__ void pipe_layer(const uint8_t* lds_buf, half8 (&bf)[N
   if constexpr (D > 1 && N > 1) lds_read_frag<1024>(ring[1 % D], addr);
   if constexpr (D > 2 && N > 2) lds_read_frag<2048>(ring[2 % D], addr);
   if constexpr (D > 3 && N > 3) lds_read_frag<3072>(ring[3 % D], addr);
-  PipeStep<RT, KS, NB, CT, PEND, 0>::run(addr, bf, nbf, ring, acc);
+  PipeStep<RT, KS, NB, CT, PEND, 0>::run(addr, bf, nbf, ring, acc, sj, wave_u, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

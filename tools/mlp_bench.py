@@ -19,6 +19,7 @@ ap.add_argument("--neurons", type=int, default=128)
 ap.add_argument("--layers", type=int, default=8)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--composite", action="store_true", help="time the fused per-segment composite epilogue variant")
+ap.add_argument("--samples", action="store_true", help="time rtxn_mlp_forward_radiance on a materialised float[N][5] batch (the bench.py default path)")
 args = ap.parse_args()
 
 torch.cuda.set_device(0)
@@ -39,6 +40,14 @@ if args.composite:
 
     def run():
         net.forward_segments_composite(sp, ep, sv, seg_first, total, P, seg_out)
+elif args.samples:
+    t = (torch.arange(32, device="cuda", dtype=torch.float32) / 32)[None, :, None]
+    xyz = sp[:, None, :] + t * (ep - sp)[:, None, :]
+    batch = torch.cat([xyz, sv[:, None, :].expand(P, 32, 2)], dim=2).reshape(P * 32, 5).contiguous()
+    rad = torch.empty((P * 32, 4), device="cuda")
+
+    def run():
+        net.forward_radiance(batch, rad)
 else:
     rad = torch.empty((P * 32, 4), device="cuda")
     tv = torch.empty(P * 32, device="cuda")
