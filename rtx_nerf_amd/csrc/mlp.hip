@@ -36,6 +36,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "mlp_internal.h"
@@ -49,7 +50,6 @@ using rtxn::pipe_layer;
 using rtxn::relu_pack;
 using rtxn::stage;
 
-constexpr int kTileSamples = 256;  // per block per iteration
 
 struct FwdArgs {
   const uint8_t* packed;
@@ -202,8 +202,9 @@ __device__ __forceinline__ _Float16 encode_slot(int p, const float (&x)[5], floa
 // A fragment feeds two MFMAs.  CT = 1: 8 waves x 32 samples, 2 blocks/CU (4 waves/SIMD, <= 128 VGPRs): more waves to
 // cover each other's encode/convert phases, one LDS read per MFMA.
 template <int W, int PD, int PF, int DD, int DF, int IN_MODE, int OUT_MODE, int CT>
-__global__ __launch_bounds__(CT == 2 ? 256 : 512, CT == 2 ? 2 : 4) void mlp_fwd_kernel(FwdArgs a) {
-  constexpr int THREADS = CT == 2 ? 256 : 512;
+__global__ __launch_bounds__(256, CT == 2 ? 2 : 1) void mlp_fwd_kernel(FwdArgs a) {
+  constexpr int THREADS = 256;
+  constexpr int TILE = 128 * CT, TILE_SEGS = 4 * CT;   // samples / segments per block per iteration
   using ES = EncSpec<PD, PF, DD, DF>;
   constexpr int RT = W / 32, KS = W / 16, KS0 = ES::k0 / 16;
   constexpr int NB = KS0 > KS ? KS0 : KS;
@@ -213,15 +214,15 @@ __global__ __launch_bounds__(CT == 2 ? 256 : 512, CT == 2 ? 2 : 4) void mlp_fwd_
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // the same number, known to hipcc as wave-uniform
-  static_assert(CT == 2, "pipe_layer: 4 waves x 2 column tiles");
+  static_assert(CT == 2 || CT == 4, "pipe_layer: 4 waves x CT column tiles");
   long n_tiles;
   long total_seg = 0;
   if (IN_MODE == 1) {
     total_seg = *a.total_segments;
     if (total_seg > a.max_segments) total_seg = a.max_segments;
-    n_tiles = (total_seg + 7) / 8;
+    n_tiles = (total_seg + TILE_SEGS - 1) / TILE_SEGS;
   } else {
-    n_tiles = (a.n + kTileSamples - 1) / kTileSamples;
+    n_tiles = (a.n + TILE - 1) / TILE;
   }
   if ((long)blockIdx.x >= n_tiles) return;
 
@@ -244,11 +245,11 @@ __global__ __launch_bounds__(CT == 2 ? 256 : 512, CT == 2 ? 2 : 4) void mlp_fwd_
   // rather than carried through the layer stack in registers
   auto sample_of = [&](long tile, int ct, bool& valid) -> long {
     if (IN_MODE == 1) {
-      const long seg = tile * 8 + wave_u * CT + ct;
+      const long seg = tile * TILE_SEGS + wave_u * CT + ct;
       valid = seg < total_seg;
       return seg * 32 + col;
     }
-    const long sidx = tile * kTileSamples + wave_u * (32 * CT) + ct * 32 + col;
+    const long sidx = tile * TILE + wave_u * (32 * CT) + ct * 32 + col;
     valid = sidx < a.n;
     return sidx;
   };
@@ -417,24 +418,6 @@ __device__ __forceinline__ void stage512(const uint8_t* __restrict__ g, uint8_t*
   }
 }
 
-template <int KSL>
-__device__ __forceinline__ void rowtile_pair256(const uint8_t* buf, const half8 (&bf)[16], half8& o0, half8& o1, half8& o2,
-                                                half8& o3, int lane) {
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    floatx16 acc;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
-#pragma unroll
-    for (int kk = 0; kk < KSL; ++kk) {
-      const half8 af = *reinterpret_cast<const half8*>(buf + ((r * KSL + kk) * 64 + lane) * 16);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf[kk], acc, 0, 0, 0);
-    }
-    if (r == 0) { o0 = relu_pack(acc, 0); o1 = relu_pack(acc, 1); }
-    else { o2 = relu_pack(acc, 0); o3 = relu_pack(acc, 1); }
-  }
-}
-
 template <int PD, int PF, int DD, int DF, int IN_MODE, int OUT_MODE>
 __global__ __launch_bounds__(kThreads256, 2) void mlp_fwd256_kernel(FwdArgs a) {
   using ES = EncSpec<PD, PF, DD, DF>;
@@ -455,20 +438,31 @@ __global__ __launch_bounds__(kThreads256, 2) void mlp_fwd256_kernel(FwdArgs a) {
   const int n_chunks = 4 + 4 * (a.n_hidden - 1) + 1;
   const long g_end = my_tiles * n_chunks;
   long g = 0;  // chunks consumed so far by this block
-  auto issue = [&](long gi) {
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  // chunk gi of this block's stream: offset and size in the packed buffer
+  auto chunk_src = [&](long gi, int& size) -> long {
     const int i = (int)(gi % n_chunks);
-    long off;
+    if (i < 4) { size = 2 * KS0 * 1024; return (long)i * size; }
+    if (i < n_chunks - 1) { size = 2 * KS * 1024; return 4L * 2 * KS0 * 1024 + (long)(i - 4) * size; }
+    size = KS * 1024;
+    return 4L * 2 * KS0 * 1024 + (long)(n_chunks - 5) * 2 * KS * 1024;
+  };
+  auto issue = [&](long gi) {
     int size;
-    if (i < 4) { size = 2 * KS0 * 1024; off = (long)i * size; }
-    else if (i < n_chunks - 1) { size = 2 * KS * 1024; off = 4L * 2 * KS0 * 1024 + (long)(i - 4) * size; }
-    else { size = KS * 1024; off = 4L * 2 * KS0 * 1024 + (long)(n_chunks - 5) * 2 * KS * 1024; }
+    const long off = chunk_src(gi, size);
     stage512(a.packed + off, smem + (gi % 3) * kSlot256, size, tid);
   };
   issue(0);
   if (g_end > 1) issue(1);
+  // barrier, then: the slot holding chunk g, and the job that fetches chunk g+2 into the slot chunk g-1 just left
+  rtxn::StageJob sj;
   auto next_chunk = [&]() -> const uint8_t* {
     __syncthreads();  // chunk g landed (vmcnt drained before the barrier); everyone is done with chunk g-1
-    if (g + 2 < g_end) issue(g + 2);
+    int size = 0;
+    const long off = g + 2 < g_end ? chunk_src(g + 2, size) : 0;
+    sj.g = a.packed + off;
+    sj.lds = smem + ((g + 2) % 3) * kSlot256;
+    sj.nfrags = size / 1024;
     const uint8_t* p = smem + (g % 3) * kSlot256;
     ++g;
     return p;
@@ -514,7 +508,7 @@ __global__ __launch_bounds__(kThreads256, 2) void mlp_fwd256_kernel(FwdArgs a) {
   load_inputs(blockIdx.x);
 
   for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    half8 bf[KS], bg[KS];
+    half8 bf[KS][1], bg[KS][1];
     const bool valid = valid_n;
     const long samp = samp_n;
     const float d0 = d0_n, dr = dr_n;
@@ -524,50 +518,43 @@ __global__ __launch_bounds__(kThreads256, 2) void mlp_fwd256_kernel(FwdArgs a) {
       half8 v;
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = encode_slot<ES, PD, PF, DD, DF>(8 * kk + j, xin, phase);
-      bf[kk] = v;
+      bf[kk][0] = v;
     }
     if (IN_MODE == 1 && OUT_MODE != 2 && a.t_vals && valid && h == 0) a.t_vals[samp] = (float)(col + 1) * (1.0f / 32);
     if (tile + gridDim.x < n_tiles) load_inputs(tile + gridDim.x);
 
-    // layer 0: K = 16*KS0
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    // A layer = 4 chunks of two row tiles; the second row tile of every chunk stays pending in acc2[1] and is converted
+    // under the next chunk's MFMAs (mlp_internal.h, PipeStep256).
+    floatx16 acc2[2][1];
+    auto layer = [&](auto ks_tag, auto pend_tag, half8 (&in)[KS][1], half8 (&out)[KS][1]) {
+      constexpr int KSL = decltype(ks_tag)::value;
+      constexpr bool PEND0 = decltype(pend_tag)::value;
       const uint8_t* w = next_chunk();
-      rowtile_pair256<KS0>(w, bf, bg[4 * p], bg[4 * p + 1], bg[4 * p + 2], bg[4 * p + 3], lane);
-    }
+      rtxn::pipe_chunk256<KSL, KS, 2, 0, PEND0>(w, sj, in, out, acc2, wave_u, lane);
+      w = next_chunk();
+      rtxn::pipe_chunk256<KSL, KS, 2, 2, true>(w, sj, in, out, acc2, wave_u, lane);
+      w = next_chunk();
+      rtxn::pipe_chunk256<KSL, KS, 2, 4, true>(w, sj, in, out, acc2, wave_u, lane);
+      w = next_chunk();
+      rtxn::pipe_chunk256<KSL, KS, 2, 6, true>(w, sj, in, out, acc2, wave_u, lane);
+    };
+    using std::integral_constant;
+    layer(integral_constant<int, KS0>{}, integral_constant<bool, false>{}, bf, bg);   // layer 0: K = 16*KS0
     // hidden layers 1..n_hidden-1, activations ping-pong bg -> bf -> bg
     int l = 1;
     for (; l + 1 < a.n_hidden; l += 2) {
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const uint8_t* w = next_chunk();
-        rowtile_pair256<KS>(w, bg, bf[4 * p], bf[4 * p + 1], bf[4 * p + 2], bf[4 * p + 3], lane);
-      }
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const uint8_t* w = next_chunk();
-        rowtile_pair256<KS>(w, bf, bg[4 * p], bg[4 * p + 1], bg[4 * p + 2], bg[4 * p + 3], lane);
-      }
+      layer(integral_constant<int, KS>{}, integral_constant<bool, true>{}, bg, bf);
+      layer(integral_constant<int, KS>{}, integral_constant<bool, true>{}, bf, bg);
     }
-    if (l < a.n_hidden) {
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const uint8_t* w = next_chunk();
-        rowtile_pair256<KS>(w, bg, bf[4 * p], bf[4 * p + 1], bf[4 * p + 2], bf[4 * p + 3], lane);
-      }
-#pragma unroll
-      for (int kk = 0; kk < KS; ++kk) bg[kk] = bf[kk];
+    const bool odd = l < a.n_hidden;
+    if (odd) layer(integral_constant<int, KS>{}, integral_constant<bool, true>{}, bg, bf);
+    // output layer: one row tile, raw accumulators in acc2[0]
+    {
+      const uint8_t* w = next_chunk();
+      if (odd) rtxn::pipe_chunk256<KS, KS, 1, 0, true>(w, sj, bf, bg, acc2, wave_u, lane);
+      else rtxn::pipe_chunk256<KS, KS, 1, 0, true>(w, sj, bg, bf, acc2, wave_u, lane);
     }
-    // output layer
-    const uint8_t* w = next_chunk();
-    floatx16 acc;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk) {
-      const half8 af = *reinterpret_cast<const half8*>(w + (kk * 64 + lane) * 16);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bg[kk], acc, 0, 0, 0);
-    }
+    const floatx16& acc = acc2[0][0];
     float y[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) y[e] = a.out_act == RTXN_ACT_SIGMOID ? 1.0f / (1.0f + __expf(-acc[e])) : acc[e];
@@ -603,9 +590,13 @@ struct Variant {
   size_t lds;
   int threads;        // block size
   int blocks_per_cu;  // persistent grid = CUs x this
+  int tile;           // samples per block per iteration (segments: tile / 32)
 };
 
-template <int W, int PD, int PF, int DD, int DF, int CT = 2>
+#ifndef RTXN_CT
+#define RTXN_CT 2
+#endif
+template <int W, int PD, int PF, int DD, int DF, int CT = RTXN_CT>
 Variant make_variant() {
   using ES = EncSpec<PD, PF, DD, DF>;
   constexpr int RT = W / 32, KS = W / 16, KS0 = ES::k0 / 16;
@@ -620,8 +611,9 @@ Variant make_variant() {
   v.fn[1][2] = mlp_fwd_kernel<W, PD, PF, DD, DF, 1, 2, CT>;
   v.k0 = ES::k0;
   v.lds = 2 * (size_t)(L0 > HID ? L0 : HID);
-  v.threads = CT == 2 ? 256 : 512;
-  v.blocks_per_cu = 2;
+  v.threads = 256;
+  v.blocks_per_cu = CT == 2 ? 2 : 1;
+  v.tile = 128 * CT;
   return v;
 }
 
@@ -640,6 +632,7 @@ Variant make_variant256() {
   v.lds = 3 * (size_t)kSlot256;
   v.threads = kThreads256;
   v.blocks_per_cu = 1;
+  v.tile = 256;
   return v;
 }
 
@@ -678,8 +671,11 @@ struct Pcg32 {
   }
 };
 
-int launch_fwd(const rtxn_mlp* m, FwdArgs& a, int in_mode, int out_mode, long n_tiles, hipStream_t s) {
+// n_units: samples (in_mode 0) or segments (in_mode 1) the launch may have to cover
+int launch_fwd(const rtxn_mlp* m, FwdArgs& a, int in_mode, int out_mode, long n_units, hipStream_t s) {
   const Variant& v = variants()[m->variant];
+  const long per_tile = in_mode == 1 ? v.tile / 32 : v.tile;
+  const long n_tiles = (n_units + per_tile - 1) / per_tile;
   a.packed = static_cast<const uint8_t*>(m->packed);
   a.n_hidden = m->cfg.n_hidden_layers;
   a.out_act = m->cfg.output_activation;
@@ -831,7 +827,7 @@ extern "C" int rtxn_mlp_forward(const rtxn_mlp* m, const float* input, void* out
   a.input = input;
   a.n = n;
   a.out_half = static_cast<_Float16*>(output_half);
-  return launch_fwd(m, a, 0, 0, (n + kTileSamples - 1) / kTileSamples, rtxn::as_stream(stream));
+  return launch_fwd(m, a, 0, 0, n, rtxn::as_stream(stream));
 }
 
 extern "C" int rtxn_mlp_forward_radiance(const rtxn_mlp* m, const float* input, float* radiance, long n,
@@ -848,7 +844,7 @@ extern "C" int rtxn_mlp_forward_radiance(const rtxn_mlp* m, const float* input, 
   a.input = input;
   a.n = n;
   a.radiance = reinterpret_cast<float4*>(radiance);
-  return launch_fwd(m, a, 0, 1, (n + kTileSamples - 1) / kTileSamples, rtxn::as_stream(stream));
+  return launch_fwd(m, a, 0, 1, n, rtxn::as_stream(stream));
 }
 
 extern "C" int rtxn_mlp_forward_segments(const rtxn_mlp* m, const float* start_points, const float* end_points,
@@ -871,7 +867,7 @@ extern "C" int rtxn_mlp_forward_segments(const rtxn_mlp* m, const float* start_p
   a.max_segments = max_segments;
   a.radiance = reinterpret_cast<float4*>(radiance);
   a.t_vals = t_vals;
-  return launch_fwd(m, a, 1, 1, (max_segments + 7) / 8, rtxn::as_stream(stream));
+  return launch_fwd(m, a, 1, 1, max_segments, rtxn::as_stream(stream));
 }
 
 extern "C" int rtxn_mlp_forward_segments_composite(const rtxn_mlp* m, const float* start_points, const float* end_points,
@@ -899,5 +895,5 @@ extern "C" int rtxn_mlp_forward_segments_composite(const rtxn_mlp* m, const floa
   a.seg_out = reinterpret_cast<float4*>(seg_out);
   a.vr_mode = mode;
   a.step_scale = step_scale;
-  return launch_fwd(m, a, 1, 2, (max_segments + 7) / 8, rtxn::as_stream(stream));
+  return launch_fwd(m, a, 1, 2, max_segments, rtxn::as_stream(stream));
 }
