@@ -44,6 +44,9 @@
 namespace {
 
 using rtxn::pipe_layer;
+#ifndef RTXN_DBG
+#define RTXN_DBG 0
+#endif
 #ifndef RTXN_ABLATE
 #define RTXN_ABLATE 0   // timing experiments (tools/ablate.sh): 1 no encode, 2 no barrier, 4 no weight staging -- results are wrong
 #endif
@@ -198,6 +201,124 @@ __device__ __forceinline__ _Float16 encode_slot(int p, const float (&x)[5], floa
   return (_Float16)0.0f;
 }
 
+// ---- layer 0 with the encoder inside it -------------------------------------------------------------------------
+// Encoding all KS0 B fragments before layer 0 is 108 quarter-rate v_sin_f32 (+ range reduction) per sample pair during
+// which the wave issues no MFMA.  Layer 0 therefore runs K-STEP-OUTER: the B fragments of k-step kk+1 are encoded in
+// slices behind the MFMAs of k-step kk (all RT row tiles accumulate at once: RT x CT accumulator tiles, but only two
+// k-steps of encoded input are ever live instead of KS0).  One encode unit = one dword of a B fragment = slots 2e, 2e+1
+// of (kk, ct): v_mul, v_fract, v_add(phase), v_sin per slot -- the same four instructions encode_slot compiles to --
+// then v_cvt_pk_f16_f32 (one wait state after the transcendental, which hipcc cannot insert inside asm).
+template <int PD, int PF, int DD, int DF, int P>
+struct SlotInfo {   // real slot P: input dimension and 2^(f-1)
+  static constexpr int f = P < PD * PF ? P % PF : (P - PD * PF) % DF;
+  static constexpr int dim = P < PD * PF ? P / PF : PD + (P - PD * PF) / DF;
+};
+// dword E (0..3) of the B fragment of k-step KK for one column tile
+template <class ES, int PD, int PF, int DD, int DF, int KK, int E>
+__device__ __forceinline__ int encode_unit(const float (&x)[5], float phase) {
+  constexpr int p0 = 8 * KK + 2 * E, p1 = p0 + 1;
+  if constexpr (p1 < ES::n_pairs) {
+    int r;
+    float t0, t1;
+    using S0 = SlotInfo<PD, PF, DD, DF, p0>;
+    using S1 = SlotInfo<PD, PF, DD, DF, p1>;
+    const float c0 = 0.5f * (float)(1u << S0::f), c1 = 0.5f * (float)(1u << S1::f);
+    asm volatile(
+        "v_mul_f32 %1, %4, %3\n\t"
+        "v_mul_f32 %2, %6, %5\n\t"
+        "v_fract_f32 %1, %1\n\t"
+        "v_fract_f32 %2, %2\n\t"
+        "v_add_f32 %1, %1, %7\n\t"
+        "v_add_f32 %2, %2, %7\n\t"
+        "v_sin_f32 %1, %1\n\t"
+        "v_sin_f32 %2, %2\n\t"
+        "s_nop 0\n\t"
+        "v_cvt_pk_f16_f32 %0, %1, %2"
+        : "=v"(r), "=&v"(t0), "=&v"(t1)
+        : "v"(x[S0::dim]), "s"(c0), "v"(x[S1::dim]), "s"(c1), "v"(phase));
+    return r;
+  } else {
+    // padding slots (1.0 up to enc_padded, then 0) -- or a real slot next to a padding one, which the plain path handles
+    half2v v;
+    v[0] = encode_slot<ES, PD, PF, DD, DF>(p0, x, phase);
+    v[1] = encode_slot<ES, PD, PF, DD, DF>(p1, x, phase);
+    return __builtin_bit_cast(int, v);
+  }
+}
+template <class ES, int PD, int PF, int DD, int DF, int CT, int KK, int U0, int U1>
+__device__ __forceinline__ void encode_units(const float (&xin)[CT][5], float phase, half8 (&b)[CT]) {
+  if constexpr (U0 < U1) {   // unit U: column tile U / 4, dword U % 4
+    constexpr int ct = U0 / 4, e = U0 % 4;
+    rtxn::int4v t = __builtin_bit_cast(rtxn::int4v, b[ct]);
+    t[e] = encode_unit<ES, PD, PF, DD, DF, KK, e>(xin[ct], phase);
+    b[ct] = __builtin_bit_cast(half8, t);
+    encode_units<ES, PD, PF, DD, DF, CT, KK, U0 + 1, U1>(xin, phase, b);
+  }
+}
+
+template <class ES, int PD, int PF, int DD, int DF, int RT, int KS0, int NB, int CT, int I>
+struct Layer0Step {
+  static constexpr int D = RTXN_PIPE, N = RT * KS0, WAVES = 4;
+  static constexpr int CHUNKS = N < 8 ? N : 8;
+  static constexpr int UE = (4 * CT + RT - 1) / RT;   // encode units per (kk, rt) sub-step
+  __device__ static __forceinline__ void run(unsigned addr, const float (&xin)[CT][5], float phase, half8 (&b)[2][CT],
+                                             half8 (&out)[NB][CT], half8 (&ring)[D], floatx16 (&acc)[RT][CT],
+                                             const rtxn::StageJob& sj, int wave_u, int lane) {
+    constexpr int kk = I / RT, rt = I % RT, cur = kk & 1;
+    constexpr int outstanding = (N - 1 - I) < (D - 1) ? (N - 1 - I) : (D - 1);
+    rtxn::lds_wait<outstanding>();
+#if RTXN_DBG & 1
+    if (rt == 0) { asm volatile("s_nop 7\n\ts_nop 7"); __builtin_amdgcn_sched_barrier(0); }
+#endif
+    const half8 a = ring[I % D];
+    if (kk == 0) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[rt][ct][e] = 0.0f;
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[cur][ct], acc[rt][ct], 0, 0, 0);
+#if RTXN_DBG & 2
+    asm volatile("s_nop 7\n\ts_nop 7"); __builtin_amdgcn_sched_barrier(0);
+#endif
+    if constexpr (kk + 1 < KS0) {
+      constexpr int u0 = rt * UE < 4 * CT ? rt * UE : 4 * CT, u1 = (rt + 1) * UE < 4 * CT ? (rt + 1) * UE : 4 * CT;
+      encode_units<ES, PD, PF, DD, DF, CT, kk + 1, u0, u1>(xin, phase, b[cur ^ 1]);
+    } else if constexpr (rt > 0) {
+      rtxn::convert_units<NB, CT, 0, 8 * CT>(acc[rt - 1], out, 2 * (rt - 1));   // last k-step: row tile rt-1 is complete
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (I + D < N) rtxn::lds_read_frag<(((I + D) % RT) * KS0 + (I + D) / RT) * 1024>(ring[I % D], addr);
+    if constexpr (I < CHUNKS) {
+      rtxn::stage_chunk<I, WAVES>(sj, wave_u, lane);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (I + 1 < N) Layer0Step<ES, PD, PF, DD, DF, RT, KS0, NB, CT, I + 1>::run(addr, xin, phase, b, out, ring, acc, sj, wave_u, lane);
+  }
+};
+
+// Leaves row tiles 0..RT-2 converted in out[] and the last one pending in pend[] (= acc2[1] of the kernel).
+template <class ES, int PD, int PF, int DD, int DF, int RT, int KS0, int NB, int CT>
+__device__ __forceinline__ void pipe_layer0(const uint8_t* lds_buf, const rtxn::StageJob& sj, const float (&xin)[CT][5], float phase,
+                                            half8 (&out)[NB][CT], floatx16 (&pend)[CT], int wave_u, int lane) {
+  constexpr int D = RTXN_PIPE, N = RT * KS0;
+  static_assert(N * 1024 <= 65535 + 1024, "fragment offsets must fit the 16-bit ds offset");
+  half8 ring[D];
+  const unsigned addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) uint8_t*)lds_buf + lane * 16;
+  // fragment of sub-step I = (kk, rt) sits at ((rt * KS0 + kk) * 64 + lane) * 16
+  rtxn::lds_read_frag<0>(ring[0], addr);
+  if constexpr (D > 1) rtxn::lds_read_frag<((1 % RT) * KS0 + 1 / RT) * 1024>(ring[1 % D], addr);
+  if constexpr (D > 2) rtxn::lds_read_frag<((2 % RT) * KS0 + 2 / RT) * 1024>(ring[2 % D], addr);
+  if constexpr (D > 3) rtxn::lds_read_frag<((3 % RT) * KS0 + 3 / RT) * 1024>(ring[3 % D], addr);
+  half8 b[2][CT];
+  encode_units<ES, PD, PF, DD, DF, CT, 0, 0, 4 * CT>(xin, phase, b[0]);   // k-step 0: nothing to hide behind yet
+  floatx16 acc[RT][CT];
+  Layer0Step<ES, PD, PF, DD, DF, RT, KS0, NB, CT, 0>::run(addr, xin, phase, b, out, ring, acc, sj, wave_u, lane);
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) pend[ct] = acc[RT - 1][ct];
+}
+
 // CT = 32-sample column tiles per wave.  CT = 2: 4 waves x 64 samples, 2 blocks/CU (2 waves/SIMD, ~244 VGPRs), every
 // A fragment feeds two MFMAs.  CT = 1: 8 waves x 32 samples, 2 blocks/CU (4 waves/SIMD, <= 128 VGPRs): more waves to
 // cover each other's encode/convert phases, one LDS read per MFMA.
@@ -290,7 +411,7 @@ __global__ __launch_bounds__(256, CT == 2 ? 2 : 1) void mlp_fwd_kernel(FwdArgs a
   load_inputs(blockIdx.x);
 
   for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    // ---- this wave's two column tiles -> first-layer B fragments ----
+    // ---- per-tile state; the encoding itself happens inside layer 0 (pipe_layer0) ----
     half8 bf[NB][CT];
     float d0[CT], dr[CT];
     const float phase = 0.25f * (float)h;
@@ -298,26 +419,25 @@ __global__ __launch_bounds__(256, CT == 2 ? 2 : 1) void mlp_fwd_kernel(FwdArgs a
     for (int ct = 0; ct < CT; ++ct) {
       d0[ct] = d0_n[ct];
       dr[ct] = dr_n[ct];
-#pragma unroll
-      for (int kk = 0; kk < KS0; ++kk) {
-        half8 v;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-#if RTXN_ABLATE & 1
-          v[j] = (_Float16)(xin[ct][j % 5] + phase);   // timing experiment only
-#else
-          v[j] = encode_slot<ES, PD, PF, DD, DF>(8 * kk + j, xin[ct], phase);
-#endif
-        }
-        bf[kk][ct] = v;
-      }
       if (IN_MODE == 1 && OUT_MODE != 2 && a.t_vals && h == 0) {
         bool valid;
         const long samp = sample_of(tile, ct, valid);
         if (valid) a.t_vals[samp] = (float)(col + 1) * (1.0f / 32);
       }
     }
-    if (tile + gridDim.x < n_tiles) load_inputs(tile + gridDim.x);
+
+#ifdef RTXN_L0_PLAIN
+    // all of layer 0's B fragments encoded up front (the variant pipe_layer0 replaces; kept for A/B timing)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int kk = 0; kk < KS0; ++kk) {
+        half8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = encode_slot<ES, PD, PF, DD, DF>(8 * kk + j, xin[ct], phase);
+        bf[kk][ct] = v;
+      }
+#endif
 
     // ---- layers ----  (two fragment sets used ping-pong: no register copies between layers)
     half8 bg[NB][CT];
@@ -328,7 +448,7 @@ __global__ __launch_bounds__(256, CT == 2 ? 2 : 1) void mlp_fwd_kernel(FwdArgs a
       const uint8_t* cur = smem + (q & 1) * BUF;
       sj.lds = smem + ((q + 1) & 1) * BUF;
 #if !(RTXN_ABLATE & 2)
-      __syncthreads();  // stage q landed (hipcc drains vmcnt before the barrier); the other buffer is free
+      rtxn::staged_barrier();  // stage q landed; the other buffer is free
 #endif
       if (RTXN_ABLATE & 4) {
         sj.g = a.packed, sj.nfrags = 0;
@@ -337,6 +457,9 @@ __global__ __launch_bounds__(256, CT == 2 ? 2 : 1) void mlp_fwd_kernel(FwdArgs a
       } else {
         sj.g = a.packed, sj.nfrags = tile + gridDim.x < n_tiles ? L0_BYTES / 1024 : 0;
       }
+      // next tile's inputs, one tile ahead: issued behind the first barrier after layer 0 (which still reads this tile's),
+      // so that no staged_barrier ever waits on them before they have had a whole layer to land
+      if (l == 1 && tile + gridDim.x < n_tiles) load_inputs(tile + gridDim.x);
       ++q;
       return cur;
     };
@@ -378,7 +501,16 @@ __global__ __launch_bounds__(256, CT == 2 ? 2 : 1) void mlp_fwd_kernel(FwdArgs a
     // every layer leaves its last row tile pending in acc2[1]; the next one converts it under its first MFMAs
     {
       const uint8_t* w = begin_stage(0);
+#if RTXN_ABLATE & 1
+      for (int kk = 0; kk < KS0; ++kk)
+        for (int ct = 0; ct < CT; ++ct)
+          for (int j = 0; j < 8; ++j) bf[kk][ct][j] = (_Float16)(xin[ct][j % 5] + phase);   // timing experiment only
       pipe_layer<RT, KS0, NB, CT, false>(w, sj, bf, bg, acc2, wave_u, lane);
+#elif defined(RTXN_L0_PLAIN)
+      pipe_layer<RT, KS0, NB, CT, false>(w, sj, bf, bg, acc2, wave_u, lane);
+#else
+      pipe_layer0<ES, PD, PF, DD, DF, RT, KS0, NB, CT>(w, sj, xin, phase, bg, acc2[1], wave_u, lane);
+#endif
     }
     int l = 1;
     for (; l + 1 < n_layers - 1; l += 2) {  // activations in bg at the top
@@ -438,36 +570,6 @@ __global__ __launch_bounds__(kThreads256, 2) void mlp_fwd256_kernel(FwdArgs a) {
   const int n_chunks = 4 + 4 * (a.n_hidden - 1) + 1;
   const long g_end = my_tiles * n_chunks;
   long g = 0;  // chunks consumed so far by this block
-  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  // chunk gi of this block's stream: offset and size in the packed buffer
-  auto chunk_src = [&](long gi, int& size) -> long {
-    const int i = (int)(gi % n_chunks);
-    if (i < 4) { size = 2 * KS0 * 1024; return (long)i * size; }
-    if (i < n_chunks - 1) { size = 2 * KS * 1024; return 4L * 2 * KS0 * 1024 + (long)(i - 4) * size; }
-    size = KS * 1024;
-    return 4L * 2 * KS0 * 1024 + (long)(n_chunks - 5) * 2 * KS * 1024;
-  };
-  auto issue = [&](long gi) {
-    int size;
-    const long off = chunk_src(gi, size);
-    stage512(a.packed + off, smem + (gi % 3) * kSlot256, size, tid);
-  };
-  issue(0);
-  if (g_end > 1) issue(1);
-  // barrier, then: the slot holding chunk g, and the job that fetches chunk g+2 into the slot chunk g-1 just left
-  rtxn::StageJob sj;
-  auto next_chunk = [&]() -> const uint8_t* {
-    __syncthreads();  // chunk g landed (vmcnt drained before the barrier); everyone is done with chunk g-1
-    int size = 0;
-    const long off = g + 2 < g_end ? chunk_src(g + 2, size) : 0;
-    sj.g = a.packed + off;
-    sj.lds = smem + ((g + 2) % 3) * kSlot256;
-    sj.nfrags = size / 1024;
-    const uint8_t* p = smem + (g % 3) * kSlot256;
-    ++g;
-    return p;
-  };
-
   float xin[5];
   bool valid_n;
   long samp_n;
@@ -505,6 +607,39 @@ __global__ __launch_bounds__(kThreads256, 2) void mlp_fwd256_kernel(FwdArgs a) {
       for (int c = 0; c < 5; ++c) xin[c] = a.input[5 * sidx + c];
     }
   };
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  // chunk gi of this block's stream: offset and size in the packed buffer
+  auto chunk_src = [&](long gi, int& size) -> long {
+    const int i = (int)(gi % n_chunks);
+    if (i < 4) { size = 2 * KS0 * 1024; return (long)i * size; }
+    if (i < n_chunks - 1) { size = 2 * KS * 1024; return 4L * 2 * KS0 * 1024 + (long)(i - 4) * size; }
+    size = KS * 1024;
+    return 4L * 2 * KS0 * 1024 + (long)(n_chunks - 5) * 2 * KS * 1024;
+  };
+  auto issue = [&](long gi) {
+    int size;
+    const long off = chunk_src(gi, size);
+    stage512(a.packed + off, smem + (gi % 3) * kSlot256, size, tid);
+  };
+  issue(0);
+  if (g_end > 1) issue(1);
+  // barrier, then: the slot holding chunk g, and the job that fetches chunk g+2 into the slot chunk g-1 just left
+  rtxn::StageJob sj;
+  int chunk_in_tile = 0;
+  long prefetch_tile = -1;   // tile whose inputs are fetched one tile ahead
+  auto next_chunk = [&]() -> const uint8_t* {
+    rtxn::staged_barrier();  // chunk g landed; everyone is done with chunk g-1
+    if (chunk_in_tile++ == 1 && prefetch_tile >= 0) load_inputs(prefetch_tile);   // behind a barrier: never waited on early
+    int size = 0;
+    const long off = g + 2 < g_end ? chunk_src(g + 2, size) : 0;
+    sj.g = a.packed + off;
+    sj.lds = smem + ((g + 2) % 3) * kSlot256;
+    sj.nfrags = size / 1024;
+    const uint8_t* p = smem + (g % 3) * kSlot256;
+    ++g;
+    return p;
+  };
+
   load_inputs(blockIdx.x);
 
   for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -521,7 +656,8 @@ __global__ __launch_bounds__(kThreads256, 2) void mlp_fwd256_kernel(FwdArgs a) {
       bf[kk][0] = v;
     }
     if (IN_MODE == 1 && OUT_MODE != 2 && a.t_vals && valid && h == 0) a.t_vals[samp] = (float)(col + 1) * (1.0f / 32);
-    if (tile + gridDim.x < n_tiles) load_inputs(tile + gridDim.x);
+    chunk_in_tile = 0;
+    prefetch_tile = tile + gridDim.x < n_tiles ? tile + gridDim.x : -1;
 
     // A layer = 4 chunks of two row tiles; the second row tile of every chunk stays pending in acc2[1] and is converted
     // under the next chunk's MFMAs (mlp_internal.h, PipeStep256).

@@ -60,6 +60,15 @@ __device__ __forceinline__ void stage_rt(const uint8_t* __restrict__ g, uint8_t*
   }
 }
 
+// Barrier that publishes LDS-DMA-staged fragments to the workgroup.  LDS-DMA completion is tracked by vmcnt only, and
+// hipcc does NOT reliably drain vmcnt in front of s_barrier (gfx950 has back-off barriers; the wait appeared only where
+// an unrelated dependency forced one, and a re-ordered kernel lost it: rare whole-tile errors, found by the re-render
+// determinism test).  Every wave must have its own DMA pieces landed BEFORE it arrives, so the wait is explicit.
+__device__ __forceinline__ void staged_barrier() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
 // f32 pair -> packed f16 (v_cvt_pk_f16_f32), optional ReLU as a signed-integer max on the packed
 // halves (v_pk_max_i16): a negative half is a negative int16 and rounding is monotone, so this is
 // fp16(max(x,0)) at one VALU op per two values and without the canonicalising v_max hipcc puts in

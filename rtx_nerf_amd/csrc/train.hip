@@ -227,7 +227,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_train_fwd_kernel(TrainArgs a)
   half8 bf[KS][2], bg[KS][2];
   {
     stage_rt(a.packed, smem, KS0 * RT * 1024, tid);
-    __syncthreads();
+    rtxn::staged_barrier();
     floatx16 acc[RT][2];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -276,13 +276,13 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_train_fwd_kernel(TrainArgs a)
   for (; l + 1 < L; l += 2) {
     __syncthreads();
     stage_rt(a.packed + off, smem, KS * RT * 1024, tid);
-    __syncthreads();
+    rtxn::staged_barrier();
     layer_mma<RT, KS, KS>(smem, bf, bg, lane);
     save_acts(l, bg);
     off += (long)KS * RT * 1024;
     __syncthreads();
     stage_rt(a.packed + off, smem, KS * RT * 1024, tid);
-    __syncthreads();
+    rtxn::staged_barrier();
     layer_mma<RT, KS, KS>(smem, bg, bf, lane);
     save_acts(l + 1, bf);
     off += (long)KS * RT * 1024;
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_train_fwd_kernel(TrainArgs a)
   if (l < L) {
     __syncthreads();
     stage_rt(a.packed + off, smem, KS * RT * 1024, tid);
-    __syncthreads();
+    rtxn::staged_barrier();
     layer_mma<RT, KS, KS>(smem, bf, bg, lane);
     save_acts(l, bg);
     off += (long)KS * RT * 1024;
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_train_fwd_kernel(TrainArgs a)
   // ---- output layer ----
   __syncthreads();
   stage_rt(a.packed + off, smem, KS * 1024, tid);
-  __syncthreads();
+  rtxn::staged_barrier();
   floatx16 acc[2];
   out_mma<KS, KS>(smem, bf, acc, lane);
 #pragma unroll
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_bwd_kernel(TrainArgs a) {
   }
   floatx16 dA[RT][2];
   stage_rt(a.packed, smem, RT * 1024, tid);
-  __syncthreads();
+  rtxn::staged_barrier();
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     const half8 af = *reinterpret_cast<const half8*>(smem + (rt * 64 + lane) * 16);
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_bwd_kernel(TrainArgs a) {
     const int rows_t = l == 0 ? (a.E + 31) / 32 : RT;
     __syncthreads();
     stage_rt(a.packed + off, smem, rows_t * KS * 1024, tid);
-    __syncthreads();
+    rtxn::staged_barrier();
     off += (long)rows_t * KS * 1024;
     if (l > 0) {
 #pragma unroll
