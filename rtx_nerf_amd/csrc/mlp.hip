@@ -47,6 +47,9 @@ using rtxn::pipe_layer;
 #ifndef RTXN_DBG
 #define RTXN_DBG 0
 #endif
+#ifndef RTXN_SKEW
+#define RTXN_SKEW 1
+#endif
 #ifndef RTXN_ABLATE
 #define RTXN_ABLATE 0   // timing experiments (tools/ablate.sh): 1 no encode, 2 no barrier, 4 no weight staging -- results are wrong
 #endif
@@ -258,8 +261,8 @@ __device__ __forceinline__ void encode_units(const float (&xin)[CT][5], float ph
 
 template <class ES, int PD, int PF, int DD, int DF, int RT, int KS0, int NB, int CT, int I>
 struct Layer0Step {
-  static constexpr int D = RTXN_PIPE, N = RT * KS0, WAVES = 4;
-  static constexpr int CHUNKS = N < 8 ? N : 8;
+  static constexpr int D = RTXN_PIPE, N = RT * KS0, WAVES = RTXN_NW;
+  static constexpr int CHUNKS = N < 32 / WAVES ? N : 32 / WAVES;
   static constexpr int UE = (4 * CT + RT - 1) / RT;   // encode units per (kk, rt) sub-step
   __device__ static __forceinline__ void run(unsigned addr, const float (&xin)[CT][5], float phase, half8 (&b)[2][CT],
                                              half8 (&out)[NB][CT], half8 (&ring)[D], floatx16 (&acc)[RT][CT],
@@ -323,15 +326,23 @@ __device__ __forceinline__ void pipe_layer0(const uint8_t* lds_buf, const rtxn::
 // A fragment feeds two MFMAs.  CT = 1: 8 waves x 32 samples, 2 blocks/CU (4 waves/SIMD, <= 128 VGPRs): more waves to
 // cover each other's encode/convert phases, one LDS read per MFMA.
 template <int W, int PD, int PF, int DD, int DF, int IN_MODE, int OUT_MODE, int CT>
-__global__ __launch_bounds__(256, CT == 2 ? 2 : 1) void mlp_fwd_kernel(FwdArgs a) {
-  constexpr int THREADS = 256;
-  constexpr int TILE = 128 * CT, TILE_SEGS = 4 * CT;   // samples / segments per block per iteration
+__global__ __launch_bounds__(64 * RTXN_NW, CT == 2 ? 2 : 1) void mlp_fwd_kernel(FwdArgs a) {
+  constexpr int THREADS = 64 * RTXN_NW;
+  constexpr int TILE = 32 * RTXN_NW * CT, TILE_SEGS = RTXN_NW * CT;   // samples / segments per block per iteration
   using ES = EncSpec<PD, PF, DD, DF>;
   constexpr int RT = W / 32, KS = W / 16, KS0 = ES::k0 / 16;
   constexpr int NB = KS0 > KS ? KS0 : KS;
   constexpr int L0_BYTES = KS0 * RT * 1024, HID_BYTES = KS * RT * 1024, OUT_BYTES = KS * 1024;
   constexpr int BUF = L0_BYTES > HID_BYTES ? L0_BYTES : HID_BYTES;
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 2 * BUF
+  // SKEW (8-wave blocks): waves 0-3 (group A) and 4-7 (group B, the other wave of each SIMD) run the same program one
+  // stage apart, so that one group's VALU-bound layer 0 (the encoder) always overlaps the other group's MFMA-bound
+  // stages instead of both hitting it together.  The offset costs nothing to arrange: B executes one extra barrier
+  // before its first stage and A one after its last -- s_barrier only counts arrivals.  What it needs is LDS: layer 0
+  // and the output layer stay resident (fetched once per launch), hidden layers stream through a ring of THREE slots
+  // (A's stage, B's stage, the one being fetched); every wave fetches its share of the stage group A needs NEXT.
+  constexpr bool SKEW = RTXN_SKEW && RTXN_NW == 8;
+  constexpr int RES_BYTES = L0_BYTES + OUT_BYTES;   // SKEW: [layer 0 | output layer | 3 x HID_BYTES]
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // SKEW ? RES_BYTES + 3 * HID_BYTES : 2 * BUF
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // the same number, known to hipcc as wave-uniform
@@ -354,9 +365,12 @@ __global__ __launch_bounds__(256, CT == 2 ? 2 : 1) void mlp_fwd_kernel(FwdArgs a
     return (long)L0_BYTES + (long)(l - 1) * HID_BYTES;
   };
 
-  // prologue: layer 0 of the first tile
+  const int grp = SKEW ? wave_u >> 2 : 0;   // 0: leading group, 1: one stage behind
+  const int n_hid = n_layers - 2;           // streamed (hidden) stages per tile
+  // prologue: layer 0 of the first tile (SKEW: the two resident layers)
   stage<L0_BYTES, THREADS>(a.packed, smem, tid);
-  int q = 0;  // global stage counter: buffer = q & 1
+  if (SKEW) stage<OUT_BYTES, THREADS>(a.packed + layer_off(n_layers - 1), smem + L0_BYTES, tid);
+  int q = 0;  // global stage counter: buffer = q & 1 (SKEW: hidden-stage counter of this wave, slot = q % 3)
 
   // Inputs are fetched ONE TILE AHEAD: the loads for tile t+1 are issued right after tile t's
   // encoding and have the whole layer stack of tile t to land (the first barrier drains them).
@@ -410,6 +424,17 @@ __global__ __launch_bounds__(256, CT == 2 ? 2 : 1) void mlp_fwd_kernel(FwdArgs a
   };
   load_inputs(blockIdx.x);
 
+  if (SKEW && grp == 1) {
+    // group B's bubble: its share of the first streamed stage, then the barrier that puts it one stage behind
+    if (n_hid > 0 && !(RTXN_ABLATE & 4)) {
+      rtxn::StageJob sj0{a.packed + layer_off(1), smem + RES_BYTES, HID_BYTES / 1024};
+      rtxn::stage_chunk<0, 8>(sj0, wave_u, lane);
+      rtxn::stage_chunk<1, 8>(sj0, wave_u, lane);
+      rtxn::stage_chunk<2, 8>(sj0, wave_u, lane);
+      rtxn::stage_chunk<3, 8>(sj0, wave_u, lane);
+    }
+    rtxn::staged_barrier();
+  }
   for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     // ---- per-tile state; the encoding itself happens inside layer 0 (pipe_layer0) ----
     half8 bf[NB][CT];
@@ -442,25 +467,43 @@ __global__ __launch_bounds__(256, CT == 2 ? 2 : 1) void mlp_fwd_kernel(FwdArgs a
     // ---- layers ----  (two fragment sets used ping-pong: no register copies between layers)
     half8 bg[NB][CT];
     floatx16 acc2[2][CT];
-    // barrier, then: the LDS buffer holding layer l and the job that fetches the following stage into the other one
+    // barrier, then: the LDS buffer holding layer l, and the job (this wave's share) that fetches a following stage
     rtxn::StageJob sj;
     auto begin_stage = [&](int l) -> const uint8_t* {
-      const uint8_t* cur = smem + (q & 1) * BUF;
-      sj.lds = smem + ((q + 1) & 1) * BUF;
+      const uint8_t* cur;
 #if !(RTXN_ABLATE & 2)
-      rtxn::staged_barrier();  // stage q landed; the other buffer is free
+      rtxn::staged_barrier();  // every wave's share of this stage has landed; the slot fetched into next is free
 #endif
-      if (RTXN_ABLATE & 4) {
-        sj.g = a.packed, sj.nfrags = 0;
-      } else if (l + 1 < n_layers) {
-        sj.g = a.packed + layer_off(l + 1), sj.nfrags = (l + 1 == n_layers - 1 ? OUT_BYTES : HID_BYTES) / 1024;
+      if (SKEW) {
+        // q = hidden stages this wave has begun = instance number of its next hidden stage; instance i lives in ring
+        // slot i % 3.  This wave runs layer l; the stage group A needs next is layer l + 1 + grp (wrapping into the next
+        // tile), and this wave fetches its share of it if it is a streamed one.
+        const bool hidden = l > 0 && l < n_layers - 1;
+        cur = l == 0 ? smem : (hidden ? smem + RES_BYTES + (q % 3) * HID_BYTES : smem + L0_BYTES);
+        const int h0 = l == 0 ? 0 : (hidden ? l - 1 : n_hid);      // hidden stages of this tile begun before this stage
+        int lk = l + 1 + grp, inst = q - h0;                        // inst: instance number of this tile's first hidden stage
+        bool exists = true;
+        if (lk >= n_layers) { lk -= n_layers; inst += n_hid; exists = tile + gridDim.x < n_tiles; }
+        const bool fetch = exists && lk > 0 && lk < n_layers - 1 && !(RTXN_ABLATE & 4);
+        sj.g = a.packed + layer_off(fetch ? lk : 0);
+        sj.lds = smem + RES_BYTES + ((inst + lk - 1) % 3) * HID_BYTES;
+        sj.nfrags = fetch ? HID_BYTES / 1024 : 0;
+        if (hidden) ++q;
       } else {
-        sj.g = a.packed, sj.nfrags = tile + gridDim.x < n_tiles ? L0_BYTES / 1024 : 0;
+        cur = smem + (q & 1) * BUF;
+        sj.lds = smem + ((q + 1) & 1) * BUF;
+        if (RTXN_ABLATE & 4) {
+          sj.g = a.packed, sj.nfrags = 0;
+        } else if (l + 1 < n_layers) {
+          sj.g = a.packed + layer_off(l + 1), sj.nfrags = (l + 1 == n_layers - 1 ? OUT_BYTES : HID_BYTES) / 1024;
+        } else {
+          sj.g = a.packed, sj.nfrags = tile + gridDim.x < n_tiles ? L0_BYTES / 1024 : 0;
+        }
+        ++q;
       }
       // next tile's inputs, one tile ahead: issued behind the first barrier after layer 0 (which still reads this tile's),
       // so that no staged_barrier ever waits on them before they have had a whole layer to land
       if (l == 1 && tile + gridDim.x < n_tiles) load_inputs(tile + gridDim.x);
-      ++q;
       return cur;
     };
     auto finish = [&](half8 (&in)[NB][CT], half8 (&other)[NB][CT]) {
@@ -527,6 +570,7 @@ __global__ __launch_bounds__(256, CT == 2 ? 2 : 1) void mlp_fwd_kernel(FwdArgs a
       finish(bg, bf);
     }
   }
+  if (SKEW && grp == 0) rtxn::staged_barrier();   // pairs with group B's last stage barrier (B began one barrier late)
 }
 
 // ---------------------------------------------------------------------------
@@ -746,10 +790,10 @@ Variant make_variant() {
   v.fn[0][2] = nullptr;
   v.fn[1][2] = mlp_fwd_kernel<W, PD, PF, DD, DF, 1, 2, CT>;
   v.k0 = ES::k0;
-  v.lds = 2 * (size_t)(L0 > HID ? L0 : HID);
-  v.threads = 256;
-  v.blocks_per_cu = CT == 2 ? 2 : 1;
-  v.tile = 128 * CT;
+  v.lds = (RTXN_SKEW && RTXN_NW == 8) ? (size_t)L0 + KS * 1024 + 3 * (size_t)HID : 2 * (size_t)(L0 > HID ? L0 : HID);
+  v.threads = 64 * RTXN_NW;
+  v.blocks_per_cu = (CT == 2 ? 2 : 1) * 4 / RTXN_NW;
+  v.tile = 32 * RTXN_NW * CT;
   return v;
 }
 

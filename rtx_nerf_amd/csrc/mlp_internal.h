@@ -127,6 +127,9 @@ __host__ __device__ __forceinline__ int perm_feature(int kk, int h, int j) { ret
 #ifndef RTXN_PIPE
 #define RTXN_PIPE 3
 #endif
+#ifndef RTXN_NW
+#define RTXN_NW 8   // waves per block of the 64/128-wide inference kernel (8: one 8-wave block per CU shares each staged layer)
+#endif
 typedef int int4v __attribute__((ext_vector_type(4)));
 
 template <int OFF>
@@ -191,8 +194,8 @@ struct PipeStep {
   static constexpr int U = (8 * CT + KS - 1) / KS;                 // units per k-step, row tiles 1..
   static constexpr int WIN = KS - 3 > 1 ? KS - 3 : 1;              // k-steps of row tile 0 the pending tile is spread over
   static constexpr int UP = (8 * CT + WIN - 1) / WIN;
-  static constexpr int WAVES = 4;
-  static constexpr int CHUNKS = N < 8 ? N : 8;                     // k-steps that carry a staging chunk: up to 32 KiB
+  static constexpr int WAVES = RTXN_NW;
+  static constexpr int CHUNKS = N < 32 / WAVES ? N : 32 / WAVES;   // k-steps that carry a staging chunk: up to 32 KiB
   __device__ static __forceinline__ void run(unsigned addr, half8 (&bf)[NB][CT], half8 (&nbf)[NB][CT], half8 (&ring)[D],
                                              floatx16 (&acc)[2][CT], const StageJob& sj, int wave_u, int lane) {
     constexpr int rt = I / KS, kk = I % KS, cur = rt & 1;
