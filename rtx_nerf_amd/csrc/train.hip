@@ -155,19 +155,44 @@ __global__ __launch_bounds__(kThreads) void hashgrid_backward_kernel(HgLevels lv
     __syncthreads();
   }
   const long s_begin = LDS ? (long)blockIdx.x * kHgChunk : (long)blockIdx.x * kThreads;
-  const long s_end = LDS ? (s_begin + kHgChunk < S ? s_begin + kHgChunk : S) : (s_begin + kThreads < S ? s_begin + kThreads : S);
+  const long s_end = LDS ? (s_begin + kHgChunk < S ? s_begin + kHgChunk : S) : s_begin + kThreads;   // !LDS: one pass, every lane stays
+  const int lane = threadIdx.x & 63;
   for (long s = s_begin + threadIdx.x; s < s_end; s += kThreads) {
+    const bool ok = s < S;
     float fr[3];
     unsigned g[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      const float x01 = fmaf(in[5 * s + a], 0.5f, 0.5f);
+      const float x01 = fmaf(ok ? in[5 * s + a] : 0.0f, 0.5f, 0.5f);
       const float p = fmaf(x01, lv.scale[l], 0.5f), fl = floorf(p);
       g[a] = (unsigned)(int)fl;
       fr[a] = p - fl;
     }
     float d[8];
-    for (int f = 0; f < F && f < 8; ++f) d[f] = (float)dencT[(long)(l * F + f) * Sp + s];
+    for (int f = 0; f < F && f < 8; ++f) d[f] = ok ? (float)dencT[(long)(l * F + f) * Sp + s] : 0.0f;
+    // !LDS (levels too large for an LDS copy): consecutive lanes are consecutive samples of a segment, so runs of lanes
+    // share a grid cell and with it all eight corner addresses -- up to 32 lanes on the coarser of these levels.  A
+    // segmented inclusive scan over each run (keyed on the cell) leaves the run's sum in its last lane, which alone issues
+    // the atomic: the L2 atomic units see one add per run instead of one per sample (they, not HBM, bound this kernel).
+    int run_start = lane;
+    bool run_last = true;
+    bool aggregate = false;
+    if (!LDS) {
+      const unsigned k0 = ok ? (g[0] | (g[1] << 16)) : 0xffffffffu, k1 = ok ? g[2] : (unsigned)lane;
+      const unsigned p0 = __shfl_up(k0, 1, 64), p1 = __shfl_up(k1, 1, 64);
+      const bool head = lane == 0 || p0 != k0 || p1 != k1;
+      aggregate = __ballot(head) != ~0ull;   // wave-uniform: finest levels have no runs and skip the scans
+      if (aggregate) {
+        run_start = head ? lane : 0;
+#pragma unroll
+        for (int dlt = 1; dlt < 64; dlt <<= 1) {
+          const int t = __shfl_up(run_start, dlt, 64);
+          if (lane >= dlt && t > run_start) run_start = t;
+        }
+        const int next_head = __shfl_down((int)head, 1, 64);
+        run_last = lane == 63 || next_head != 0;
+      }
+    }
 #pragma unroll
     for (int corner = 0; corner < 8; ++corner) {
       float w = 1.0f;
@@ -180,10 +205,18 @@ __global__ __launch_bounds__(kThreads) void hashgrid_backward_kernel(HgLevels lv
       }
       const unsigned idx = hg_index(p[0], p[1], p[2], lv.res[l], lv.size[l]);
       for (int f = 0; f < F && f < 8; ++f) {
-        const float v = w * d[f];
-        if (v != 0.0f) {
-          if (LDS) atomicAdd(&hist[idx * F + f], v);
-          else atomicAdd(&gdst[(size_t)idx * F + f], v);
+        float v = w * d[f];
+        if (LDS) {
+          if (v != 0.0f) atomicAdd(&hist[idx * F + f], v);
+        } else {
+          if (aggregate) {
+#pragma unroll
+            for (int dlt = 1; dlt < 64; dlt <<= 1) {
+              const float t = __shfl_up(v, dlt, 64);
+              if (lane - dlt >= run_start) v += t;
+            }
+          }
+          if (ok && run_last && v != 0.0f) atomicAdd(&gdst[(size_t)idx * F + f], v);
         }
       }
     }
@@ -451,15 +484,33 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_bwd_kernel(TrainArgs a) {
 }
 
 // ------------------------------------------------------------------------- weight gradient
-// dW[o][i] += sum_s dZ[o][s] * X[i][s].  One wave = one 64x64 output super-tile over a chunk of
-// samples; grid = (super-tiles, sample chunks); block = 4 waves on 4 consecutive chunks.
-__global__ __launch_bounds__(kThreads) void wgrad_kernel(const _Float16* __restrict__ dZ, const _Float16* __restrict__ X,
-                                                         float* __restrict__ dW, int M, int N, long Sp, int tiles_n,
-                                                         long chunk) {
+// dW_l[o][i] += sum_s dZ_l[o][s] * X_l[i][s] for every layer l in ONE launch.  One wave = one 64x64 output super-tile
+// of one layer over a chunk of samples; grid = (super-tiles of the widest layer, sample chunks / 4, layers); block = 4
+// waves on 4 consecutive chunks.  The contraction runs over samples, so each MFMA operand fragment (8 consecutive
+// samples of one feature row of the feature-major tensors) is one 16-byte load; the loop is unrolled 4 k-steps deep with
+// all 16 loads issued before the first MFMA (a wave is latency-bound otherwise: ~2 us per dependent load round).
+struct WgradLayer {
+  const _Float16* dZ;
+  const _Float16* X;
+  float* dW;
+  int M, N, tiles_n, n_tiles;
+};
+struct WgradArgs {
+  WgradLayer layer[17];
+  long Sp, chunk;
+};
+
+__global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
+  const WgradLayer& L = a.layer[blockIdx.z];
+  if ((int)blockIdx.x >= L.n_tiles) return;
+  const _Float16* __restrict__ dZ = L.dZ;
+  const _Float16* __restrict__ X = L.X;
+  const int M = L.M, N = L.N;
+  const long Sp = a.Sp;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
-  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
-  const long s_begin = ((long)blockIdx.y * 4 + wave) * chunk;
-  const long s_end = s_begin + chunk < Sp ? s_begin + chunk : Sp;
+  const int tm = blockIdx.x / L.tiles_n, tn = blockIdx.x % L.tiles_n;
+  const long s_begin = ((long)blockIdx.y * 4 + wave) * a.chunk;
+  const long s_end = s_begin + a.chunk < Sp ? s_begin + a.chunk : Sp;
   if (s_begin >= Sp) return;
   floatx16 acc[2][2];
 #pragma unroll
@@ -469,18 +520,30 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(const _Float16* __restr
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
   const int row0 = 64 * tm + r, row1 = row0 + 32, col0 = 64 * tn + r, col1 = col0 + 32;
-  const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (long s = s_begin; s < s_end; s += 16) {
-    const long so = s + 8 * h;
-    const half8 a0 = row0 < M ? *reinterpret_cast<const half8*>(dZ + (long)row0 * Sp + so) : zero;
-    const half8 a1 = row1 < M ? *reinterpret_cast<const half8*>(dZ + (long)row1 * Sp + so) : zero;
-    const half8 b0 = col0 < N ? *reinterpret_cast<const half8*>(X + (long)col0 * Sp + so) : zero;
-    const half8 b1 = col1 < N ? *reinterpret_cast<const half8*>(X + (long)col1 * Sp + so) : zero;
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
+  // rows beyond the layer read row 0 (valid memory) and are masked at the store
+  const _Float16* pa0 = dZ + (long)(row0 < M ? row0 : 0) * Sp + 8 * h;
+  const _Float16* pa1 = dZ + (long)(row1 < M ? row1 : 0) * Sp + 8 * h;
+  const _Float16* pb0 = X + (long)(col0 < N ? col0 : 0) * Sp + 8 * h;
+  const _Float16* pb1 = X + (long)(col1 < N ? col1 : 0) * Sp + 8 * h;
+  constexpr int U = 4;   // Sp and the chunk are multiples of 256: whole groups of U k-steps
+  for (long s = s_begin; s < s_end; s += 16 * U) {
+    half8 a0[U], a1[U], b0[U], b1[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      a0[u] = *reinterpret_cast<const half8*>(pa0 + s + 16 * u);
+      a1[u] = *reinterpret_cast<const half8*>(pa1 + s + 16 * u);
+      b0[u] = *reinterpret_cast<const half8*>(pb0 + s + 16 * u);
+      b1[u] = *reinterpret_cast<const half8*>(pb1 + s + 16 * u);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[u], b0[u], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[u], b1[u], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[u], b0[u], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[u], b1[u], acc[1][1], 0, 0, 0);
+    }
   }
+  float* __restrict__ dW = L.dW;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -649,19 +712,28 @@ extern "C" int rtxn_mlp_train_backward(const rtxn_mlp* m, const void* encT, cons
     hipLaunchKernelGGL(mlp_bwd_kernel<128>, dim3((unsigned)(Sp / kTile)), dim3(kThreads), lds, s, a);
   }
   RTXN_LAUNCH_CHECK("mlp_bwd_kernel");
-  // per-layer weight gradients: dW_l += dZ_l X_l^T, X_0 = enc, X_l = acts[l-1], X_L = acts[L-1]
-  const long chunk = 2048;
-  const unsigned kblocks = (unsigned)((Sp + 4 * chunk - 1) / (4 * chunk));
+  // weight gradients of all layers in one launch: dW_l += dZ_l X_l^T, X_0 = enc, X_l = acts[l-1], X_L = acts[L-1]
+  RTXN_REQUIRE(L + 1 <= 17, "rtxn_mlp_train_backward: %d layers exceed the weight-gradient launch table", L + 1);
+  WgradArgs wa;
+  wa.Sp = Sp;
+  wa.chunk = 1024;
+  const unsigned kblocks = (unsigned)((Sp + 4 * wa.chunk - 1) / (4 * wa.chunk));
   long poff = 0;
+  int max_tiles = 0;
   for (int l = 0; l <= L; ++l) {
     const int M = l == L ? 16 : W, N = l == 0 ? E : W;
-    const _Float16* dz = l == L ? a.dzL : a.dz + (long)l * W * Sp;
-    const _Float16* x = l == 0 ? a.encT : a.acts + (long)(l - 1) * W * Sp;
-    const int tiles_m = (M + 63) / 64, tiles_n = (N + 63) / 64;
-    wgrad_kernel<<<dim3((unsigned)(tiles_m * tiles_n), kblocks), kThreads, 0, s>>>(dz, x, dparams + poff, M, N, Sp, tiles_n, chunk);
-    RTXN_LAUNCH_CHECK("wgrad_kernel");
+    WgradLayer& wl = wa.layer[l];
+    wl.dZ = l == L ? a.dzL : a.dz + (long)l * W * Sp;
+    wl.X = l == 0 ? a.encT : a.acts + (long)(l - 1) * W * Sp;
+    wl.dW = dparams + poff;
+    wl.M = M, wl.N = N;
+    wl.tiles_n = (N + 63) / 64;
+    wl.n_tiles = ((M + 63) / 64) * wl.tiles_n;
+    if (wl.n_tiles > max_tiles) max_tiles = wl.n_tiles;
     poff += (long)M * N;
   }
+  wgrad_kernel<<<dim3((unsigned)max_tiles, kblocks, (unsigned)(L + 1)), kThreads, 0, s>>>(wa);
+  RTXN_LAUNCH_CHECK("wgrad_kernel");
   return RTXN_OK;
 }
 
