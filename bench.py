@@ -65,6 +65,10 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--fused", action="store_true", help="per-segment compositing in the MLP epilogue (measured slower: frame is MFMA-bound)")
     ap.add_argument("--kernel-steps", type=int, default=5, help="extra frames with HIP events around the MLP kernel")
+    ap.add_argument("--serial", action="store_true", help="one stream, stages of a frame strictly one after another (no frame pipelining)")
+    ap.add_argument("--emulate-shard-of", type=int, default=0, metavar="N", help="diagnostic, single process: render only rank 0's "
+                    "row shard of an N-rank run (no collective) to see what one rank's frame costs; the JSON line is marked "
+                    "'emulated_shard_of' and its value is NOT a whole-job figure")
     return ap.parse_args()
 
 
@@ -109,7 +113,7 @@ def main():
         poses = [scenes.pose_forward_facing(0.3 * np.cos(i), 0.2 * np.sin(i)) for i in range(args.poses)]
 
     # ray shard of this rank: image rows rank, rank+world, ... (rtx_nerf_amd/shard.py)
-    sh = RowShard(W, H, rank, world)
+    sh = RowShard(W, H, 0, args.emulate_shard_of) if (args.emulate_shard_of > 1 and world == 1) else RowShard(W, H, rank, world)
     n_local, ray_begin = sh.n_local, sh.ray_begin
     pipe = render.RenderPipeline(net, R, W, H, focal, occupancy=occ, max_rays=n_local, max_segments=1024,
                                  window=sh.window, fused=args.fused)
@@ -123,21 +127,31 @@ def main():
         if (world > 1 and rank == 0) else [None, None]
     pending = [None, None]
 
+    # Frames are software-pipelined (render.py, render_async): traversal of frame i+1 and compositing of frame i-1 run on
+    # side streams underneath the MLP kernel of frame i; every step still enqueues exactly one full frame of every stage.
     def step(i):
         b = i & 1
-        if pending[b] is not None:
-            pending[b].wait()           # frame i-2's gather is done with this buffer
-            pending[b] = None
-        pipe.look_at.copy_(poses_d[i % len(poses_d)], non_blocking=True)
-        pipe.render(ray_begin=ray_begin, ray_count=n_local, out=pix_bufs[b][:n_local])
-        if world > 1:
-            pending[b] = sh.gather(pix_bufs[b], gather_bufs[b], async_op=True)
+        pix, done, comp = pipe.render_async(poses_d[i % len(poses_d)], ray_begin=ray_begin, ray_count=n_local,
+                                            out=pix_bufs[b][:n_local]) if not args.serial else (None, None, None)
+        if args.serial:
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
+            pipe.look_at.copy_(poses_d[i % len(poses_d)], non_blocking=True)
+            pipe.render(ray_begin=ray_begin, ray_count=n_local, out=pix_bufs[b][:n_local])
+            if world > 1:
+                pending[b] = sh.gather(pix_bufs[b], gather_bufs[b], async_op=True)
+        elif world > 1:
+            with torch.cuda.stream(comp):          # composite(i) -> gather(i) -> composite(i+2) on the compositor stream
+                w = sh.gather(pix_bufs[b], gather_bufs[b], async_op=True)
+                w.wait()                           # RCCL: a stream-side wait, it orders the next writer of this buffer
 
     def drain():
         for b in range(2):
             if pending[b] is not None:
                 pending[b].wait()
                 pending[b] = None
+        pipe.drain_async()
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
@@ -206,6 +220,9 @@ def main():
             "trace_mode": "dda+mip",
         },
     }
+    if args.emulate_shard_of > 1 and world == 1:
+        out["emulated_shard_of"] = args.emulate_shard_of
+        out["value"] = None   # one rank's shard only: not a throughput of the workload
     if rank == 0:
         flops = net.flops_per_sample()
         ms = float(np.mean(kern_ms)) if kern_ms else None

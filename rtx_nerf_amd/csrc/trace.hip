@@ -279,18 +279,33 @@ __device__ void march_dda(const float (&o)[3], const float (&d)[3], int R, const
 constexpr int kCoarseLdsWords = 8192;  // 32 KiB: coarse mip of up to 256^3 (64^3 bits)
 constexpr int kSuperLdsWords = 512;    // 2 KiB: super mip (16^3-cell blocks) of up to 400^3
 
+// LDS copy of the two coarse levels, sized by the launch to the grid at hand (128^3: 4 KiB + 64 B) rather than to the
+// largest grid supported: a traversal block then fits on a CU beside a resident block of the MLP kernel (132 KiB of the
+// 160), which is what lets the next frame's traversal run underneath this frame's MLP (render.py, render_async).
+struct TraceLds { int coarse_words, super_words; };   // words staged in LDS (0: read that level from global memory)
+__host__ __device__ inline TraceLds trace_lds(const rtxn_trace_params& p) {
+  TraceLds t{0, 0};
+  if (p.mode != RTXN_TRACE_DDA || !p.occupancy_coarse) return t;
+  const int Rc = p.grid_res >> 2, Rs = p.grid_res >> 4;
+  const int words = (Rc * Rc * Rc + 31) >> 5, swords = p.occupancy_super ? (Rs * Rs * Rs + 31) >> 5 : 0;
+  if (words <= kCoarseLdsWords) t.coarse_words = words;
+  if (swords > 0 && swords <= kSuperLdsWords) t.super_words = swords;
+  return t;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void trace_kernel(rtxn_trace_params p) {
-  __shared__ uint32_t coarse_lds[MODE == RTXN_TRACE_DDA ? kCoarseLdsWords : 1];
-  __shared__ uint32_t super_lds[MODE == RTXN_TRACE_DDA ? kSuperLdsWords : 1];
+  extern __shared__ uint32_t trace_smem[];   // [coarse_words | super_words]
   const uint32_t* coarse = nullptr;
   const uint32_t* super = nullptr;
   if (MODE == RTXN_TRACE_DDA && p.occupancy_coarse) {
-    const int Rc = p.grid_res >> 2;
-    const int words = (Rc * Rc * Rc + 31) >> 5;
+    const TraceLds tl = trace_lds(p);
     const int Rs = p.grid_res >> 4;
+    const int words = tl.coarse_words;
     const int swords = p.occupancy_super ? (Rs * Rs * Rs + 31) >> 5 : 0;
-    const bool c_lds = words <= kCoarseLdsWords, s_lds = swords > 0 && swords <= kSuperLdsWords;
+    const bool c_lds = tl.coarse_words > 0, s_lds = tl.super_words > 0;
+    uint32_t* coarse_lds = trace_smem;
+    uint32_t* super_lds = trace_smem + tl.coarse_words;
     if (c_lds)
       for (int i = threadIdx.x; i < words; i += blockDim.x) coarse_lds[i] = p.occupancy_coarse[i];
     if (s_lds)
@@ -436,8 +451,10 @@ extern "C" int rtxn_trace_grid(const rtxn_trace_params* p, rtxn_stream_t stream)
   RTXN_REQUIRE(p->num_hits != nullptr, "rtxn_trace_grid: num_hits is NULL");
   hipStream_t s = rtxn::as_stream(stream);
   dim3 grid((p->ray_count + 255) / 256), block(256);
+  const TraceLds tl = trace_lds(*p);
+  const size_t lds = (size_t)(tl.coarse_words + tl.super_words) * sizeof(uint32_t);
   if (p->mode == RTXN_TRACE_COMPAT) trace_kernel<RTXN_TRACE_COMPAT><<<grid, block, 0, s>>>(*p);
-  else trace_kernel<RTXN_TRACE_DDA><<<grid, block, 0, s>>>(*p);
+  else trace_kernel<RTXN_TRACE_DDA><<<grid, block, lds, s>>>(*p);
   RTXN_LAUNCH_CHECK("trace_kernel");
   return RTXN_OK;
 }

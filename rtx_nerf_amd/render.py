@@ -48,45 +48,93 @@ class RenderPipeline:
         # default capacity: every ray crossing a full grid diagonal's worth of occupied cells is far too
         # pessimistic; callers size it from a counting pass (see calibrate())
         self.max_segments = int(max_segments) if max_segments is not None else 16 * n
-        d = self.dev
-        self.look_at = torch.zeros(16, device=d)
-        self.view_dirs = torch.empty((n, 2), device=d)
-        self.num_hits = torch.empty(n, dtype=torch.int32, device=d)
-        self.num_hits_c = torch.empty(n, dtype=torch.int32, device=d)
-        self.indices = torch.empty(n, dtype=torch.int32, device=d)
-        self.total = torch.zeros(1, dtype=torch.int32, device=d)
         ws = api._lib.lib().rtxn_scan_workspace_bytes(n)
-        self.scan_ws = torch.empty((ws + 3) // 4, dtype=torch.int32, device=d)
-        self.pixels = torch.empty((n, 3), device=d)
-        self._alloc_segments()
+        self.scan_ws = torch.empty((ws + 3) // 4, dtype=torch.int32, device=self.dev)
+        self.pixels = torch.empty((n, 3), device=self.dev)
+        # per-frame buffers live in "slots": slot 0 is the one render() uses (and what the attributes self.start,
+        # self.num_hits, ... alias); render_async() alternates between two so that consecutive frames overlap
+        self._slots = [self._alloc_slot()]
+        self._bind_slot0()
+        self._async = None
+
+    _SLOT_FIELDS = ("look_at", "view_dirs", "num_hits", "num_hits_c", "indices", "total", "start", "end", "seg_view",
+                    "seg_first", "seg_out", "radiance", "t_vals")
+
+    def _alloc_slot(self):
+        from types import SimpleNamespace
+        d, n = self.dev, self.max_rays
+        g = SimpleNamespace()
+        g.look_at = torch.zeros(16, device=d)
+        g.view_dirs = torch.empty((n, 2), device=d)
+        g.num_hits = torch.empty(n, dtype=torch.int32, device=d)
+        g.num_hits_c = torch.empty(n, dtype=torch.int32, device=d)
+        g.indices = torch.empty(n, dtype=torch.int32, device=d)
+        g.total = torch.zeros(1, dtype=torch.int32, device=d)
+        self._alloc_slot_segments(g)
+        return g
+
+    def _alloc_slot_segments(self, g):
+        d, m = self.dev, self.max_segments
+        g.start = torch.empty((m, 3), device=d)
+        g.end = torch.empty((m, 3), device=d)
+        g.seg_view = torch.empty((m, 2), device=d)
+        if self.fused:
+            g.seg_first = torch.empty(m, dtype=torch.uint8, device=d)
+            g.seg_out = torch.empty((m, 4), device=d)
+            g.radiance = g.t_vals = None
+        else:
+            g.seg_first = g.seg_out = None
+            g.radiance = torch.empty((m * api.NUM_SAMPLES_PER_SEGMENT, 4), device=d)
+            g.t_vals = torch.empty(m * api.NUM_SAMPLES_PER_SEGMENT, device=d)
+
+    def _bind_slot0(self):
+        for f in self._SLOT_FIELDS:
+            setattr(self, f, getattr(self._slots[0], f))
 
     def _alloc_segments(self):
-        d, m = self.dev, self.max_segments
-        self.start = torch.empty((m, 3), device=d)
-        self.end = torch.empty((m, 3), device=d)
-        self.seg_view = torch.empty((m, 2), device=d)
-        if self.fused:
-            self.seg_first = torch.empty(m, dtype=torch.uint8, device=d)
-            self.seg_out = torch.empty((m, 4), device=d)
-            self.radiance = self.t_vals = None
-        else:
-            self.seg_first = self.seg_out = None
-            self.radiance = torch.empty((m * api.NUM_SAMPLES_PER_SEGMENT, 4), device=d)
-            self.t_vals = torch.empty(m * api.NUM_SAMPLES_PER_SEGMENT, device=d)
+        """(Re)allocate the segment-sized buffers of every slot for the current max_segments (calibrate()); the pose and
+        the per-ray buffers stay."""
+        for g in self._slots:
+            self._alloc_slot_segments(g)
+        self._bind_slot0()
 
     def set_pose(self, look_at):
         """look_at: 16 floats (host or device), row-major camera-to-world (params.h:17)."""
         self.look_at.copy_(torch.as_tensor(look_at, dtype=torch.float32).reshape(16), non_blocking=True)
 
-    def _trace(self, ray_begin, ray_count, write):
+    def _trace(self, ray_begin, ray_count, write, slot=None):
+        g = self._slots[0] if slot is None else slot
         kw = dict(grid_res=self.R, ray_begin=ray_begin, ray_count=ray_count, occupancy=self.occ,
                   occupancy_coarse=self.coarse, occupancy_bricks=self.bricks, occupancy_super=self.super_mip, mode=self.trace_mode,
-                  viewing_direction=self.view_dirs,
-                  num_hits=self.num_hits, window_chunk=self.window[0], window_stride=self.window[1])
+                  viewing_direction=g.view_dirs,
+                  num_hits=g.num_hits, window_chunk=self.window[0], window_stride=self.window[1])
         if write:
-            kw.update(indices=self.indices, start_points=self.start, end_points=self.end, seg_view=self.seg_view,
-                      seg_first=self.seg_first, num_stored=self.num_hits_c, segment_capacity=self.max_segments)
-        api.trace_grid(self.look_at, self.focal, self.aspect, self.W, self.H, **kw)
+            kw.update(indices=g.indices, start_points=g.start, end_points=g.end, seg_view=g.seg_view,
+                      seg_first=g.seg_first, num_stored=g.num_hits_c, segment_capacity=self.max_segments)
+        api.trace_grid(g.look_at, self.focal, self.aspect, self.W, self.H, **kw)
+
+    def _geometry(self, g, ray_begin, n):
+        """count -> scan -> write of one frame into slot g (current stream)."""
+        self._trace(ray_begin, n, write=False, slot=g)
+        api.scan_hits(g.num_hits[:n], g.indices[:n], g.total, self.scan_ws)
+        self._trace(ray_begin, n, write=True, slot=g)
+
+    def _shade(self, g):
+        """sampler + encode + MLP (+ per-segment compositing when fused) over slot g's packed segments."""
+        if self.fused:
+            self.net.forward_segments_composite(g.start, g.end, g.seg_view, g.seg_first, g.total,
+                                                self.max_segments, g.seg_out, self.vr_mode, self.step_scale)
+        else:
+            self.net.forward_segments(g.start, g.end, g.seg_view, g.total, self.max_segments, g.radiance, g.t_vals)
+
+    def _composite(self, g, n, pixels):
+        # rays whose segments would overflow the capacity are truncated on the device (never out of bounds):
+        # the write pass reports how many segments it actually stored per ray (num_hits_c)
+        if self.fused:
+            api.composite_segments(g.seg_out, g.num_hits_c[:n], g.indices[:n], n, pixels)
+        else:
+            api.launch_volrender_cuda(None, g.radiance, g.num_hits_c[:n], g.indices[:n], g.t_vals, n,
+                                      api.NUM_SAMPLES_PER_SEGMENT, pixels, mode=self.vr_mode)
 
     def count_segments(self, ray_begin=0, ray_count=None):
         """Counting pass + scan; returns the number of segments (host int, synchronises)."""
@@ -112,23 +160,72 @@ class RenderPipeline:
         pixel buffer view float[ray_count, 3] (or `out`).  No host synchronisation."""
         n = self.max_rays if ray_count is None else ray_count
         pixels = self.pixels[:n] if out is None else out
-        nh, idx = self.num_hits[:n], self.indices[:n]
-        self._trace(ray_begin, n, write=False)
-        api.scan_hits(nh, idx, self.total, self.scan_ws)
-        self._trace(ray_begin, n, write=True)
-        # rays whose segments would overflow the capacity are truncated on the device (never out of bounds):
-        # the write pass reports how many segments it actually stored per ray
-        nhc = self.num_hits_c[:n]
-        if self.fused:
-            self.net.forward_segments_composite(self.start, self.end, self.seg_view, self.seg_first, self.total,
-                                                self.max_segments, self.seg_out, self.vr_mode, self.step_scale)
-            api.composite_segments(self.seg_out, nhc, idx, n, pixels)
-        else:
-            self.net.forward_segments(self.start, self.end, self.seg_view, self.total,
-                                      self.max_segments, self.radiance, self.t_vals)
-            api.launch_volrender_cuda(None, self.radiance, nhc, idx, self.t_vals, n, api.NUM_SAMPLES_PER_SEGMENT,
-                                      pixels, mode=self.vr_mode)
+        g = self._slots[0]
+        self._geometry(g, ray_begin, n)
+        self._shade(g)
+        self._composite(g, n, pixels)
         return pixels
+
+    # ------------------------------------------------------------------------------------------ frame pipelining
+    # A frame is three dependent stages with very different bounds: traversal (two latency-bound passes + scan, ~0.45 ms
+    # whatever the ray count), the MLP kernel (MFMA-bound, 96 % of the time) and the compositor (HBM-bound).  render_async
+    # puts them on three HIP streams and alternates between two buffer slots, so that while the MLP kernel of frame i runs,
+    # frame i+1 is traversed and frame i-1 composited on the same CUs: a traversal block (56 VGPRs, 4 KiB LDS) and a
+    # compositor block (33 VGPRs, no LDS) fit beside a resident MLP block (2 x 216 VGPRs, 132 of 160 KiB LDS).  The host
+    # never synchronises; it simply runs ahead.  Steady-state frame time = the MLP kernel alone, which matters most when
+    # the frame is sharded over N GPUs (the fixed traversal latency is 16 % of a rank's frame at N = 8).
+    def _async_state(self):
+        if self._async is None:
+            from types import SimpleNamespace
+            while len(self._slots) < 2:
+                self._slots.append(self._alloc_slot())
+            a = SimpleNamespace()
+            a.geo, a.comp = torch.cuda.Stream(), torch.cuda.Stream()
+            a.ev_geo = [torch.cuda.Event() for _ in range(2)]
+            a.ev_mlp = [torch.cuda.Event() for _ in range(2)]
+            a.ev_comp = [torch.cuda.Event() for _ in range(2)]
+            a.used = [False, False]
+            a.frame = 0
+            self._async = a
+        return self._async
+
+    def render_async(self, look_at, ray_begin=0, ray_count=None, out=None):
+        """Enqueue one frame, software-pipelined against its neighbours.  look_at: 16 floats on the DEVICE (copied into the
+        slot on the traversal stream).  Returns (pixels, done_event, comp_stream): `pixels` is complete once `done_event`
+        has fired; follow-up work on it (a gather, a copy) is best enqueued on `comp_stream`."""
+        a = self._async_state()
+        n = self.max_rays if ray_count is None else ray_count
+        pixels = self.pixels[:n] if out is None else out
+        b = a.frame & 1
+        a.frame += 1
+        g = self._slots[b]
+        main = torch.cuda.current_stream()
+        with torch.cuda.stream(a.geo):
+            if a.used[b]:
+                a.geo.wait_event(a.ev_comp[b])        # frame i-2 (MLP and compositor) is done with this slot
+            else:
+                a.geo.wait_stream(main)               # first use: whatever set the pipeline up
+            g.look_at.copy_(look_at, non_blocking=True)
+            self._geometry(g, ray_begin, n)
+            a.ev_geo[b].record(a.geo)
+        main.wait_event(a.ev_geo[b])
+        if a.used[b]:
+            main.wait_event(a.ev_comp[b])             # radiance / seg_out of this slot were last read by compositor i-2
+        self._shade(g)
+        a.ev_mlp[b].record(main)
+        with torch.cuda.stream(a.comp):
+            a.comp.wait_event(a.ev_mlp[b])
+            self._composite(g, n, pixels)
+            a.ev_comp[b].record(a.comp)
+        a.used[b] = True
+        return pixels, a.ev_comp[b], a.comp
+
+    def drain_async(self):
+        """Make the current stream wait for every frame enqueued with render_async."""
+        if self._async is not None:
+            main = torch.cuda.current_stream()
+            main.wait_stream(self._async.geo)
+            main.wait_stream(self._async.comp)
 
     def capture(self, ray_begin=0, ray_count=None, out=None):
         """Capture one frame into a hipGraph (torch.cuda.CUDAGraph over the C-ABI launches: none of them
@@ -140,4 +237,4 @@ class RenderPipeline:
         return g, pixels
 
     def overflowed(self):
-        return int(self.total.item()) > self.max_segments
+        return any(int(g.total.item()) > self.max_segments for g in self._slots)

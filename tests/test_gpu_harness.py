@@ -80,3 +80,33 @@ def test_data_parallel_equals_single_process(gpu, tmp_path):
     # rounding noise; the bulk must agree
     pa, pb = a[1], b[1]
     assert np.median(np.abs(pa - pb)) < 1e-4 and (np.abs(pa - pb) < 1e-2).mean() > 0.97
+
+
+@pytest.mark.gpu
+def test_pipelined_frames_equal_serial_frames(gpu):
+    """render_async (three streams, two buffer slots, frames overlapping) must produce exactly the frames render() does."""
+    torch = gpu
+    from rtx_nerf_amd import api, render, scenes
+    R, W, H = 64, 160, 120
+    occ = torch.from_numpy(scenes.pack_occupancy(scenes.lego_standin_density(R, seed=0)).view(np.int32).copy()).cuda()
+    net = api.Network(n_neurons=64, n_hidden_layers=2)
+    net.set_params(torch.from_numpy(scenes.xavier_params_fp16(64, 2, net.encoded_width(), seed=7)).cuda())
+    focal = scenes.lego_focal_length(True)
+    poses = [scenes.pose_spherical(40.0 * i, -30.0, origin_scale=10.0) for i in range(5)]
+    pipe = render.RenderPipeline(net, R, W, H, focal, occupancy=occ, max_segments=1024)
+    pipe.calibrate(poses)
+    want = []
+    for p in poses:
+        pipe.set_pose(p)
+        want.append(pipe.render().clone())
+    torch.cuda.synchronize()
+    poses_d = [torch.from_numpy(p.reshape(16).astype(np.float32)).cuda() for p in poses]
+    outs = [torch.empty((W * H, 3), device="cuda") for _ in poses]
+    for _ in range(2):                                   # twice: the second round reuses both slots
+        for p, o in zip(poses_d, outs):
+            pipe.render_async(p, out=o)
+        pipe.drain_async()
+        torch.cuda.synchronize()
+        for o, w in zip(outs, want):
+            assert torch.equal(o, w)
+    assert not pipe.overflowed()
