@@ -174,6 +174,21 @@ def main():
         elapsed = float(t.item())
     assert not pipe.overflowed(), "segment capacity overflow: calibrate() margin too small"
 
+    # ---- N > 1: the gathered frame must be the single-GPU frame, bit for bit (outside the timed region) ----
+    gather_check = None
+    if world > 1:
+        last = args.warmup + args.steps - 1
+        if rank == 0:
+            full = render.RenderPipeline(net, R, W, H, focal, occupancy=occ, max_segments=1024)
+            full.calibrate([poses[last % len(poses)]])
+            full.set_pose(poses[last % len(poses)])
+            want = full.render().reshape(H, W, 3)
+            got = sh.assemble(gather_bufs[last & 1])
+            torch.cuda.synchronize()
+            gather_check = "bit-identical to the single-GPU frame" if torch.equal(got, want) else \
+                f"MISMATCH: {int((got != want).any(dim=2).sum())} of {W * H} pixels differ"
+            del full
+
     # ---- dominant kernel (fused sampler+encode+MLP), HIP events on the launch stream ----
     kern_ms, kern_samples = [], []
     for i in range(args.kernel_steps):
@@ -220,6 +235,8 @@ def main():
             "trace_mode": "dda+mip",
         },
     }
+    if gather_check is not None:
+        out["gather_check"] = gather_check
     if args.emulate_shard_of > 1 and world == 1:
         out["emulated_shard_of"] = args.emulate_shard_of
         out["value"] = None   # one rank's shard only: not a throughput of the workload
