@@ -3,13 +3,18 @@
 // with two launches and no host round trip: `total` stays in device memory and
 // is read by the consumers (rtxn_mlp_forward_segments) directly.
 //
-// HBM-bound, 8 B/ray algorithmic (4 read + 4 written).  Each 1024-thread block
-// owns a 4096-int chunk (int4 per thread, coalesced 16-B accesses).
+// HBM-bound, 8 B/ray algorithmic (4 read + 4 written).  Each 256-thread block
+// owns a 1024-int chunk (int4 per thread, coalesced 16-B accesses).  256 threads,
+// not 1024: a block is then one wave per SIMD with ~20 VGPRs and fits on a CU
+// beside a resident block of the MLP kernel, so the next frame's compaction runs
+// underneath this frame's MLP (render.py, render_async); a 1024-thread block
+// (4 waves per SIMD) did not fit and stalled the traversal stream until the MLP
+// kernel ended.
 #include "common.h"
 
 namespace {
 
-constexpr int kBlock = 1024;
+constexpr int kBlock = 256;
 constexpr int kItems = 4;
 constexpr int kChunk = kBlock * kItems;
 
