@@ -43,16 +43,20 @@
 
 namespace {
 
-using rtxn::pipe_layer;
-#ifndef RTXN_DBG
-#define RTXN_DBG 0
-#endif
+// Build-time knobs of the 64/128-wide inference kernel (defaults are the measured best; tools/ablate.sh builds variants):
+//   RTXN_NW     waves per block, 8 (one block per CU) or 4 (two)            -- mlp_internal.h
+//   RTXN_SKEW   1: the two wave groups of an 8-wave block run one stage apart (resident first/last layer, 3-slot ring)
+//   RTXN_CT     column tiles per wave, 2 (4: one wave per SIMD with AGPRs, measured slower)
+//   RTXN_PIPE   depth of the A-fragment register ring                        -- mlp_internal.h
+//   RTXN_L0_PLAIN  encode all of layer 0's input up front instead of inside layer 0 (A/B timing)
+//   RTXN_ABLATE    timing experiments only, RESULTS ARE WRONG: 1 no encoding, 2 no barriers, 4 no weight staging
 #ifndef RTXN_SKEW
 #define RTXN_SKEW 1
 #endif
 #ifndef RTXN_ABLATE
-#define RTXN_ABLATE 0   // timing experiments (tools/ablate.sh): 1 no encode, 2 no barrier, 4 no weight staging -- results are wrong
+#define RTXN_ABLATE 0
 #endif
+using rtxn::pipe_layer;
 using rtxn::relu_pack;
 using rtxn::stage;
 
@@ -270,9 +274,6 @@ struct Layer0Step {
     constexpr int kk = I / RT, rt = I % RT, cur = kk & 1;
     constexpr int outstanding = (N - 1 - I) < (D - 1) ? (N - 1 - I) : (D - 1);
     rtxn::lds_wait<outstanding>();
-#if RTXN_DBG & 1
-    if (rt == 0) { asm volatile("s_nop 7\n\ts_nop 7"); __builtin_amdgcn_sched_barrier(0); }
-#endif
     const half8 a = ring[I % D];
     if (kk == 0) {
 #pragma unroll
@@ -282,9 +283,6 @@ struct Layer0Step {
     }
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[cur][ct], acc[rt][ct], 0, 0, 0);
-#if RTXN_DBG & 2
-    asm volatile("s_nop 7\n\ts_nop 7"); __builtin_amdgcn_sched_barrier(0);
-#endif
     if constexpr (kk + 1 < KS0) {
       constexpr int u0 = rt * UE < 4 * CT ? rt * UE : 4 * CT, u1 = (rt + 1) * UE < 4 * CT ? (rt + 1) * UE : 4 * CT;
       encode_units<ES, PD, PF, DD, DF, CT, kk + 1, u0, u1>(xin, phase, b[cur ^ 1]);
