@@ -56,6 +56,8 @@ class TraceParams(C.Structure):
         ("occupancy_bricks", C.c_void_p),
         ("occupancy_super", C.c_void_p),
         ("num_stored", C.c_void_p),
+        ("sub_rays", C.c_int),
+        ("sub_hits", C.c_void_p),
     ]
 
 

@@ -46,7 +46,7 @@ def trace_grid(look_at=None, focal_length=1.0, aspect_ratio=1.0, width=0, height
                occupancy_coarse=None, occupancy_bricks=None, occupancy_super=None, mode=TRACE_COMPAT, ray_origins=None, viewing_direction=None,
                num_hits=None, intersection_arr_size=0, indices=None, start_points=None,
                end_points=None, t_start=None, t_end=None, seg_ray=None, seg_view=None, seg_first=None, num_stored=None, segment_capacity=0,
-               window_chunk=0, window_stride=0):
+               window_chunk=0, window_stride=0, sub_rays=0, sub_hits=None):
     """optixLaunch(pipeline_ray_march, ..., width, height, 1) with Params (main.cu:481-508)."""
     p = TraceParams()
     p.look_at = _ptr(look_at, torch.float32, "look_at")
@@ -79,7 +79,22 @@ def trace_grid(look_at=None, focal_length=1.0, aspect_ratio=1.0, width=0, height
     p.num_stored = _ptr(num_stored, torch.int32, "num_stored")
     p.segment_capacity = segment_capacity
     p.window_chunk, p.window_stride = window_chunk, window_stride
+    p.sub_rays = sub_rays
+    p.sub_hits = _ptr(sub_hits, torch.int32, "sub_hits")
     check(_lib.lib().rtxn_trace_grid(C.byref(p), _stream()), "rtxn_trace_grid")
+
+
+def auto_sub_rays(n_rays):
+    """Lanes per ray (rtxn_trace_params.sub_rays) for a launch of n_rays: measured on MI355X (tools/trace_bench.py), the
+    smaller the launch the more the longest ray's walk dominates it -- 640 k rays: 2 (0.20 -> 0.15 ms), 80 k: 8 (0.18 ->
+    0.07 ms), a 4096-ray training batch: 16."""
+    if n_rays >= 300_000:
+        return 2
+    if n_rays >= 120_000:
+        return 4
+    if n_rays >= 30_000:
+        return 8
+    return 16
 
 
 def build_occupancy_mip(occupancy, grid_res):

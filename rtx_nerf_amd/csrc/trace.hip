@@ -39,6 +39,7 @@ struct Sink {
   long limit;  // first slot this ray may not write
   int ray;
   int n;
+  int prior;   // segments of this ray emitted by earlier sub-ray lanes (seg_first)
   __device__ __forceinline__ void emit(const float (&p0)[3], const float (&p1)[3], float a, float b) {
     const long k = base + n;
     if (k < limit) {
@@ -48,7 +49,7 @@ struct Sink {
       if (t1) t1[k] = b;
       if (seg_ray) seg_ray[k] = ray;
       if (seg_view) { seg_view[2 * k] = view[0]; seg_view[2 * k + 1] = view[1]; }
-      if (seg_first) seg_first[k] = n == 0;
+      if (seg_first) seg_first[k] = prior + n == 0;
     }
     ++n;
   }
@@ -182,9 +183,38 @@ __device__ __forceinline__ float plane_t(int i, float L, float o, float inv) { r
 // (R/4)^3 mip.  An empty coarse block is crossed in one step: every axis advances
 // while its exit plane's t is <= the block's exit t, which is exactly the state
 // the flat walk reaches (plane_t depends only on the cell index).
+// The state the flat walk is in once every plane with plane_t <= tc has been crossed, starting from cell c: each axis
+// is estimated from the position and fixed up with the walk's own exact comparisons (exit plane of cell i is plane
+// i + up; crossed iff <= tc).  Returns false if the walk has left the grid by then.
+__device__ __forceinline__ bool land_at(int (&c)[3], float tc, const float (&o)[3], const float (&d)[3], const float (&inv)[3],
+                                        const int (&step)[3], const int (&up)[3], int R, float L) {
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    if (d[a] != 0.0f) {
+      const int c0 = c[a];
+      int est = (int)floorf((fmaf(tc, d[a], o[a]) + 1.0f) / L);
+      est = step[a] > 0 ? max(est, c0) : min(est, c0);
+      est = min(max(est, 0), R - 1);
+      while (est != c0 && plane_t(est - step[a] + up[a], L, o[a], inv[a]) > tc) est -= step[a];
+      while (plane_t(est + up[a], L, o[a], inv[a]) <= tc) {
+        est += step[a];
+        if (est < 0 || est >= R) return false;
+      }
+      c[a] = est;
+    }
+  }
+  return true;
+}
+
+// sub > 1: this lane is piece `piece` of `sub` of the ray.  The ray's parameter range inside the grid is cut at
+// T_k = t_enter + (t_exit - t_enter) * k / sub; a cell belongs to the piece with T_piece < t_out <= T_piece+1 (first and
+// last piece unbounded), so every cell is emitted by exactly one lane, in ray order across the lanes.  A piece starts in
+// the cell the flat walk is in at T_piece (land_at) with the entry time the flat walk has there: t_in is always the t of
+// the last plane crossed, which is an entry plane of the current cell, and both are pure functions of integer cell
+// indices -- so the pieces reproduce the one-thread walk bit for bit.
 __device__ void march_dda(const float (&o)[3], const float (&d)[3], int R, const uint32_t* __restrict__ occ,
                           const uint32_t* coarse, const uint32_t* super, const unsigned long long* __restrict__ bricks,
-                          Sink& s) {
+                          int piece, int sub, Sink& s) {
   const float L = 2.0f / (float)R;
   int c[3];
   float t_in;
@@ -196,6 +226,23 @@ __device__ void march_dda(const float (&o)[3], const float (&d)[3], int R, const
     inv[a] = 1.0f / d[a];
     step[a] = d[a] < 0 ? -1 : 1;
     up[a] = d[a] < 0 ? 0 : 1;
+  }
+  float t_stop = INFINITY;   // cells leaving after t_stop belong to the next piece
+  if (sub > 1) {
+    float t_exit = INFINITY;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+      if (d[a] != 0.0f) t_exit = fminf(t_exit, plane_t(up[a] ? R : 0, L, o[a], inv[a]));
+    const float span = t_exit - t_in, t_enter = t_in;
+    if (piece + 1 < sub) t_stop = fmaf(span, (float)(piece + 1) / (float)sub, t_enter);
+    if (piece > 0) {
+      const float t_from = fmaf(span, (float)piece / (float)sub, t_enter);   // == the previous piece's t_stop
+      const int c_in[3] = {c[0], c[1], c[2]};
+      if (!land_at(c, t_from, o, d, inv, step, up, R, L)) return;
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+        if (d[a] != 0.0f && c[a] != c_in[a]) t_in = fmaxf(t_in, plane_t(c[a] + 1 - up[a], L, o[a], inv[a]));
+    }
   }
   const int Rc = R >> 2;
   // brick cache: the 64 fine bits of the occupied 4^3 block the walk is currently in (one 8-byte load per block
@@ -229,25 +276,10 @@ __device__ void march_dda(const float (&o)[3], const float (&d)[3], int R, const
         for (int a = 0; a < 3; ++a) {
           if (d[a] != 0.0f) tc = fminf(tc, plane_t(((c[a] >> shift) + up[a]) << shift, L, o[a], inv[a]));
         }
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          if (d[a] != 0.0f) {
-            // land directly in the cell the flat walk would be in at tc: estimate it from the position, then fix the
-            // estimate with the walk's own exact comparisons (exit plane of cell i is plane i + up; crossed iff <= tc)
-            const int c0 = c[a];
-            int est = (int)floorf((fmaf(tc, d[a], o[a]) + 1.0f) / L);
-            est = step[a] > 0 ? max(est, c0) : min(est, c0);
-            est = min(max(est, 0), R - 1);
-            while (est != c0 && plane_t(est - step[a] + up[a], L, o[a], inv[a]) > tc) est -= step[a];
-            while (plane_t(est + up[a], L, o[a], inv[a]) <= tc) {
-              est += step[a];
-              if (est < 0 || est >= R) { out = true; break; }
-            }
-            c[a] = est;
-          }
-        }
-        if (out) break;
+        // land directly in the cell the flat walk would be in at tc
+        if (!land_at(c, tc, o, d, inv, step, up, R, L)) break;
         if (tc > t_in) t_in = tc;
+        if (t_in >= t_stop) break;   // everything from here on leaves after t_stop
         continue;
       }
     }
@@ -255,6 +287,7 @@ __device__ void march_dda(const float (&o)[3], const float (&d)[3], int R, const
 #pragma unroll
     for (int a = 0; a < 3; ++a) te[a] = d[a] == 0.0f ? INFINITY : plane_t(c[a] + up[a], L, o[a], inv[a]);
     const float t_out = fminf(fminf(te[0], te[1]), te[2]);
+    if (t_out > t_stop) break;   // this cell and all later ones belong to the following pieces
     bool on;
     if (coarse && bricks) on = (brick >> (((c[0] & 3) << 4) | ((c[1] & 3) << 2) | (c[2] & 3))) & 1ull;
     else on = occ_test(occ, R, c[0], c[1], c[2]);
@@ -314,12 +347,15 @@ __global__ __launch_bounds__(256) void trace_kernel(rtxn_trace_params p) {
     coarse = c_lds ? coarse_lds : p.occupancy_coarse;
     if (swords) super = s_lds ? super_lds : p.occupancy_super;
   }
-  // 16x16 pixel tiles per block keep a block's rays on neighbouring cells (shared
-  // occupancy words); a ray window that is not tile-aligned falls back to linear order.
-  const unsigned r = blockIdx.x * 256u + threadIdx.x;
-  if (r >= p.ray_count) return;
-  const unsigned gid = p.window_chunk ? p.ray_begin + (r / p.window_chunk) * p.window_stride + (r % p.window_chunk)
-                                      : p.ray_begin + r;
+  // sub_rays = Q > 1: Q adjacent lanes share a ray (thread = ray * Q + piece); Q divides 64, so a ray never straddles waves
+  const int Q = MODE == RTXN_TRACE_DDA && p.sub_rays > 1 ? p.sub_rays : 1;
+  const unsigned tid = blockIdx.x * 256u + threadIdx.x;
+  const unsigned r = tid / (unsigned)Q;
+  const int piece = (int)(tid % (unsigned)Q);
+  const bool live = r < p.ray_count;   // dead lanes stay for the wave-level sums below
+  const unsigned rr = live ? r : 0;
+  const unsigned gid = p.window_chunk ? p.ray_begin + (rr / p.window_chunk) * p.window_stride + (rr % p.window_chunk)
+                                      : p.ray_begin + rr;
   float o[3], d[3], v[2];
   if (p.look_at) {
     make_ray(p.look_at, p.focal_length, p.aspect_ratio, p.width, p.height, gid % p.width, gid / p.width, o, d, v);
@@ -329,20 +365,44 @@ __global__ __launch_bounds__(256) void trace_kernel(rtxn_trace_params p) {
     v[0] = atan2f(sqrtf(fmaf(d[0], d[0], d[1] * d[1])), d[2]);
     v[1] = atan2f(d[1], d[0]);
   }
-  if (p.ray_origins) { p.ray_origins[3 * (size_t)r] = o[0]; p.ray_origins[3 * (size_t)r + 1] = o[1]; p.ray_origins[3 * (size_t)r + 2] = o[2]; }
-  if (p.viewing_direction) { p.viewing_direction[2 * (size_t)r] = v[0]; p.viewing_direction[2 * (size_t)r + 1] = v[1]; }
+  if (live && piece == 0) {
+    if (p.ray_origins) { p.ray_origins[3 * (size_t)r] = o[0]; p.ray_origins[3 * (size_t)r + 1] = o[1]; p.ray_origins[3 * (size_t)r + 2] = o[2]; }
+    if (p.viewing_direction) { p.viewing_direction[2 * (size_t)r] = v[0]; p.viewing_direction[2 * (size_t)r + 1] = v[1]; }
+  }
+  const bool writing = p.start_points || p.end_points || p.t_start || p.t_end || p.seg_ray || p.seg_view || p.seg_first;
+  // sub-ray write pass: this piece's segments follow those of the earlier pieces (their counts come from the counting pass)
+  int prior = 0;
+  if (Q > 1 && writing) {
+    const int mine = live ? p.sub_hits[(size_t)r * Q + piece] : 0;
+    int incl = mine;
+    for (int dlt = 1; dlt < Q; dlt <<= 1) {
+      const int t = __shfl_up(incl, dlt, 64);
+      if (piece >= dlt) incl += t;
+    }
+    prior = incl - mine;
+  }
   Sink s;
   s.start = p.start_points; s.end = p.end_points; s.t0 = p.t_start; s.t1 = p.t_end; s.seg_ray = p.seg_ray; s.seg_view = p.seg_view; s.seg_first = p.seg_first; s.view[0] = v[0]; s.view[1] = v[1];
-  s.ray = (int)r; s.n = 0;
-  if (p.indices) { s.base = p.indices[r]; s.limit = p.segment_capacity > 0 ? p.segment_capacity : 0x7fffffffffffffffL; }
-  else { s.base = (long)r * p.intersection_arr_size; s.limit = s.base + p.intersection_arr_size; }
-  if (!p.start_points && !p.end_points && !p.t_start && !p.t_end && !p.seg_ray && !p.seg_view && !p.seg_first) s.limit = 0;
-  if (MODE == RTXN_TRACE_COMPAT) march_compat(o, d, p.grid_res, p.occupancy, s);
-  else march_dda(o, d, p.grid_res, p.occupancy, coarse, super, reinterpret_cast<const unsigned long long*>(p.occupancy_bricks), s);
-  p.num_hits[r] = s.n;
-  if (p.num_stored) {
-    const long room = s.limit - s.base;
-    p.num_stored[r] = (int)(room <= 0 ? 0 : (room < s.n ? room : s.n));
+  s.ray = (int)r; s.n = 0; s.prior = prior;
+  if (p.indices) { s.base = (long)p.indices[rr] + prior; s.limit = p.segment_capacity > 0 ? p.segment_capacity : 0x7fffffffffffffffL; }
+  else { s.base = (long)r * p.intersection_arr_size + prior; s.limit = ((long)r + 1) * p.intersection_arr_size; }
+  if (!writing || !live) s.limit = 0;
+  if (live) {
+    if (MODE == RTXN_TRACE_COMPAT) march_compat(o, d, p.grid_res, p.occupancy, s);
+    else march_dda(o, d, p.grid_res, p.occupancy, coarse, super, reinterpret_cast<const unsigned long long*>(p.occupancy_bricks), piece, Q, s);
+  }
+  const long room = s.limit - s.base;
+  int hits = s.n, stored = (int)(room <= 0 ? 0 : (room < s.n ? room : s.n));
+  if (Q > 1) {
+    if (live && !writing) p.sub_hits[(size_t)r * Q + piece] = s.n;
+    for (int dlt = 1; dlt < Q; dlt <<= 1) {   // sum over the ray's Q lanes (aligned group)
+      hits += __shfl_xor(hits, dlt, 64);
+      stored += __shfl_xor(stored, dlt, 64);
+    }
+  }
+  if (live && piece == 0) {
+    p.num_hits[r] = hits;
+    if (p.num_stored) p.num_stored[r] = stored;
   }
 }
 
@@ -450,7 +510,11 @@ extern "C" int rtxn_trace_grid(const rtxn_trace_params* p, rtxn_stream_t stream)
   if (p->ray_count == 0) return RTXN_OK;
   RTXN_REQUIRE(p->num_hits != nullptr, "rtxn_trace_grid: num_hits is NULL");
   hipStream_t s = rtxn::as_stream(stream);
-  dim3 grid((p->ray_count + 255) / 256), block(256);
+  const int Q = p->mode == RTXN_TRACE_DDA && p->sub_rays > 1 ? p->sub_rays : 1;
+  RTXN_REQUIRE(p->sub_rays >= 0 && (Q == 1 || Q == 2 || Q == 4 || Q == 8 || Q == 16) && (p->sub_rays <= 1 || p->mode == RTXN_TRACE_DDA),
+               "rtxn_trace_grid: sub_rays = %d must be 0, 1, 2, 4, 8 or 16 (RTXN_TRACE_DDA only)", p->sub_rays);
+  RTXN_REQUIRE(Q == 1 || p->sub_hits != nullptr, "rtxn_trace_grid: sub_rays = %d needs the sub_hits scratch", p->sub_rays);
+  dim3 grid((unsigned)(((size_t)p->ray_count * Q + 255) / 256)), block(256);
   const TraceLds tl = trace_lds(*p);
   const size_t lds = (size_t)(tl.coarse_words + tl.super_words) * sizeof(uint32_t);
   if (p->mode == RTXN_TRACE_COMPAT) trace_kernel<RTXN_TRACE_COMPAT><<<grid, block, 0, s>>>(*p);

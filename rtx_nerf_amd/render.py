@@ -21,7 +21,7 @@ from . import api
 class RenderPipeline:
     def __init__(self, network, grid_res, width, height, focal_length, aspect_ratio=None, occupancy=None,
                  max_rays=None, max_segments=None, trace_mode=api.TRACE_DDA, vr_mode=api.VR_COMPAT,
-                 device="cuda", window=(0, 0), fused=False, step_scale=1.0):
+                 device="cuda", window=(0, 0), fused=False, step_scale=1.0, sub_rays=None):
         self.net = network
         self.R = grid_res
         self.W, self.H = width, height
@@ -29,6 +29,10 @@ class RenderPipeline:
         self.aspect = float(width) / float(height) if aspect_ratio is None else float(aspect_ratio)
         self.trace_mode, self.vr_mode = trace_mode, vr_mode
         self.window = window   # (chunk, stride) ray interleave of this shard, see rtxn_trace_params
+        # sub_rays = Q in {2,4,8,16}: Q lanes walk consecutive pieces of each ray (rtxn_trace_params.sub_rays): same
+        # segments bit for bit, a shorter critical path -- worth it when the launch is small (a shard, a training batch)
+        n_rays = width * height if max_rays is None else max_rays
+        self.sub_rays = (api.auto_sub_rays(n_rays) if sub_rays is None else int(sub_rays)) if trace_mode == api.TRACE_DDA else 0
         # fused: the compositor's per-segment half runs in the MLP epilogue (16 B/segment leave the kernel);
         # unfused (default): per-sample radiance + t_vals (20 B/sample) and the reference-shaped launch_volrender_cuda.
         # Measured on MI355X (same run, 800x800 bench frame): fused 22.9 ms/frame vs unfused 21.7 -- the frame is
@@ -70,6 +74,7 @@ class RenderPipeline:
         g.num_hits_c = torch.empty(n, dtype=torch.int32, device=d)
         g.indices = torch.empty(n, dtype=torch.int32, device=d)
         g.total = torch.zeros(1, dtype=torch.int32, device=d)
+        g.sub_hits = torch.zeros(n * self.sub_rays, dtype=torch.int32, device=d) if self.sub_rays > 1 else None
         self._alloc_slot_segments(g)
         return g
 
@@ -107,7 +112,8 @@ class RenderPipeline:
         kw = dict(grid_res=self.R, ray_begin=ray_begin, ray_count=ray_count, occupancy=self.occ,
                   occupancy_coarse=self.coarse, occupancy_bricks=self.bricks, occupancy_super=self.super_mip, mode=self.trace_mode,
                   viewing_direction=g.view_dirs,
-                  num_hits=g.num_hits, window_chunk=self.window[0], window_stride=self.window[1])
+                  num_hits=g.num_hits, window_chunk=self.window[0], window_stride=self.window[1],
+                  sub_rays=self.sub_rays, sub_hits=g.sub_hits)
         if write:
             kw.update(indices=g.indices, start_points=g.start, end_points=g.end, seg_view=g.seg_view,
                       seg_first=g.seg_first, num_stored=g.num_hits_c, segment_capacity=self.max_segments)

@@ -75,6 +75,9 @@ class Trainer:
         self.num_hits = torch.empty(B, dtype=torch.int32, device=d)
         self.indices = torch.empty(B, dtype=torch.int32, device=d)
         self.total = torch.zeros(1, dtype=torch.int32, device=d)
+        # a batch is a small launch: several lanes walk each ray (bit-identical segments, shorter critical path)
+        self.sub_rays = api.auto_sub_rays(B)
+        self.sub_hits = torch.zeros(B * self.sub_rays, dtype=torch.int32, device=d)
         self.scan_ws = torch.empty((api._lib.lib().rtxn_scan_workspace_bytes(B) + 3) // 4, dtype=torch.int32, device=d)
         self.start = torch.empty((M, 3), device=d)
         self.end = torch.empty((M, 3), device=d)
@@ -95,7 +98,7 @@ class Trainer:
     def _segments(self, rays_o, rays_d, n):
         kw = dict(grid_res=self.R, rays_o=rays_o, rays_d=rays_d, width=n, height=1, ray_begin=0, ray_count=n,
                   occupancy=self.occ, occupancy_coarse=self.coarse, occupancy_bricks=self.bricks, occupancy_super=self.super_mip, mode=api.TRACE_DDA,
-                  viewing_direction=self.view_dirs, num_hits=self.num_hits)
+                  viewing_direction=self.view_dirs, num_hits=self.num_hits, sub_rays=self.sub_rays, sub_hits=self.sub_hits)
         api.trace_grid(None, **kw)
         api.scan_hits(self.num_hits[:n], self.indices[:n], self.total, self.scan_ws)
         api.trace_grid(None, indices=self.indices, start_points=self.start, end_points=self.end,

@@ -51,9 +51,18 @@ for it in range(a.iters):
     ep = torch.full((n * S, 3), -2.0, device="cuda")
     t0 = torch.full((n * S,), -2.0, device="cuda")
     t1 = torch.full((n * S,), -2.0, device="cuda")
-    api.trace_grid(torch.from_numpy(la.reshape(16)).cuda(), f, W / H, W, H, grid_res=R, occupancy=occ, occupancy_coarse=coarse, occupancy_bricks=bricks, occupancy_super=sup,
-                   mode=mode, ray_origins=og, viewing_direction=vd, num_hits=nh, intersection_arr_size=S, start_points=sp,
-                   end_points=ep, t_start=t0, t_end=t1)
+    # sub-ray walk (DDA only): Q lanes per ray, counting pass first (it fills sub_hits), then the write pass
+    Q = int(rng.choice([1, 1, 2, 4, 8, 16])) if mode == 1 else 1
+    sub = torch.zeros(n * Q, dtype=torch.int32, device="cuda") if Q > 1 else None
+    la_d = torch.from_numpy(la.reshape(16)).cuda()
+    common = dict(grid_res=R, occupancy=occ, occupancy_coarse=coarse, occupancy_bricks=bricks, occupancy_super=sup, mode=mode,
+                  num_hits=nh, intersection_arr_size=S, sub_rays=Q, sub_hits=sub)
+    if Q > 1:
+        api.trace_grid(la_d, f, W / H, W, H, **common)
+        assert np.array_equal(nh.cpu().numpy(), want["num_hits"]), "counting pass"
+        nh.zero_()
+    api.trace_grid(la_d, f, W / H, W, H, ray_origins=og, viewing_direction=vd, start_points=sp, end_points=ep, t_start=t0, t_end=t1,
+                   **common)
     torch.cuda.synchronize()
     finite = all(np.isfinite(x.cpu().numpy()).all() for x in (sp, ep, t0, t1, og, vd))
     ok = (finite and np.array_equal(nh.cpu().numpy(), want["num_hits"]) and np.array_equal(sp.cpu().numpy(), want["start"])
@@ -63,7 +72,7 @@ for it in range(a.iters):
     if not ok:
         bad += 1
         d = np.nonzero(nh.cpu().numpy() != want["num_hits"])[0]
-        print(f"MISMATCH it={it} R={R} {W}x{H} mode={mode} occ={'none' if words is None else 'yes'} coarse={use_coarse} "
+        print(f"MISMATCH it={it} Q={Q} R={R} {W}x{H} mode={mode} occ={'none' if words is None else 'yes'} coarse={use_coarse} "
               f"rays with different num_hits: {d[:8]}", flush=True)
         for name, g_, w_ in (("start", sp, want["start"]), ("end", ep, want["end"]), ("t_start", t0, want["t_start"]),
                              ("t_end", t1, want["t_end"]), ("origins", og, want["origins"]), ("view", vd, want["view_dirs"])):

@@ -16,6 +16,8 @@ ap.add_argument("--scene", default="lego")
 ap.add_argument("--grid", type=int, default=128)
 ap.add_argument("--width", type=int, default=800)
 ap.add_argument("--height", type=int, default=800)
+ap.add_argument("--sub-rays", type=int, default=0, help="lanes per ray (rtxn_trace_params.sub_rays)")
+ap.add_argument("--shard-of", type=int, default=1, help="trace only rank 0's row shard of an N-rank run")
 a = ap.parse_args()
 torch.cuda.set_device(0)
 R = a.grid
@@ -25,10 +27,13 @@ net = api.Network(n_neurons=64, n_hidden_layers=2)
 net.set_params(torch.from_numpy(scenes.xavier_params_fp16(64, 2, 112)).cuda())
 la = scenes.pose_spherical(15.0, -30.0, origin_scale=10.0) if a.scene == "lego" else scenes.pose_forward_facing(0.2, 0.1)
 f = scenes.lego_focal_length(True) if a.scene == "lego" else 1.6
-pipe = render.RenderPipeline(net, R, a.width, a.height, f, occupancy=occ, max_segments=1024)
-pipe.calibrate([la])
+from rtx_nerf_amd.shard import RowShard
+sh = RowShard(a.width, a.height, 0, a.shard_of)
+pipe = render.RenderPipeline(net, R, a.width, a.height, f, occupancy=occ, max_rays=sh.n_local, max_segments=1024, window=sh.window,
+                             sub_rays=a.sub_rays)
+pipe.calibrate([la], ray_begin=sh.ray_begin, ray_count=sh.n_local)
 pipe.set_pose(la)
-n = a.width * a.height
+n = sh.n_local
 sup = pipe.super_mip
 for label, bricks, pipe.super_mip in (("3-level", pipe.bricks, sup), ("2-level", pipe.bricks, None), ("3-level", pipe.bricks, sup),
                                       ("2-level", pipe.bricks, None)):
@@ -40,8 +45,8 @@ for label, bricks, pipe.super_mip in (("3-level", pipe.bricks, sup), ("2-level",
                 api.scan_hits(pipe.num_hits[:n], pipe.indices[:n], pipe.total, pipe.scan_ws)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            pipe._trace(0, n, write=write)
+            pipe._trace(sh.ray_begin, n, write=write)
             e1.record()
             torch.cuda.synchronize()
             ms[write].append(e0.elapsed_time(e1))
-    print(f"{label:10s} count {np.median(ms[False]):.4f} ms  write {np.median(ms[True]):.4f} ms  segments {int(pipe.total.item())}")
+    print(f"rays {n} sub_rays {a.sub_rays} {label:10s} count {np.median(ms[False]):.4f} ms  write {np.median(ms[True]):.4f} ms  segments {int(pipe.total.item())}")
