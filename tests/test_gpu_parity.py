@@ -145,8 +145,10 @@ def test_trace_occupancy_and_hierarchical_skip(gpu, oracle, R, use_coarse):
             _assert_trace_equal(got, want)
 
 
-def test_trace_window_and_packed_two_pass(gpu, oracle):
-    """Ray window (the multi-GPU shard) + count -> scan -> write into the packed CSR layout."""
+@pytest.mark.parametrize("sub_rays", [0, 2, 8, 16])
+def test_trace_window_and_packed_two_pass(gpu, oracle, sub_rays):
+    """Ray window (the multi-GPU shard) + count -> scan -> write into the packed CSR layout; with sub_rays = Q the ray
+    is walked by Q lanes in consecutive pieces and must give the same segments, in the same order, bit for bit."""
     torch = gpu
     from rtx_nerf_amd import api
     R, W, H = 32, 64, 48
@@ -162,8 +164,9 @@ def test_trace_window_and_packed_two_pass(gpu, oracle):
     la_d = _dev(torch, la.reshape(16))
     nh = torch.zeros(count, dtype=torch.int32, device="cuda")
     vd = torch.zeros((count, 2), device="cuda")
+    sub = torch.zeros(count * max(sub_rays, 1), dtype=torch.int32, device="cuda")
     kw = dict(grid_res=R, ray_begin=begin, ray_count=count, occupancy=occ, occupancy_coarse=coarse, mode=1,
-              viewing_direction=vd, num_hits=nh)
+              viewing_direction=vd, num_hits=nh, sub_rays=sub_rays, sub_hits=sub)
     api.trace_grid(la_d, f, 1.0, W, H, **kw)
     idx, total = api.scan_hits(nh)
     P = int(total.item())
@@ -173,10 +176,16 @@ def test_trace_window_and_packed_two_pass(gpu, oracle):
     ep = torch.full((P, 3), -2.0, device="cuda")
     sr = torch.full((P,), -1, dtype=torch.int32, device="cuda")
     sv = torch.full((P, 2), -9.0, device="cuda")
-    api.trace_grid(la_d, f, 1.0, W, H, indices=idx, start_points=sp, end_points=ep, seg_ray=sr, seg_view=sv,
-                   segment_capacity=cap, **kw)
+    sf = torch.full((P,), 7, dtype=torch.uint8, device="cuda")
+    stored = torch.zeros(count, dtype=torch.int32, device="cuda")
+    api.trace_grid(la_d, f, 1.0, W, H, indices=idx, start_points=sp, end_points=ep, seg_ray=sr, seg_view=sv, seg_first=sf,
+                   num_stored=stored, segment_capacity=cap, **kw)
     torch.cuda.synchronize()
     np.testing.assert_array_equal(nh.cpu().numpy(), want["num_hits"])
+    first = np.zeros(P, np.uint8)
+    first[want["indices"][want["num_hits"] > 0]] = 1
+    np.testing.assert_array_equal(sf.cpu().numpy()[:cap], first[:cap])
+    np.testing.assert_array_equal(stored.cpu().numpy(), np.clip(cap - want["indices"], 0, want["num_hits"]))
     np.testing.assert_array_equal(idx.cpu().numpy(), want["indices"])
     np.testing.assert_array_equal(sp.cpu().numpy()[:cap], want["start"][:cap])
     np.testing.assert_array_equal(ep.cpu().numpy()[:cap], want["end"][:cap])
