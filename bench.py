@@ -12,7 +12,12 @@ Multi-GPU (--gpus N, launched by torch.distributed.run, one rank per GPU): the
 frame's image rows are dealt round-robin to the ranks (ray sharding, no
 data-path collective), each rank renders its rows, and the rendered rows are
 gathered on rank 0 with one RCCL gather per frame (0.96 MB per rank at N=8).
-Total work per step is fixed, so this is strong scaling.
+Total work per step is fixed, so this is strong scaling.  Rank 0 checks the gathered frame bit for
+bit against its own single-GPU render after the timed loop ("gather_check").
+
+Frames are software-pipelined across three HIP streams (render.py, render_async): the next frame's traversal and
+the previous frame's compositing run underneath this frame's MLP kernel; every step still enqueues one whole frame
+of every stage (--serial times the one-stream form).
 
 Prints ONE JSON line on rank 0; see DESIGN.md for the roofline arithmetic.
 """
