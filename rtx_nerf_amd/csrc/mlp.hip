@@ -48,6 +48,7 @@ namespace {
 //   RTXN_SKEW   1: the two wave groups of an 8-wave block run one stage apart (resident first/last layer, 3-slot ring)
 //   RTXN_CT     column tiles per wave, 2 (4: one wave per SIMD with AGPRs, measured slower)
 //   RTXN_PIPE   depth of the A-fragment register ring                        -- mlp_internal.h
+//   RTXN_SHARE_DIR 1: segment input computes a column tile's direction features once per lane-half (DirShare)
 //   RTXN_L0_PLAIN  encode all of layer 0's input up front instead of inside layer 0 (A/B timing)
 //   RTXN_ABLATE    timing experiments only, RESULTS ARE WRONG: 1 no encoding, 2 no barriers, 4 no weight staging
 #ifndef RTXN_SKEW
@@ -55,6 +56,9 @@ namespace {
 #endif
 #ifndef RTXN_ABLATE
 #define RTXN_ABLATE 0
+#endif
+#ifndef RTXN_SHARE_DIR
+#define RTXN_SHARE_DIR 1
 #endif
 using rtxn::pipe_layer;
 using rtxn::relu_pack;
@@ -220,11 +224,40 @@ struct SlotInfo {   // real slot P: input dimension and 2^(f-1)
   static constexpr int f = P < PD * PF ? P % PF : (P - PD * PF) % DF;
   static constexpr int dim = P < PD * PF ? P / PF : PD + (P - PD * PF) / DF;
 };
+// Segment input (IN_MODE 1): a 32-sample column tile is ONE segment, so its direction features (DD*DF of the n_pairs
+// slots: 24 of 54 for the reference model) are the same for all 32 lanes of a lane-half.  Instead of every lane computing
+// all of them, lane c of each half computes slot c alone (same four instructions, scale 2^(f-1) from v_ldexp), neighbouring
+// lanes pack their two values with one DPP move + v_cvt_pk_f16_f32, and DD*DF/2 ds_bpermute broadcasts hand every lane the
+// finished B-fragment dwords -- bit-identical values, 23 fewer v_sin_f32 per lane and column tile.
+template <int PD, int PF, int DD, int DF>
+struct DirShare {
+  static constexpr bool possible = (PD * PF) % 2 == 0 && (DD * DF) % 2 == 0 && DD == 2 && DD * DF <= 32;
+  static constexpr int n_dwords = possible ? DD * DF / 2 : 1;
+};
+
+template <int PD, int PF, int DD, int DF>
+__device__ __forceinline__ void share_direction(const float (&x)[5], float phase, int lane, int (&dirs)[DirShare<PD, PF, DD, DF>::n_dwords]) {
+  const int c = lane & 31;
+  const int q = c < DD * DF ? c : 0;                 // this lane's direction slot
+  const float xs = q >= DF ? x[PD + 1] : x[PD];
+  const float rev = __builtin_amdgcn_fractf(xs * ldexpf(0.5f, q % DF)) + phase;
+  const float v = __builtin_amdgcn_sinf(rev);
+  // the neighbour's value (lanes 2j <-> 2j+1): quad_perm [1,0,3,2]
+  const float w = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  float2v pr = {v, w};                                // correct order in the even lane of each pair
+  const int packed = __builtin_bit_cast(int, __builtin_convertvector(pr, half2v));
+#pragma unroll
+  for (int j = 0; j < DirShare<PD, PF, DD, DF>::n_dwords; ++j)
+    dirs[j] = __builtin_amdgcn_ds_bpermute(4 * ((lane & 32) + 2 * j), packed);
+}
+
 // dword E (0..3) of the B fragment of k-step KK for one column tile
-template <class ES, int PD, int PF, int DD, int DF, int KK, int E>
-__device__ __forceinline__ int encode_unit(const float (&x)[5], float phase) {
+template <class ES, int PD, int PF, int DD, int DF, bool SHARE, int KK, int E>
+__device__ __forceinline__ int encode_unit(const float (&x)[5], float phase, const int (&dirs)[DirShare<PD, PF, DD, DF>::n_dwords]) {
   constexpr int p0 = 8 * KK + 2 * E, p1 = p0 + 1;
-  if constexpr (p1 < ES::n_pairs) {
+  if constexpr (SHARE && p0 >= PD * PF && p1 < ES::n_pairs) {
+    return dirs[(p0 - PD * PF) / 2];
+  } else if constexpr (p1 < ES::n_pairs) {
     int r;
     float t0, t1;
     using S0 = SlotInfo<PD, PF, DD, DF, p0>;
@@ -252,25 +285,27 @@ __device__ __forceinline__ int encode_unit(const float (&x)[5], float phase) {
     return __builtin_bit_cast(int, v);
   }
 }
-template <class ES, int PD, int PF, int DD, int DF, int CT, int KK, int U0, int U1>
-__device__ __forceinline__ void encode_units(const float (&xin)[CT][5], float phase, half8 (&b)[CT]) {
+template <class ES, int PD, int PF, int DD, int DF, int CT, bool SHARE, int KK, int U0, int U1>
+__device__ __forceinline__ void encode_units(const float (&xin)[CT][5], float phase, half8 (&b)[CT],
+                                             const int (&dirs)[CT][DirShare<PD, PF, DD, DF>::n_dwords]) {
   if constexpr (U0 < U1) {   // unit U: column tile U / 4, dword U % 4
     constexpr int ct = U0 / 4, e = U0 % 4;
     rtxn::int4v t = __builtin_bit_cast(rtxn::int4v, b[ct]);
-    t[e] = encode_unit<ES, PD, PF, DD, DF, KK, e>(xin[ct], phase);
+    t[e] = encode_unit<ES, PD, PF, DD, DF, SHARE, KK, e>(xin[ct], phase, dirs[ct]);
     b[ct] = __builtin_bit_cast(half8, t);
-    encode_units<ES, PD, PF, DD, DF, CT, KK, U0 + 1, U1>(xin, phase, b);
+    encode_units<ES, PD, PF, DD, DF, CT, SHARE, KK, U0 + 1, U1>(xin, phase, b, dirs);
   }
 }
 
-template <class ES, int PD, int PF, int DD, int DF, int RT, int KS0, int NB, int CT, int I>
+template <class ES, int PD, int PF, int DD, int DF, int RT, int KS0, int NB, int CT, bool SHARE, int I>
 struct Layer0Step {
+  using DirTab = int[CT][DirShare<PD, PF, DD, DF>::n_dwords];
   static constexpr int D = RTXN_PIPE, N = RT * KS0, WAVES = RTXN_NW;
   static constexpr int CHUNKS = N < 32 / WAVES ? N : 32 / WAVES;
   static constexpr int UE = (4 * CT + RT - 1) / RT;   // encode units per (kk, rt) sub-step
   __device__ static __forceinline__ void run(unsigned addr, const float (&xin)[CT][5], float phase, half8 (&b)[2][CT],
                                              half8 (&out)[NB][CT], half8 (&ring)[D], floatx16 (&acc)[RT][CT],
-                                             const rtxn::StageJob& sj, int wave_u, int lane) {
+                                             const rtxn::StageJob& sj, int wave_u, int lane, const DirTab& dirs) {
     constexpr int kk = I / RT, rt = I % RT, cur = kk & 1;
     constexpr int outstanding = (N - 1 - I) < (D - 1) ? (N - 1 - I) : (D - 1);
     rtxn::lds_wait<outstanding>();
@@ -285,7 +320,7 @@ struct Layer0Step {
     for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[cur][ct], acc[rt][ct], 0, 0, 0);
     if constexpr (kk + 1 < KS0) {
       constexpr int u0 = rt * UE < 4 * CT ? rt * UE : 4 * CT, u1 = (rt + 1) * UE < 4 * CT ? (rt + 1) * UE : 4 * CT;
-      encode_units<ES, PD, PF, DD, DF, CT, kk + 1, u0, u1>(xin, phase, b[cur ^ 1]);
+      encode_units<ES, PD, PF, DD, DF, CT, SHARE, kk + 1, u0, u1>(xin, phase, b[cur ^ 1], dirs);
     } else if constexpr (rt > 0) {
       rtxn::convert_units<NB, CT, 0, 8 * CT>(acc[rt - 1], out, 2 * (rt - 1));   // last k-step: row tile rt-1 is complete
     }
@@ -295,13 +330,15 @@ struct Layer0Step {
       rtxn::stage_chunk<I, WAVES>(sj, wave_u, lane);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr (I + 1 < N) Layer0Step<ES, PD, PF, DD, DF, RT, KS0, NB, CT, I + 1>::run(addr, xin, phase, b, out, ring, acc, sj, wave_u, lane);
+    if constexpr (I + 1 < N)
+      Layer0Step<ES, PD, PF, DD, DF, RT, KS0, NB, CT, SHARE, I + 1>::run(addr, xin, phase, b, out, ring, acc, sj, wave_u, lane, dirs);
   }
 };
 
 // Leaves row tiles 0..RT-2 converted in out[] and the last one pending in pend[] (= acc2[1] of the kernel).
-template <class ES, int PD, int PF, int DD, int DF, int RT, int KS0, int NB, int CT>
+template <class ES, int PD, int PF, int DD, int DF, int RT, int KS0, int NB, int CT, bool SHARE>
 __device__ __forceinline__ void pipe_layer0(const uint8_t* lds_buf, const rtxn::StageJob& sj, const float (&xin)[CT][5], float phase,
+                                            const int (&dirs)[CT][DirShare<PD, PF, DD, DF>::n_dwords],
                                             half8 (&out)[NB][CT], floatx16 (&pend)[CT], int wave_u, int lane) {
   constexpr int D = RTXN_PIPE, N = RT * KS0;
   static_assert(N * 1024 <= 65535 + 1024, "fragment offsets must fit the 16-bit ds offset");
@@ -313,9 +350,9 @@ __device__ __forceinline__ void pipe_layer0(const uint8_t* lds_buf, const rtxn::
   if constexpr (D > 2) rtxn::lds_read_frag<((2 % RT) * KS0 + 2 / RT) * 1024>(ring[2 % D], addr);
   if constexpr (D > 3) rtxn::lds_read_frag<((3 % RT) * KS0 + 3 / RT) * 1024>(ring[3 % D], addr);
   half8 b[2][CT];
-  encode_units<ES, PD, PF, DD, DF, CT, 0, 0, 4 * CT>(xin, phase, b[0]);   // k-step 0: nothing to hide behind yet
+  encode_units<ES, PD, PF, DD, DF, CT, SHARE, 0, 0, 4 * CT>(xin, phase, b[0], dirs);   // k-step 0: nothing to hide behind yet
   floatx16 acc[RT][CT];
-  Layer0Step<ES, PD, PF, DD, DF, RT, KS0, NB, CT, 0>::run(addr, xin, phase, b, out, ring, acc, sj, wave_u, lane);
+  Layer0Step<ES, PD, PF, DD, DF, RT, KS0, NB, CT, SHARE, 0>::run(addr, xin, phase, b, out, ring, acc, sj, wave_u, lane, dirs);
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) pend[ct] = acc[RT - 1][ct];
 }
@@ -462,6 +499,14 @@ __global__ __launch_bounds__(64 * RTXN_NW, CT == 2 ? 2 : 1) void mlp_fwd_kernel(
       }
 #endif
 
+    // segment input: the column tile's direction features, computed once per lane-half and broadcast (DirShare)
+    constexpr bool SHARE = RTXN_SHARE_DIR && IN_MODE == 1 && DirShare<PD, PF, DD, DF>::possible && !(RTXN_ABLATE & 1);
+    int dirs[CT][DirShare<PD, PF, DD, DF>::n_dwords];
+    if constexpr (SHARE) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) share_direction<PD, PF, DD, DF>(xin[ct], phase, lane, dirs[ct]);
+    }
+
     // ---- layers ----  (two fragment sets used ping-pong: no register copies between layers)
     half8 bg[NB][CT];
     floatx16 acc2[2][CT];
@@ -550,7 +595,7 @@ __global__ __launch_bounds__(64 * RTXN_NW, CT == 2 ? 2 : 1) void mlp_fwd_kernel(
 #elif defined(RTXN_L0_PLAIN)
       pipe_layer<RT, KS0, NB, CT, false>(w, sj, bf, bg, acc2, wave_u, lane);
 #else
-      pipe_layer0<ES, PD, PF, DD, DF, RT, KS0, NB, CT>(w, sj, xin, phase, bg, acc2[1], wave_u, lane);
+      pipe_layer0<ES, PD, PF, DD, DF, RT, KS0, NB, CT, SHARE>(w, sj, xin, phase, dirs, bg, acc2[1], wave_u, lane);
 #endif
     }
     int l = 1;
