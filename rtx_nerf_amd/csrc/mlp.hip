@@ -735,12 +735,25 @@ __global__ __launch_bounds__(kThreads256, 2) void mlp_fwd256_kernel(FwdArgs a) {
     const long samp = samp_n;
     const float d0 = d0_n, dr = dr_n;
     const float phase = 0.25f * (float)h;
+    constexpr bool SHARE = RTXN_SHARE_DIR && IN_MODE == 1 && DirShare<PD, PF, DD, DF>::possible;
+    int dirs[DirShare<PD, PF, DD, DF>::n_dwords];
+    if constexpr (SHARE) share_direction<PD, PF, DD, DF>(xin, phase, lane, dirs);   // one segment per column tile
 #pragma unroll
     for (int kk = 0; kk < KS0; ++kk) {
-      half8 v;
+      rtxn::int4v v;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = encode_slot<ES, PD, PF, DD, DF>(8 * kk + j, xin, phase);
-      bf[kk][0] = v;
+      for (int e = 0; e < 4; ++e) {
+        const int p0 = 8 * kk + 2 * e;
+        if (SHARE && p0 >= PD * PF && p0 + 1 < ES::n_pairs) {
+          v[e] = dirs[(p0 - PD * PF) / 2];
+        } else {
+          half2v h2;
+          h2[0] = encode_slot<ES, PD, PF, DD, DF>(p0, xin, phase);
+          h2[1] = encode_slot<ES, PD, PF, DD, DF>(p0 + 1, xin, phase);
+          v[e] = __builtin_bit_cast(int, h2);
+        }
+      }
+      bf[kk][0] = __builtin_bit_cast(half8, v);
     }
     if (IN_MODE == 1 && OUT_MODE != 2 && a.t_vals && valid && h == 0) a.t_vals[samp] = (float)(col + 1) * (1.0f / 32);
     chunk_in_tile = 0;
