@@ -110,6 +110,9 @@ def main():
     net = api.Network(n_neurons=args.neurons, n_hidden_layers=args.layers)
     params = scenes.xavier_params_fp16(args.neurons, args.layers, net.encoded_width(), seed=1337)
     net.set_params(torch.from_numpy(params).cuda())
+    if world > 1 and not rehearse:
+        net.set_reserved_cus(4)   # the per-frame RCCL gather runs beside the MLP kernel: give its kernels somewhere to land
+                                  # (free: the chip is power-limited under this kernel, 4 idle CUs cost no time -- DESIGN 3.4)
     if args.scene == "lego":
         focal = scenes.lego_focal_length(True)
         poses = [scenes.pose_spherical(360.0 * i / args.poses + 15.0, -30.0, origin_scale=10.0) for i in range(args.poses)]

@@ -219,6 +219,10 @@ int rtxn_mlp_destroy(rtxn_mlp* m);
 /* number of fp16 parameters, tcnn layout: per layer a row-major [out][in]
  * matrix (first: n_neurons x enc_padded; hidden: n_neurons^2; last: 16 x
  * n_neurons), layers concatenated. */
+/* The fused inference kernels run a persistent grid that fills every CU.  Work launched beside them on other streams
+ * co-resides only if it fits the CU's left-over registers/LDS (this library's traversal, scan and compositor kernels do);
+ * a collective library's kernels may not.  n_cus > 0 keeps that many CUs free of MLP blocks (default 0). */
+int rtxn_mlp_set_reserved_cus(rtxn_mlp* m, int n_cus);
 long rtxn_mlp_n_params(const rtxn_mlp* m);
 int rtxn_mlp_padded_output_width(const rtxn_mlp* m); /* 16 (main.cu:715) */
 int rtxn_mlp_encoded_width(const rtxn_mlp* m);       /* padded to a multiple of 16 */

@@ -201,6 +201,10 @@ class Network:
     def padded_output_width(self):
         return int(_lib.lib().rtxn_mlp_padded_output_width(self._h))
 
+    def set_reserved_cus(self, n_cus):
+        """Keep n_cus CUs free of the persistent inference grid (for a collective library's kernels on other streams)."""
+        check(_lib.lib().rtxn_mlp_set_reserved_cus(self._h, int(n_cus)), "rtxn_mlp_set_reserved_cus")
+
     def encoded_width(self):
         return int(_lib.lib().rtxn_mlp_encoded_width(self._h))
 

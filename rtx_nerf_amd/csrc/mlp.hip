@@ -923,7 +923,8 @@ int launch_fwd(const rtxn_mlp* m, FwdArgs& a, int in_mode, int out_mode, long n_
     RTXN_HIP(hipGetDeviceProperties(&prop, dev));
     n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
-  long grid = n_tiles < (long)n_cu * v.blocks_per_cu ? n_tiles : (long)n_cu * v.blocks_per_cu;  // persistent grid
+  const int cus = n_cu - m->reserved_cus > 1 ? n_cu - m->reserved_cus : 1;
+  long grid = n_tiles < (long)cus * v.blocks_per_cu ? n_tiles : (long)cus * v.blocks_per_cu;  // persistent grid
   if (grid < 1) grid = 1;
   fwd_fn fn = v.fn[in_mode][out_mode];
   static bool attr_set[16][2][3] = {};
@@ -997,6 +998,13 @@ extern "C" int rtxn_mlp_destroy(rtxn_mlp* m) {
   if (m->packed_train) (void)hipFree(m->packed_train);
   if (m->packed_t) (void)hipFree(m->packed_t);
   delete m;
+  return RTXN_OK;
+}
+
+extern "C" int rtxn_mlp_set_reserved_cus(rtxn_mlp* m, int n_cus) {
+  RTXN_REQUIRE(m != nullptr, "rtxn_mlp_set_reserved_cus: NULL model");
+  RTXN_REQUIRE(n_cus >= 0 && n_cus <= 64, "rtxn_mlp_set_reserved_cus: n_cus = %d out of [0,64]", n_cus);
+  m->reserved_cus = n_cus;
   return RTXN_OK;
 }
 

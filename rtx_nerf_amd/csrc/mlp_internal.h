@@ -16,6 +16,7 @@ struct rtxn_mlp {
   int k0;           // inference kernel: first-layer K as staged (multiple of 16 covering all encode slots)
   long n_params;
   int variant;      // index into the inference kernel table, -1 if this model has no fused inference kernel
+  int reserved_cus; // CUs the persistent inference grid leaves free (rtxn_mlp_set_reserved_cus)
   // device buffers owned by the model, (re)built by rtxn_mlp_set_params
   void* packed;       // inference: A fragments, layer 0 in the sin/cos-pair slot order
   size_t packed_bytes;
