@@ -70,6 +70,8 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--fused", action="store_true", help="per-segment compositing in the MLP epilogue (measured slower: frame is MFMA-bound)")
     ap.add_argument("--kernel-steps", type=int, default=5, help="extra frames with HIP events around the MLP kernel")
+    ap.add_argument("--no-compact", action="store_true", help="fp32 float4 radiance + t_vals between the MLP kernel and the compositor "
+                    "(the reference's convertHalfToFloat layout) instead of the network's half outputs")
     ap.add_argument("--serial", action="store_true", help="one stream, stages of a frame strictly one after another (no frame pipelining)")
     ap.add_argument("--emulate-shard-of", type=int, default=0, metavar="N", help="diagnostic, single process: render only rank 0's "
                     "row shard of an N-rank run (no collective) to see what one rank's frame costs; the JSON line is marked "
@@ -124,7 +126,7 @@ def main():
     sh = RowShard(W, H, 0, args.emulate_shard_of) if (args.emulate_shard_of > 1 and world == 1) else RowShard(W, H, rank, world)
     n_local, ray_begin = sh.n_local, sh.ray_begin
     pipe = render.RenderPipeline(net, R, W, H, focal, occupancy=occ, max_rays=n_local, max_segments=1024,
-                                 window=sh.window, fused=args.fused)
+                                 window=sh.window, fused=args.fused, compact=False if (args.no_compact or args.fused) else None)
     worst = pipe.calibrate(poses, ray_begin=ray_begin, ray_count=n_local)
     poses_d = [torch.from_numpy(p.reshape(16)).cuda() for p in poses]
 
@@ -207,12 +209,7 @@ def main():
         pipe._trace(ray_begin, n_local, write=True)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        if pipe.fused:
-            net.forward_segments_composite(pipe.start, pipe.end, pipe.seg_view, pipe.seg_first, pipe.total,
-                                           pipe.max_segments, pipe.seg_out, pipe.vr_mode, pipe.step_scale)
-        else:
-            net.forward_segments(pipe.start, pipe.end, pipe.seg_view, pipe.total, pipe.max_segments, pipe.radiance,
-                                 pipe.t_vals)
+        pipe._shade(pipe._slots[0])   # the MLP launch exactly as the frames above make it
         e1.record()
         torch.cuda.synchronize()
         kern_ms.append(e0.elapsed_time(e1))
@@ -255,7 +252,7 @@ def main():
         if ms:
             ach = flops * smp / (ms * 1e-3) / 1e12
             out["roofline"] = {
-                "kernel": f"mlp_fwd_kernel<{args.neurons},3,10,2,12,segments,{'segment-composite' if args.fused else 'radiance'}>",
+                "kernel": f"mlp_fwd_kernel<{args.neurons},3,10,2,12,segments,{'segment-composite' if args.fused else ('half4' if pipe.compact else 'radiance')}>",
                 "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": pmc_traffic(smp),
                 "flop_per_sample": flops, "samples_per_launch": smp, "kernel_ms": round(ms, 4),

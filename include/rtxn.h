@@ -249,6 +249,16 @@ int rtxn_mlp_forward_segments(const rtxn_mlp* m, const float* start_points, cons
                               const float* seg_view, const int* total_segments, long max_segments,
                               float* radiance, float* t_vals, rtxn_stream_t stream);
 
+/* Compact form of the two calls above for the render pipeline: the kernel stores the network's own four half outputs per
+ * sample (half[N][4], 8 B instead of the 16-B float4 of convertHalfToFloat, main.cu:203-208) and no t_vals -- REGULAR
+ * sampling makes them (i + 1)/32 of the sample index -- and rtxn_volrender_fwd_compact consumes exactly that.  Pixels are
+ * bit-identical to rtxn_mlp_forward_segments + rtxn_volrender_fwd(RTXN_VR_COMPAT) at 40 % of the HBM traffic. */
+int rtxn_mlp_forward_segments_compact(const rtxn_mlp* m, const float* start_points, const float* end_points,
+                                      const float* seg_view, const int* total_segments, long max_segments,
+                                      void* radiance_half4, rtxn_stream_t stream);
+int rtxn_volrender_fwd_compact(const void* radiance_half4, const int* num_hits, const int* indices, int batch_size,
+                               int num_samples_per_hit, float* pixels, rtxn_stream_t stream);
+
 /* Fused compositor, first half: as rtxn_mlp_forward_segments, but instead of per-sample radiance the kernel
  * composites each segment's 32 samples in its epilogue and writes ONE record per segment,
  * seg_out[s] = (C_r, C_g, C_b, X) with C = sum_i w_i c_i and X = sum_i delta_i sigma_i over the segment

@@ -106,6 +106,8 @@ SYMBOLS = {
     "rtxn_mlp_forward": (_I, [_P, _P, _P, _L, _P]),
     "rtxn_mlp_forward_radiance": (_I, [_P, _P, _P, _L, _P]),
     "rtxn_mlp_forward_segments": (_I, [_P, _P, _P, _P, _P, _L, _P, _P, _P]),
+    "rtxn_mlp_forward_segments_compact": (_I, [_P, _P, _P, _P, _P, _L, _P, _P]),
+    "rtxn_volrender_fwd_compact": (_I, [_P, _P, _P, _I, _I, _P, _P]),
     "rtxn_mlp_forward_segments_composite": (_I, [_P, _P, _P, _P, _P, _P, _L, _P, _I, _F, _P]),
     "rtxn_composite_segments": (_I, [_P, _P, _P, _I, _P, _P]),
     "rtxn_padded_samples": (_L, [_L]),

@@ -257,6 +257,26 @@ class Network:
         return radiance
 
 
+def _net_forward_segments_compact(self, start_points, end_points, seg_view, total_segments, max_segments, radiance_half4):
+    """As forward_segments, but stores the network's four half outputs per sample (half[N, 4]) and no t_vals."""
+    check(_lib.lib().rtxn_mlp_forward_segments_compact(
+        self._h, _ptr(start_points, torch.float32, "start_points"), _ptr(end_points, torch.float32, "end_points"),
+        _ptr(seg_view, torch.float32, "seg_view"), _ptr(total_segments, torch.int32, "total_segments"),
+        max_segments, _ptr(radiance_half4, torch.float16, "radiance_half4"), _stream()), "rtxn_mlp_forward_segments_compact")
+    return radiance_half4
+
+
+Network.forward_segments_compact = _net_forward_segments_compact
+
+
+def volrender_compact(radiance_half4, num_hits, indices, batch_size, num_samples_per_hit, pixels):
+    """RTXN_VR_COMPAT compositing of half[N, 4] radiance with the implicit REGULAR t_vals (i + 1) / K."""
+    check(_lib.lib().rtxn_volrender_fwd_compact(_ptr(radiance_half4, torch.float16, "radiance_half4"),
+                                                _ptr(num_hits, torch.int32, "num_hits"), _ptr(indices, torch.int32, "indices"),
+                                                batch_size, num_samples_per_hit, _ptr(pixels, torch.float32, "pixels"), _stream()),
+          "rtxn_volrender_fwd_compact")
+
+
 def _net_forward_segments_composite(self, start_points, end_points, seg_view, seg_first, total_segments, max_segments,
                                     seg_out, mode=VR_COMPAT, step_scale=1.0):
     """sampler + forward + glue + the per-segment half of the compositor in one launch (16 B/segment out)."""

@@ -576,6 +576,14 @@ __global__ __launch_bounds__(64 * RTXN_NW, CT == 2 ? 2 : 1) void mlp_fwd_kernel(
             _Float16* o = a.out_half + samp * 16;
             *reinterpret_cast<half4v*>(o + 4 * h) = lo;
             *reinterpret_cast<half4v*>(o + 8 + 4 * h) = hi;
+          } else if (OUT_MODE == 3) {
+            // compact: the four half outputs themselves (8 B/sample); the consumer widens them (rtxn_volrender_fwd_compact)
+            if (h == 0) {
+              half4v o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = (_Float16)y[e];
+              *reinterpret_cast<half4v*>(a.out_half + samp * 4) = o;
+            }
           } else if (h == 0) {
             // radiance = fp32(fp16(y)): the half output of network->forward, then convertHalfToFloat
             a.radiance[samp] = make_float4((float)(_Float16)y[0], (float)(_Float16)y[1],
@@ -806,6 +814,13 @@ __global__ __launch_bounds__(kThreads256, 2) void mlp_fwd256_kernel(FwdArgs a) {
         _Float16* o = a.out_half + samp * 16;
         *reinterpret_cast<half4v*>(o + 4 * h) = lo;
         *reinterpret_cast<half4v*>(o + 8 + 4 * h) = hi;
+      } else if (OUT_MODE == 3) {
+        if (h == 0) {
+          half4v o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (_Float16)y[e];
+          *reinterpret_cast<half4v*>(a.out_half + samp * 4) = o;
+        }
       } else if (h == 0) {
         a.radiance[samp] = make_float4((float)(_Float16)y[0], (float)(_Float16)y[1], (float)(_Float16)y[2],
                                        (float)(_Float16)y[3]);
@@ -821,7 +836,7 @@ typedef void (*fwd_fn)(FwdArgs);
 
 struct Variant {
   int W, PD, PF, DD, DF;
-  fwd_fn fn[2][3];  // [IN_MODE][OUT_MODE]; OUT_MODE 2 (segment composite) exists for IN_MODE 1 only
+  fwd_fn fn[2][4];  // [IN_MODE][OUT_MODE]; OUT_MODE 2 (segment composite) and 3 (compact half4) exist for IN_MODE 1 only
   int k0;
   size_t lds;
   int threads;        // block size
@@ -845,6 +860,8 @@ Variant make_variant() {
   v.fn[1][1] = mlp_fwd_kernel<W, PD, PF, DD, DF, 1, 1, CT>;
   v.fn[0][2] = nullptr;
   v.fn[1][2] = mlp_fwd_kernel<W, PD, PF, DD, DF, 1, 2, CT>;
+  v.fn[0][3] = nullptr;
+  v.fn[1][3] = mlp_fwd_kernel<W, PD, PF, DD, DF, 1, 3, CT>;
   v.k0 = ES::k0;
   v.lds = (RTXN_SKEW && RTXN_NW == 8) ? (size_t)L0 + KS * 1024 + 3 * (size_t)HID : 2 * (size_t)(L0 > HID ? L0 : HID);
   v.threads = 64 * RTXN_NW;
@@ -864,6 +881,8 @@ Variant make_variant256() {
   v.fn[1][1] = mlp_fwd256_kernel<PD, PF, DD, DF, 1, 1>;
   v.fn[0][2] = nullptr;
   v.fn[1][2] = mlp_fwd256_kernel<PD, PF, DD, DF, 1, 2>;
+  v.fn[0][3] = nullptr;
+  v.fn[1][3] = mlp_fwd256_kernel<PD, PF, DD, DF, 1, 3>;
   v.k0 = ES::k0;
   v.lds = 3 * (size_t)kSlot256;
   v.threads = kThreads256;
@@ -927,7 +946,7 @@ int launch_fwd(const rtxn_mlp* m, FwdArgs& a, int in_mode, int out_mode, long n_
   long grid = n_tiles < (long)cus * v.blocks_per_cu ? n_tiles : (long)cus * v.blocks_per_cu;  // persistent grid
   if (grid < 1) grid = 1;
   fwd_fn fn = v.fn[in_mode][out_mode];
-  static bool attr_set[16][2][3] = {};
+  static bool attr_set[16][2][4] = {};
   if (!attr_set[m->variant][in_mode][out_mode]) {
     RTXN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)v.lds));
@@ -1112,6 +1131,28 @@ extern "C" int rtxn_mlp_forward_segments(const rtxn_mlp* m, const float* start_p
   a.radiance = reinterpret_cast<float4*>(radiance);
   a.t_vals = t_vals;
   return launch_fwd(m, a, 1, 1, max_segments, rtxn::as_stream(stream));
+}
+
+extern "C" int rtxn_mlp_forward_segments_compact(const rtxn_mlp* m, const float* start_points, const float* end_points,
+                                                 const float* seg_view, const int* total_segments, long max_segments,
+                                                 void* radiance_half4, rtxn_stream_t stream) {
+  int rc = check_ready(m, "rtxn_mlp_forward_segments_compact");
+  if (rc != RTXN_OK) return rc;
+  RTXN_REQUIRE(max_segments >= 0, "rtxn_mlp_forward_segments_compact: max_segments = %ld < 0", max_segments);
+  RTXN_DEVICE_OR_FAIL();
+  if (max_segments == 0) return RTXN_OK;
+  RTXN_REQUIRE(start_points && end_points && seg_view && total_segments && radiance_half4,
+               "rtxn_mlp_forward_segments_compact: NULL buffer");
+  RTXN_REQUIRE(((uintptr_t)radiance_half4 & 7) == 0, "rtxn_mlp_forward_segments_compact: radiance must be 8-byte aligned");
+  FwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.start = start_points;
+  a.end = end_points;
+  a.seg_view = seg_view;
+  a.total_segments = total_segments;
+  a.max_segments = max_segments;
+  a.out_half = static_cast<_Float16*>(radiance_half4);
+  return launch_fwd(m, a, 1, 3, max_segments, rtxn::as_stream(stream));
 }
 
 extern "C" int rtxn_mlp_forward_segments_composite(const rtxn_mlp* m, const float* start_points, const float* end_points,

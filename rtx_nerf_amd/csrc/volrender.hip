@@ -38,7 +38,14 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-template <int MODE>
+struct alignas(8) half4 {
+  __half x, y, z, w;
+};
+
+// COMPACT: radiance is half[N][4] (the network's own output, 8 B/sample instead of 16) and t_vals are not read at all:
+// REGULAR sampling makes them the function (i + 1) / K of the sample index (sampler.cu:52-66).  Same arithmetic from there
+// on, so the pixels are bit-identical to the float4 + t_vals form at 40 % of its bytes.
+template <int MODE, bool COMPACT = false>
 __global__ __launch_bounds__(256) void volrender_fwd_kernel(const float4* __restrict__ radiance,
                                                             const int* __restrict__ num_hits,
                                                             const int* __restrict__ indices,
@@ -56,8 +63,14 @@ __global__ __launch_bounds__(256) void volrender_fwd_kernel(const float4* __rest
     float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
     float t = 0.0f;
     if (act) {
-      c = radiance[base + s0 + lane];
-      t = ray_hit[base + s0 + lane];
+      if (COMPACT) {
+        const half4 c16 = reinterpret_cast<const half4*>(radiance)[base + s0 + lane];
+        c = make_float4(__half2float(c16.x), __half2float(c16.y), __half2float(c16.z), __half2float(c16.w));
+        t = (float)((int)((s0 + lane) % K) + 1) * (1.0f / (float)K);
+      } else {
+        c = radiance[base + s0 + lane];
+        t = ray_hit[base + s0 + lane];
+      }
     }
     float x, w;
     if (MODE == RTXN_VR_COMPAT) {
@@ -90,10 +103,6 @@ __global__ __launch_bounds__(256) void volrender_fwd_kernel(const float4* __rest
     pixels[3 * (long)ray + 2] = ab;
   }
 }
-
-struct alignas(8) half4 {
-  __half x, y, z, w;
-};
 
 // COMPAT backward: per-sample, reference vol_render.cu:75-143 (not the analytic
 // gradient of the forward).
@@ -279,6 +288,21 @@ extern "C" int rtxn_volrender_fwd(const float* network_inputs, const float* netw
     volrender_fwd_kernel<RTXN_VR_NERF><<<grid, block, 0, s>>>(rad, num_hits, indices, ray_hit, batch_size,
                                                                num_samples_per_hit, pixels);
   RTXN_LAUNCH_CHECK("volrender_fwd_kernel");
+  return RTXN_OK;
+}
+
+extern "C" int rtxn_volrender_fwd_compact(const void* radiance_half4, const int* num_hits, const int* indices, int batch_size,
+                                          int num_samples_per_hit, float* pixels, rtxn_stream_t stream) {
+  RTXN_REQUIRE(batch_size >= 0, "rtxn_volrender_fwd_compact: batch_size = %d < 0", batch_size);
+  RTXN_REQUIRE(num_samples_per_hit > 0, "rtxn_volrender_fwd_compact: num_samples_per_hit = %d", num_samples_per_hit);
+  RTXN_DEVICE_OR_FAIL();
+  if (batch_size == 0) return RTXN_OK;
+  RTXN_REQUIRE(radiance_half4 && num_hits && indices && pixels, "rtxn_volrender_fwd_compact: NULL buffer");
+  RTXN_REQUIRE(((uintptr_t)radiance_half4 & 7) == 0, "rtxn_volrender_fwd_compact: radiance must be 8-byte aligned");
+  dim3 grid((batch_size + 3) / 4), block(256);
+  volrender_fwd_kernel<RTXN_VR_COMPAT, true><<<grid, block, 0, rtxn::as_stream(stream)>>>(
+      static_cast<const float4*>(radiance_half4), num_hits, indices, nullptr, batch_size, num_samples_per_hit, pixels);
+  RTXN_LAUNCH_CHECK("volrender_fwd_kernel<compact>");
   return RTXN_OK;
 }
 

@@ -21,7 +21,7 @@ from . import api
 class RenderPipeline:
     def __init__(self, network, grid_res, width, height, focal_length, aspect_ratio=None, occupancy=None,
                  max_rays=None, max_segments=None, trace_mode=api.TRACE_DDA, vr_mode=api.VR_COMPAT,
-                 device="cuda", window=(0, 0), fused=False, step_scale=1.0, sub_rays=None):
+                 device="cuda", window=(0, 0), fused=False, step_scale=1.0, sub_rays=None, compact=None):
         self.net = network
         self.R = grid_res
         self.W, self.H = width, height
@@ -39,6 +39,12 @@ class RenderPipeline:
         # MFMA/issue-bound, not HBM-bound, and the scan in the epilogue costs the MLP kernel 6.5 % while the
         # per-sample round trip it removes is only 2 % of the frame.  Fusion stays available for HBM-capacity reasons.
         self.fused, self.step_scale = fused, step_scale
+        # compact (default wherever it applies: unfused RTXN_VR_COMPAT): the MLP kernel hands the compositor the network's
+        # own half outputs (8 B/sample) and no t_vals (REGULAR sampling makes them (i+1)/32) -- bit-identical pixels at
+        # 40 % of the intermediate's bytes (0.8 instead of 2.0 GB per bench frame)
+        self.compact = (not fused and vr_mode == api.VR_COMPAT) if compact is None else bool(compact)
+        if self.compact and (fused or vr_mode != api.VR_COMPAT):
+            raise ValueError("compact needs the unfused RTXN_VR_COMPAT pipeline")
         self.dev = torch.device(device)
         self.occ = occupancy
         self.coarse = self.bricks = self.super_mip = None
@@ -87,6 +93,9 @@ class RenderPipeline:
             g.seg_first = torch.empty(m, dtype=torch.uint8, device=d)
             g.seg_out = torch.empty((m, 4), device=d)
             g.radiance = g.t_vals = None
+        elif self.compact:
+            g.seg_first = g.seg_out = g.t_vals = None
+            g.radiance = torch.empty((m * api.NUM_SAMPLES_PER_SEGMENT, 4), dtype=torch.float16, device=d)
         else:
             g.seg_first = g.seg_out = None
             g.radiance = torch.empty((m * api.NUM_SAMPLES_PER_SEGMENT, 4), device=d)
@@ -130,6 +139,8 @@ class RenderPipeline:
         if self.fused:
             self.net.forward_segments_composite(g.start, g.end, g.seg_view, g.seg_first, g.total,
                                                 self.max_segments, g.seg_out, self.vr_mode, self.step_scale)
+        elif self.compact:
+            self.net.forward_segments_compact(g.start, g.end, g.seg_view, g.total, self.max_segments, g.radiance)
         else:
             self.net.forward_segments(g.start, g.end, g.seg_view, g.total, self.max_segments, g.radiance, g.t_vals)
 
@@ -138,6 +149,8 @@ class RenderPipeline:
         # the write pass reports how many segments it actually stored per ray (num_hits_c)
         if self.fused:
             api.composite_segments(g.seg_out, g.num_hits_c[:n], g.indices[:n], n, pixels)
+        elif self.compact:
+            api.volrender_compact(g.radiance, g.num_hits_c[:n], g.indices[:n], n, api.NUM_SAMPLES_PER_SEGMENT, pixels)
         else:
             api.launch_volrender_cuda(None, g.radiance, g.num_hits_c[:n], g.indices[:n], g.t_vals, n,
                                       api.NUM_SAMPLES_PER_SEGMENT, pixels, mode=self.vr_mode)

@@ -23,7 +23,7 @@ def frame(gpu):
     net.set_params(torch.from_numpy(params).cuda())
     la = scenes.pose_spherical(15.0, -30.0, origin_scale=10.0)
     f = scenes.lego_focal_length(True)
-    pipe = render.RenderPipeline(net, R, W, H, f, occupancy=occ, max_segments=1024)
+    pipe = render.RenderPipeline(net, R, W, H, f, occupancy=occ, max_segments=1024, compact=False)   # fp32 radiance + t_vals kept for the property tests
     pipe.calibrate([la])
     pipe.set_pose(la)
     pix = pipe.render().clone()

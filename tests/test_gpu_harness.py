@@ -110,3 +110,29 @@ def test_pipelined_frames_equal_serial_frames(gpu):
         for o, w in zip(outs, want):
             assert torch.equal(o, w)
     assert not pipe.overflowed()
+
+
+@pytest.mark.gpu
+def test_compact_intermediate_gives_identical_pixels(gpu):
+    """half4 radiance + implicit REGULAR t_vals between the MLP kernel and the compositor (the default) vs the reference's
+    float4 + t_vals layout: the same pixels bit for bit, and the fp16 values are exactly what the fp32 buffer holds."""
+    torch = gpu
+    from rtx_nerf_amd import api, render, scenes
+    R, W, H = 64, 200, 150
+    occ = torch.from_numpy(scenes.pack_occupancy(scenes.lego_standin_density(R, seed=0)).view(np.int32).copy()).cuda()
+    net = api.Network(n_neurons=128, n_hidden_layers=3)
+    net.set_params(torch.from_numpy(scenes.xavier_params_fp16(128, 3, net.encoded_width(), seed=3)).cuda())
+    la = scenes.pose_spherical(70.0, -25.0, origin_scale=10.0)
+    focal = scenes.lego_focal_length(True)
+    pipes = [render.RenderPipeline(net, R, W, H, focal, occupancy=occ, max_segments=1024, compact=c) for c in (True, False)]
+    assert pipes[0].compact and not pipes[1].compact and pipes[0].radiance.dtype == torch.float16 and pipes[0].t_vals is None
+    outs = []
+    for p in pipes:
+        p.calibrate([la])
+        p.set_pose(la)
+        outs.append(p.render().clone())
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and float(outs[0].abs().sum()) > 0
+    S = int(pipes[0].total.item()) * 32
+    assert torch.equal(pipes[0].radiance[:S].float(), pipes[1].radiance[:S])
+    assert render.RenderPipeline(net, R, W, H, focal, occupancy=occ, vr_mode=api.VR_NERF).compact is False

@@ -25,7 +25,7 @@ occ = torch.from_numpy(scenes.pack_occupancy(scenes.lego_standin_density(R, seed
 net = api.Network(n_neurons=128, n_hidden_layers=8)
 net.set_params(torch.from_numpy(scenes.xavier_params_fp16(128, 8, net.encoded_width(), seed=1337)).cuda())
 pose = scenes.pose_spherical(15.0, -30.0, origin_scale=10.0)
-pipe = render.RenderPipeline(net, R, W, H, scenes.lego_focal_length(True), occupancy=occ, max_segments=1024)
+pipe = render.RenderPipeline(net, R, W, H, scenes.lego_focal_length(True), occupancy=occ, max_segments=1024, compact=False)
 P = pipe.calibrate([pose])
 pipe.set_pose(pose)
 pipe.render()
@@ -36,6 +36,7 @@ t_vals = torch.empty(S, device="cuda")
 pixels = torch.empty((n, 3), device="cuda")
 lgrad = (torch.randn((n, 3), device="cuda") * 0.1).half()
 rgrad = torch.empty((S, 4), dtype=torch.float16, device="cuda")
+rad16 = pipe.radiance[:S].half()
 
 
 def timed(fn):
@@ -65,6 +66,8 @@ stages = [
     ("mlp_forward_radiance (float[N][5] in)", lambda: net.forward_radiance(samples, pipe.radiance), None),
     ("launch_volrender_cuda COMPAT", lambda: api.launch_volrender_cuda(None, pipe.radiance, pipe.num_hits_c, pipe.indices, t_vals, n, K,
                                                                        pixels), 20 * n + 640 * P),
+    ("rtxn_volrender_fwd_compact (half4, implicit t)", lambda: api.volrender_compact(rad16, pipe.num_hits_c, pipe.indices, n, K, pixels),
+     20 * n + 256 * P),
     ("launch_volrender_cuda NERF", lambda: api.launch_volrender_cuda(None, pipe.radiance, pipe.num_hits_c, pipe.indices, t_vals, n, K,
                                                                      pixels, mode=api.VR_NERF), 20 * n + 640 * P),
     ("launch_volrender_backward_cuda COMPAT", lambda: api.launch_volrender_backward_cuda(None, lgrad, pipe.radiance, t_vals, pipe.num_hits_c,
