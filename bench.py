@@ -72,6 +72,7 @@ def parse():
     ap.add_argument("--kernel-steps", type=int, default=5, help="extra frames with HIP events around the MLP kernel")
     ap.add_argument("--no-compact", action="store_true", help="fp32 float4 radiance + t_vals between the MLP kernel and the compositor "
                     "(the reference's convertHalfToFloat layout) instead of the network's half outputs")
+    ap.add_argument("--reserve-cus", type=int, default=-1, help="CUs kept free of the persistent MLP grid (default: 4 at N > 1, else 0)")
     ap.add_argument("--serial", action="store_true", help="one stream, stages of a frame strictly one after another (no frame pipelining)")
     ap.add_argument("--emulate-shard-of", type=int, default=0, metavar="N", help="diagnostic, single process: render only rank 0's "
                     "row shard of an N-rank run (no collective) to see what one rank's frame costs; the JSON line is marked "
@@ -112,7 +113,9 @@ def main():
     net = api.Network(n_neurons=args.neurons, n_hidden_layers=args.layers)
     params = scenes.xavier_params_fp16(args.neurons, args.layers, net.encoded_width(), seed=1337)
     net.set_params(torch.from_numpy(params).cuda())
-    if world > 1 and not rehearse:
+    if args.reserve_cus >= 0:
+        net.set_reserved_cus(args.reserve_cus)
+    elif world > 1 and not rehearse:
         net.set_reserved_cus(4)   # the per-frame RCCL gather runs beside the MLP kernel: give its kernels somewhere to land
                                   # (free: the chip is power-limited under this kernel, 4 idle CUs cost no time -- DESIGN 3.4)
     if args.scene == "lego":

@@ -195,15 +195,18 @@ class RenderPipeline:
     # the frame is sharded over N GPUs (the fixed traversal latency is 16 % of a rank's frame at N = 8).
     def _async_state(self):
         if self._async is None:
+            import os
             from types import SimpleNamespace
-            while len(self._slots) < 2:
+            n_slots = int(os.environ.get("RTXN_ASYNC_SLOTS", "3"))
+            while len(self._slots) < n_slots:
                 self._slots.append(self._alloc_slot())
             a = SimpleNamespace()
+            a.n = n_slots
             a.geo, a.comp = torch.cuda.Stream(), torch.cuda.Stream()
-            a.ev_geo = [torch.cuda.Event() for _ in range(2)]
-            a.ev_mlp = [torch.cuda.Event() for _ in range(2)]
-            a.ev_comp = [torch.cuda.Event() for _ in range(2)]
-            a.used = [False, False]
+            a.ev_geo = [torch.cuda.Event() for _ in range(n_slots)]
+            a.ev_mlp = [torch.cuda.Event() for _ in range(n_slots)]
+            a.ev_comp = [torch.cuda.Event() for _ in range(n_slots)]
+            a.used = [False] * n_slots
             a.frame = 0
             self._async = a
         return self._async
@@ -215,7 +218,7 @@ class RenderPipeline:
         a = self._async_state()
         n = self.max_rays if ray_count is None else ray_count
         pixels = self.pixels[:n] if out is None else out
-        b = a.frame & 1
+        b = a.frame % a.n
         a.frame += 1
         g = self._slots[b]
         main = torch.cuda.current_stream()
