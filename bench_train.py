@@ -26,14 +26,17 @@ ap.add_argument("--warmup", type=int, default=5)
 ap.add_argument("--batch", type=int, default=4096)
 ap.add_argument("--grid", type=int, default=128)
 ap.add_argument("--encoding", default="hash")
+ap.add_argument("--neurons", type=int, default=64)
+ap.add_argument("--layers", type=int, default=4)
+ap.add_argument("--dir-freqs", type=int, default=4)
 a = ap.parse_args()
 torch.cuda.set_device(0)
 R = a.grid
 dense = scenes.lego_standin_density(R, seed=0)
 occ = torch.from_numpy(scenes.pack_occupancy(dense).view(np.int32).copy()).cuda()
-tr = Trainer(R, occ, encoding=a.encoding, n_neurons=64, n_hidden_layers=4,
+tr = Trainer(R, occ, encoding=a.encoding, n_neurons=a.neurons, n_hidden_layers=a.layers,
              hashgrid=dict(n_levels=16, n_features=2, log2_hashmap_size=19, base_resolution=16, per_level_scale=1.5),
-             n_dir_freqs=4, batch_rays=max(a.batch, 128 * 128), max_segments=max(a.batch, 128 * 128) * 24, lr=1e-2,
+             n_dir_freqs=a.dir_freqs, batch_rays=max(a.batch, 128 * 128), max_segments=max(a.batch, 128 * 128) * 24, lr=1e-2,
              loss_scale=128.0, density_scale=300.0, mode="nerf")
 focal = scenes.lego_focal_length(True)
 ro, rd, tg = [], [], []

@@ -236,10 +236,10 @@ struct DirShare {
 };
 
 template <int PD, int PF, int DD, int DF>
-__device__ __forceinline__ void share_direction(const float (&x)[5], float phase, int lane, int (&dirs)[DirShare<PD, PF, DD, DF>::n_dwords]) {
+__device__ __forceinline__ void share_direction(float theta, float phi, float phase, int lane, int (&dirs)[DirShare<PD, PF, DD, DF>::n_dwords]) {
   const int c = lane & 31;
   const int q = c < DD * DF ? c : 0;                 // this lane's direction slot
-  const float xs = q >= DF ? x[PD + 1] : x[PD];
+  const float xs = q >= DF ? phi : theta;   // by value: a select on an array element made hipcc index the array in scratch
   const float rev = __builtin_amdgcn_fractf(xs * ldexpf(0.5f, q % DF)) + phase;
   const float v = __builtin_amdgcn_sinf(rev);
   // the neighbour's value (lanes 2j <-> 2j+1): quad_perm [1,0,3,2]
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(64 * RTXN_NW, CT == 2 ? 2 : 1) void mlp_fwd_kernel(
     int dirs[CT][DirShare<PD, PF, DD, DF>::n_dwords];
     if constexpr (SHARE) {
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct) share_direction<PD, PF, DD, DF>(xin[ct], phase, lane, dirs[ct]);
+      for (int ct = 0; ct < CT; ++ct) share_direction<PD, PF, DD, DF>(xin[ct][PD], xin[ct][PD + 1], phase, lane, dirs[ct]);
     }
 
     // ---- layers ----  (two fragment sets used ping-pong: no register copies between layers)
@@ -745,7 +745,7 @@ __global__ __launch_bounds__(kThreads256, 2) void mlp_fwd256_kernel(FwdArgs a) {
     const float phase = 0.25f * (float)h;
     constexpr bool SHARE = RTXN_SHARE_DIR && IN_MODE == 1 && DirShare<PD, PF, DD, DF>::possible;
     int dirs[DirShare<PD, PF, DD, DF>::n_dwords];
-    if constexpr (SHARE) share_direction<PD, PF, DD, DF>(xin, phase, lane, dirs);   // one segment per column tile
+    if constexpr (SHARE) share_direction<PD, PF, DD, DF>(xin[PD], xin[PD + 1], phase, lane, dirs);   // one segment per column tile
 #pragma unroll
     for (int kk = 0; kk < KS0; ++kk) {
       rtxn::int4v v;

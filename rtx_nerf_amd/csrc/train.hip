@@ -304,19 +304,31 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_train_fwd_kernel(TrainArgs a)
       }
   };
   save_acts(0, bf);
+  // hidden layer on the hand-scheduled pipeline of the inference kernel (accumulators double-buffered by row tile: the
+  // compiler-scheduled loop kept all RT tiles live and spilled at W = 128); nothing is staged underneath it here, and
+  // the row tile it leaves pending is converted at once because the activations are stored after every layer
+  auto hidden_layer = [&](half8 (&in)[KS][2], half8 (&out)[KS][2]) {
+    const rtxn::StageJob none{a.packed, smem, 0};
+    floatx16 acc2[2][2];
+    rtxn::pipe_layer<RT, KS, KS, 2, false>(smem, none, in, out, acc2, 0, lane);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) out[2 * (RT - 1) + s2][ct] = rtxn::relu_pack(acc2[1][ct], s2);
+  };
   // ---- hidden layers 1..L-1 (ping-pong bf <-> bg) ----
   int l = 1;
   for (; l + 1 < L; l += 2) {
     __syncthreads();
     stage_rt(a.packed + off, smem, KS * RT * 1024, tid);
     rtxn::staged_barrier();
-    layer_mma<RT, KS, KS>(smem, bf, bg, lane);
+    hidden_layer(bf, bg);
     save_acts(l, bg);
     off += (long)KS * RT * 1024;
     __syncthreads();
     stage_rt(a.packed + off, smem, KS * RT * 1024, tid);
     rtxn::staged_barrier();
-    layer_mma<RT, KS, KS>(smem, bg, bf, lane);
+    hidden_layer(bg, bf);
     save_acts(l + 1, bf);
     off += (long)KS * RT * 1024;
   }
@@ -324,7 +336,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_train_fwd_kernel(TrainArgs a)
     __syncthreads();
     stage_rt(a.packed + off, smem, KS * RT * 1024, tid);
     rtxn::staged_barrier();
-    layer_mma<RT, KS, KS>(smem, bf, bg, lane);
+    hidden_layer(bf, bg);
     save_acts(l, bg);
     off += (long)KS * RT * 1024;
 #pragma unroll
@@ -391,93 +403,102 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_bwd_kernel(TrainArgs a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) a.dzL[(long)perm_feature(0, h, j) * a.Sp + s] = v[j];
   }
-  floatx16 dA[RT][2];
+  // One accumulator pair at a time: row tile rt of dA_{l} = W^T dZ is masked with relu'(act_l), rounded to fp16 and packed
+  // straight into the B fragments of the next (earlier) layer's MFMAs -- the backward chain stays in registers exactly as the
+  // forward does, and no full-layer fp32 dA is ever held (the first version kept one: 128 VGPRs at W = 128, 378 spills).
+  auto mask_pack_store = [&](int l, int rt, const floatx16 (&acc)[2], half8 (&dst)[KS][2]) {
+    const _Float16* act = a.acts + (long)l * W * a.Sp;
+    _Float16* dzl = a.dz + (long)l * W * a.Sp;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const long s = tile0 + ct * 32 + col;
+      floatx16 m;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int feat = 32 * rt + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const _Float16 av = act[(long)feat * a.Sp + s];
+        m[e] = (float)av > 0.0f ? acc[ct][e] : 0.0f;
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const half8 v = pack8<false>(m, s2);
+        dst[2 * rt + s2][ct] = v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dzl[(long)perm_feature(2 * rt + s2, h, j) * a.Sp + s] = v[j];
+      }
+    }
+  };
+
+  half8 bz[KS][2], bn[KS][2];
   stage_rt(a.packed, smem, RT * 1024, tid);
   rtxn::staged_barrier();
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
+  for (int rt = 0; rt < RT; ++rt) {   // dZ_{L-1}: the output layer's single k-step
     const half8 af = *reinterpret_cast<const half8*>(smem + (rt * 64 + lane) * 16);
+    floatx16 acc[2];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
       floatx16 z;
 #pragma unroll
       for (int e = 0; e < 16; ++e) z[e] = 0.0f;
-      dA[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bo[ct], z, 0, 0, 0);
+      acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bo[ct], z, 0, 0, 0);
     }
+    mask_pack_store(L - 1, rt, acc, bz);
   }
   off += (long)RT * 1024;
 
-  for (int l = L - 1; l >= 0; --l) {
-    // ---- dZ_l = relu'(act_l) (*) dA ; packed to the next MFMA's B fragments; stored feature-major ----
-    half8 bz[KS][2];
-    const _Float16* act = a.acts + (long)l * W * a.Sp;
-    _Float16* dzl = a.dz + (long)l * W * a.Sp;
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
-        const long s = tile0 + ct * 32 + col;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int feat = 32 * rt + (e & 3) + 8 * (e >> 2) + 4 * h;
-          const _Float16 av = act[(long)feat * a.Sp + s];
-          dA[rt][ct][e] = (float)av > 0.0f ? dA[rt][ct][e] : 0.0f;
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const half8 v = pack8<false>(dA[rt][ct], s2);
-          bz[2 * rt + s2][ct] = v;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) dzl[(long)perm_feature(2 * rt + s2, h, j) * a.Sp + s] = v[j];
-        }
-      }
-    if (l == 0 && !a.dencT) break;
-    // ---- dA_{l-1} = W_l^T dZ_l ----
-    const int rows_t = l == 0 ? (a.E + 31) / 32 : RT;
+  for (int l = L - 1; l >= 1; --l) {   // bz = dZ_l  ->  dZ_{l-1} = relu'(act_{l-1}) (*) W_l^T dZ_l
     __syncthreads();
-    stage_rt(a.packed + off, smem, rows_t * KS * 1024, tid);
+    stage_rt(a.packed + off, smem, RT * KS * 1024, tid);
     rtxn::staged_barrier();
-    off += (long)rows_t * KS * 1024;
-    if (l > 0) {
+    off += (long)RT * KS * 1024;
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        floatx16 acc[2];
+    for (int rt = 0; rt < RT; ++rt) {
+      floatx16 acc[2];
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
+      for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) acc[ct][e] = 0.0f;
+        for (int e = 0; e < 16; ++e) acc[ct][e] = 0.0f;
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) {
-          const half8 af = *reinterpret_cast<const half8*>(smem + ((rt * KS + kk) * 64 + lane) * 16);
+      for (int kk = 0; kk < KS; ++kk) {
+        const half8 af = *reinterpret_cast<const half8*>(smem + ((rt * KS + kk) * 64 + lane) * 16);
 #pragma unroll
-          for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bz[kk][ct], acc[ct], 0, 0, 0);
-        }
-        dA[rt][0] = acc[0];
-        dA[rt][1] = acc[1];
+        for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bz[kk][ct], acc[ct], 0, 0, 0);
       }
-    } else {
-      for (int rt = 0; rt < rows_t; ++rt) {
-        floatx16 acc[2];
+      mask_pack_store(l - 1, rt, acc, bn);
+      __builtin_amdgcn_sched_barrier(0);   // keep the tiles apart: hoisted activation loads of all tiles do not fit
+    }
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
+    for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) acc[ct][e] = 0.0f;
+      for (int ct = 0; ct < 2; ++ct) bz[kk][ct] = bn[kk][ct];
+  }
+  if (!a.dencT) return;
+  // ---- d(encoding) = W_0^T dZ_0 (hash-grid models) ----
+  const int rows_t = (a.E + 31) / 32;
+  __syncthreads();
+  stage_rt(a.packed + off, smem, rows_t * KS * 1024, tid);
+  rtxn::staged_barrier();
+  for (int rt = 0; rt < rows_t; ++rt) {
+    floatx16 acc[2];
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) {
-          const half8 af = *reinterpret_cast<const half8*>(smem + ((rt * KS + kk) * 64 + lane) * 16);
+    for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-          for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bz[kk][ct], acc[ct], 0, 0, 0);
-        }
+      for (int e = 0; e < 16; ++e) acc[ct][e] = 0.0f;
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-          const long s = tile0 + ct * 32 + col;
-          const bool ok = s < a.S;
+    for (int kk = 0; kk < KS; ++kk) {
+      const half8 af = *reinterpret_cast<const half8*>(smem + ((rt * KS + kk) * 64 + lane) * 16);
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int feat = 32 * rt + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (feat < a.E) a.dencT[(long)feat * a.Sp + s] = ok ? (_Float16)acc[ct][e] : (_Float16)0.0f;
-          }
-        }
+      for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bz[kk][ct], acc[ct], 0, 0, 0);
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const long s = tile0 + ct * 32 + col;
+      const bool ok = s < a.S;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int feat = 32 * rt + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (feat < a.E) a.dencT[(long)feat * a.Sp + s] = ok ? (_Float16)acc[ct][e] : (_Float16)0.0f;
       }
     }
   }

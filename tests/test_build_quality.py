@@ -1,0 +1,39 @@
+"""Build-time properties of the gfx950 code objects (no GPU needed: hipcc cross-compiles): no kernel may use private
+(scratch) memory or spill vector registers -- a select on an array element once made hipcc index an input array through
+scratch in two variants without anyone noticing -- and the fused MLP kernels must keep the two-waves-per-SIMD budget."""
+import glob
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+SOURCES = sorted(glob.glob(os.path.join(ROOT, "rtx_nerf_amd", "csrc", "*.hip")))
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+@pytest.mark.parametrize("src", SOURCES, ids=[os.path.basename(s) for s in SOURCES])
+def test_kernels_use_no_scratch_and_do_not_spill(src, tmp_path):
+    out = tmp_path / "k.s"
+    subprocess.check_call([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", f"-I{ROOT}/include",
+                           f"-I{ROOT}/rtx_nerf_amd/csrc", "-S", "--cuda-device-only", "-o", str(out), src],
+                          stderr=subprocess.DEVNULL, timeout=600)
+    txt = out.read_text()
+    kernels = re.findall(r"\.name:\s+(\S+)\n(.*?)\.wavefront_size", txt, re.S)
+    if "__global__" not in open(src).read():
+        return   # host-only translation unit (common.hip)
+    assert kernels, "no kernel metadata found"
+    for name, body in kernels:
+        scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", body).group(1))
+        spills = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", body).group(1))
+        vgprs = int(re.search(r"\.vgpr_count:\s+(\d+)", body).group(1))
+        if re.search(r"mlp_(train_fwd|bwd)_kernelILi128E", name):
+            # known: the 128-wide TRAINING kernels still spill (fwd 69, bwd 107 VGPRs; the bwd kernel had 378 before it
+            # stopped holding a full-layer fp32 dA) -- bounded here so that it can only get better
+            assert spills <= 120, f"{name}: {spills} VGPR spills (regressed)"
+            continue
+        assert scratch == 0 and spills == 0, f"{name}: {scratch} B scratch, {spills} VGPR spills"
+        if "mlp_fwd" in name or "mlp_train_fwd" in name or "mlp_bwd" in name:
+            assert vgprs <= 256, f"{name}: {vgprs} VGPRs break the two-waves-per-SIMD budget"
