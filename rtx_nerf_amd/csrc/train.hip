@@ -47,6 +47,8 @@ constexpr int kThreads = 256;
 constexpr int kTile = 256;
 
 inline long padded(long S) { return (S + kTile - 1) / kTile * kTile; }
+// the fused training kernels address X[feature][S_pad] with one 32-bit per-lane byte offset (row_elem): (s + 4*S_pad)*2 < 2^32
+constexpr long kMaxTrainSamples = (1L << 32) / 10 - kTile;
 
 // ------------------------------------------------------------------------- encoders
 __device__ __forceinline__ float sin_turns(float x, int f, int ph) {
@@ -246,6 +248,17 @@ struct TrainArgs {
   _Float16* dencT;          // [E][Sp] or NULL
 };
 
+// Element (feature row f0 + 4h, sample s) of a feature-major tensor X[feature][Sp]: the address is split into a wave-uniform
+// part (X + f0*Sp: scalar registers) and ONE 32-bit per-lane byte offset ((s + 4h*Sp)*2, < 2^32 for Sp < 2^28) that is the
+// same for every access of the kernel -- the global instruction takes both (saddr + voffset).  Forming a 64-bit VGPR address
+// per access instead made hipcc keep hundreds of them live across the layer loop.
+__device__ __forceinline__ _Float16* row_elem(_Float16* X, int f0, long Sp, unsigned lane_off) {
+  return reinterpret_cast<_Float16*>(reinterpret_cast<char*>(X + (long)f0 * Sp) + lane_off);
+}
+__device__ __forceinline__ const _Float16* row_elem(const _Float16* X, int f0, long Sp, unsigned lane_off) {
+  return reinterpret_cast<const _Float16*>(reinterpret_cast<const char*>(X + (long)f0 * Sp) + lane_off);
+}
+
 template <int W>
 __global__ __launch_bounds__(kThreads, 2) void mlp_train_fwd_kernel(TrainArgs a) {
   constexpr int RT = W / 32, KS = W / 16;
@@ -256,6 +269,15 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_train_fwd_kernel(TrainArgs a)
   const int L = a.n_hidden;
   long off = 0;
 
+  // per-lane byte offset of this lane's sample within a feature row, lane-half row shift (4h rows) folded in
+  unsigned lane_off[2];
+  bool ok_s[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const long s = tile0 + ct * 32 + col;
+    ok_s[ct] = s < a.S;
+    lane_off[ct] = (unsigned)((s + 4L * h * a.Sp) * 2);
+  }
   // ---- layer 0: B fragments straight from encT (8 two-byte loads per k-step per column tile) ----
   half8 bf[KS][2], bg[KS][2];
   {
@@ -271,11 +293,9 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_train_fwd_kernel(TrainArgs a)
     for (int kk = 0; kk < KS0; ++kk) {
       half8 b[2];
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
-        const long s = tile0 + ct * 32 + col;
+      for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) b[ct][j] = a.encT[(long)perm_feature(kk, h, j) * a.Sp + s];
-      }
+        for (int j = 0; j < 8; ++j) b[ct][j] = *row_elem(a.encT, perm_feature(kk, 0, j), a.Sp, lane_off[ct]);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
         const half8 af = *reinterpret_cast<const half8*>(smem + ((rt * KS0 + kk) * 64 + lane) * 16);
@@ -296,12 +316,10 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_train_fwd_kernel(TrainArgs a)
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
-        const long s = tile0 + ct * 32 + col;
-        const bool ok = s < a.S;
+      for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dst[(long)perm_feature(kk, h, j) * a.Sp + s] = ok ? v[kk][ct][j] : (_Float16)0.0f;
-      }
+        for (int j = 0; j < 8; ++j)
+          *row_elem(dst, perm_feature(kk, 0, j), a.Sp, lane_off[ct]) = ok_s[ct] ? v[kk][ct][j] : (_Float16)0.0f;
   };
   save_acts(0, bf);
   // hidden layer on the hand-scheduled pipeline of the inference kernel (accumulators double-buffered by row tile: the
@@ -379,6 +397,9 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_bwd_kernel(TrainArgs a) {
   const long tile0 = (long)blockIdx.x * kTile + wave * 64;
   const int L = a.n_hidden;
   long off = 0;
+  unsigned lane_off[2];   // see row_elem
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) lane_off[ct] = (unsigned)((tile0 + ct * 32 + col + 4L * h * a.Sp) * 2);
 
   // ---- output layer: dZ_out = dout (*) act'(out), one k-step (16 rows) ----
   half8 bo[2];
@@ -401,7 +422,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_bwd_kernel(TrainArgs a) {
     }
     bo[ct] = v;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) a.dzL[(long)perm_feature(0, h, j) * a.Sp + s] = v[j];
+    for (int j = 0; j < 8; ++j) *row_elem(a.dzL, perm_feature(0, 0, j), a.Sp, lane_off[ct]) = v[j];
   }
   // One accumulator pair at a time: row tile rt of dA_{l} = W^T dZ is masked with relu'(act_l), rounded to fp16 and packed
   // straight into the B fragments of the next (earlier) layer's MFMAs -- the backward chain stays in registers exactly as the
@@ -411,12 +432,11 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_bwd_kernel(TrainArgs a) {
     _Float16* dzl = a.dz + (long)l * W * a.Sp;
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
-      const long s = tile0 + ct * 32 + col;
       floatx16 m;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int feat = 32 * rt + (e & 3) + 8 * (e >> 2) + 4 * h;
-        const _Float16 av = act[(long)feat * a.Sp + s];
+        const int feat0 = 32 * rt + (e & 3) + 8 * (e >> 2);   // + 4h: in lane_off
+        const _Float16 av = *row_elem(act, feat0, a.Sp, lane_off[ct]);
         m[e] = (float)av > 0.0f ? acc[ct][e] : 0.0f;
       }
 #pragma unroll
@@ -424,7 +444,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_bwd_kernel(TrainArgs a) {
         const half8 v = pack8<false>(m, s2);
         dst[2 * rt + s2][ct] = v;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dzl[(long)perm_feature(2 * rt + s2, h, j) * a.Sp + s] = v[j];
+        for (int j = 0; j < 8; ++j) *row_elem(dzl, perm_feature(2 * rt + s2, 0, j), a.Sp, lane_off[ct]) = v[j];
       }
     }
   };
@@ -493,12 +513,11 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_bwd_kernel(TrainArgs a) {
     }
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
-      const long s = tile0 + ct * 32 + col;
-      const bool ok = s < a.S;
+      const bool ok = tile0 + ct * 32 + col < a.S;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int feat = 32 * rt + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (feat < a.E) a.dencT[(long)feat * a.Sp + s] = ok ? (_Float16)acc[ct][e] : (_Float16)0.0f;
+        const int feat0 = 32 * rt + (e & 3) + 8 * (e >> 2);
+        if (feat0 + 4 * h < a.E) *row_elem(a.dencT, feat0, a.Sp, lane_off[ct]) = ok ? (_Float16)acc[ct][e] : (_Float16)0.0f;
       }
     }
   }
@@ -663,7 +682,7 @@ extern "C" int rtxn_mlp_train_forward(const rtxn_mlp* m, const void* encT, long 
                                       void* output_half, float* radiance, rtxn_stream_t stream) {
   int rc = check_train(m, "rtxn_mlp_train_forward");
   if (rc != RTXN_OK) return rc;
-  RTXN_REQUIRE(n_samples >= 0, "rtxn_mlp_train_forward: n_samples = %ld < 0", n_samples);
+  RTXN_REQUIRE(n_samples >= 0 && n_samples <= kMaxTrainSamples, "rtxn_mlp_train_forward: n_samples = %ld out of [0, %ld]", n_samples, kMaxTrainSamples);
   RTXN_DEVICE_OR_FAIL();
   if (n_samples == 0) return RTXN_OK;
   RTXN_REQUIRE(encT && workspace && output_half, "rtxn_mlp_train_forward: NULL buffer");
@@ -700,7 +719,7 @@ extern "C" int rtxn_mlp_train_backward(const rtxn_mlp* m, const void* encT, cons
                                        void* dencT, rtxn_stream_t stream) {
   int rc = check_train(m, "rtxn_mlp_train_backward");
   if (rc != RTXN_OK) return rc;
-  RTXN_REQUIRE(n_samples >= 0, "rtxn_mlp_train_backward: n_samples = %ld < 0", n_samples);
+  RTXN_REQUIRE(n_samples >= 0 && n_samples <= kMaxTrainSamples, "rtxn_mlp_train_backward: n_samples = %ld out of [0, %ld]", n_samples, kMaxTrainSamples);
   RTXN_DEVICE_OR_FAIL();
   if (n_samples == 0) return RTXN_OK;
   RTXN_REQUIRE(encT && output_half && dout_half4 && workspace && dparams, "rtxn_mlp_train_backward: NULL buffer");

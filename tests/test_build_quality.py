@@ -29,11 +29,6 @@ def test_kernels_use_no_scratch_and_do_not_spill(src, tmp_path):
         scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", body).group(1))
         spills = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", body).group(1))
         vgprs = int(re.search(r"\.vgpr_count:\s+(\d+)", body).group(1))
-        if re.search(r"mlp_(train_fwd|bwd)_kernelILi128E", name):
-            # known: the 128-wide TRAINING kernels still spill (fwd 69, bwd 107 VGPRs; the bwd kernel had 378 before it
-            # stopped holding a full-layer fp32 dA) -- bounded here so that it can only get better
-            assert spills <= 120, f"{name}: {spills} VGPR spills (regressed)"
-            continue
         assert scratch == 0 and spills == 0, f"{name}: {scratch} B scratch, {spills} VGPR spills"
         if "mlp_fwd" in name or "mlp_train_fwd" in name or "mlp_bwd" in name:
             assert vgprs <= 256, f"{name}: {vgprs} VGPRs break the two-waves-per-SIMD budget"
