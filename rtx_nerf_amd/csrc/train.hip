@@ -538,11 +538,12 @@ struct WgradLayer {
 struct WgradArgs {
   WgradLayer layer[17];
   long Sp, chunk;
+  int lds_path;   // layers with >= 2 tiles are left to wgrad_lds_kernel
 };
 
 __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
   const WgradLayer& L = a.layer[blockIdx.z];
-  if ((int)blockIdx.x >= L.n_tiles) return;
+  if ((int)blockIdx.x >= L.n_tiles || (a.lds_path && L.n_tiles >= 2)) return;   // multi-tile layers: wgrad_lds_kernel
   const _Float16* __restrict__ dZ = L.dZ;
   const _Float16* __restrict__ X = L.X;
   const int M = L.M, N = L.N;
@@ -582,6 +583,80 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[u], b0[u], acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[u], b1[u], acc[1][1], 0, 0, 0);
     }
+  }
+  float* __restrict__ dW = L.dW;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int o = 64 * tm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int c = 64 * tn + 32 * j + r;
+        if (o < M && c < N) atomicAdd(&dW[(long)o * N + c], acc[i][j][e]);
+      }
+}
+
+// Layers with more than one 64x64 output tile (M or N up to 128): one BLOCK per sample chunk computes the whole (up to)
+// 128x128 gradient, wave w its 64x64 quadrant (w >> 1, w & 1), from operands staged ONCE in LDS.  The per-wave kernel
+// above reads every dZ / X row from global memory once per tile that uses it -- twice for a 128x128 layer, and it is
+// bound by exactly that traffic (32 FLOP per byte).  Staging is LDS-DMA straight into MFMA fragment order: fragment
+// (k-step kk, row group q: 0-3 dZ rows, 4-7 X rows) = lane (h, r)'s 16 bytes (8 samples 16kk + 8h.. of row 32q + r), so
+// one global_load_lds instruction fills one 1-KiB fragment and every operand read is one conflict-free ds_read_b128.
+constexpr int kWgK = 4;                                  // k-steps (of 16 samples) per stage
+constexpr int kWgStage = kWgK * 8 * 1024;                // bytes per stage: kWgK x 8 fragments
+__global__ __launch_bounds__(kThreads) void wgrad_lds_kernel(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t wsm[];   // 2 stages
+  const WgradLayer& L = a.layer[blockIdx.y];
+  if (L.n_tiles < 2) return;                             // single-tile layers: wgrad_kernel
+  const _Float16* __restrict__ dZ = L.dZ;
+  const _Float16* __restrict__ X = L.X;
+  const int M = L.M, N = L.N;
+  const long Sp = a.Sp;
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tm = wave >> 1, tn = wave & 1;
+  const long s_begin = (long)blockIdx.x * a.chunk;
+  const long s_end = s_begin + a.chunk < Sp ? s_begin + a.chunk : Sp;
+  if (s_begin >= Sp) return;
+  // this wave's 8 fragments of a stage: (kk, q) = ((wave*8 + i) / 8, (wave*8 + i) % 8) = (wave, i) for kWgK == 4
+  const _Float16* src[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int row = 32 * (q & 3) + r, lim = q < 4 ? M : N;
+    src[q] = (q < 4 ? dZ : X) + (long)(row < lim ? row : 0) * Sp + 16 * wave + 8 * h;   // rows beyond the layer: row 0, masked at the store
+  }
+  auto stage = [&](int buf, long s0) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[q] + s0),
+                                       (__attribute__((address_space(3))) void*)(wsm + buf * kWgStage + (wave * 8 + q) * 1024), 16, 0, 0);
+  };
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+  stage(0, s_begin);
+  int buf = 0;
+  for (long s = s_begin; s < s_end; s += 16 * kWgK) {
+    rtxn::staged_barrier();                              // this stage landed; everyone is done with the other buffer
+    if (s + 16 * kWgK < s_end) stage(buf ^ 1, s + 16 * kWgK);
+    const uint8_t* st = wsm + buf * kWgStage + lane * 16;
+#pragma unroll
+    for (int kk = 0; kk < kWgK; ++kk) {
+      const half8 a0 = *reinterpret_cast<const half8*>(st + (kk * 8 + 2 * tm) * 1024);
+      const half8 a1 = *reinterpret_cast<const half8*>(st + (kk * 8 + 2 * tm + 1) * 1024);
+      const half8 b0 = *reinterpret_cast<const half8*>(st + (kk * 8 + 4 + 2 * tn) * 1024);
+      const half8 b1 = *reinterpret_cast<const half8*>(st + (kk * 8 + 4 + 2 * tn + 1) * 1024);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    buf ^= 1;
   }
   float* __restrict__ dW = L.dW;
 #pragma unroll
@@ -772,8 +847,24 @@ extern "C" int rtxn_mlp_train_backward(const rtxn_mlp* m, const void* encT, cons
     if (wl.n_tiles > max_tiles) max_tiles = wl.n_tiles;
     poff += (long)M * N;
   }
-  wgrad_kernel<<<dim3((unsigned)max_tiles, kblocks, (unsigned)(L + 1)), kThreads, 0, s>>>(wa);
-  RTXN_LAUNCH_CHECK("wgrad_kernel");
+  int multi = 0, single = 0;
+  for (int l = 0; l <= L; ++l) (wa.layer[l].n_tiles >= 2 ? multi : single)++;
+  wa.lds_path = multi > 0 && W <= 128 && E <= 128;
+  if (single > 0 || !wa.lds_path) {
+    wgrad_kernel<<<dim3((unsigned)(wa.lds_path ? 1 : max_tiles), kblocks, (unsigned)(L + 1)), kThreads, 0, s>>>(wa);
+    RTXN_LAUNCH_CHECK("wgrad_kernel");
+  }
+  if (wa.lds_path) {
+    WgradArgs wl = wa;
+    wl.chunk = 2048;
+    static bool attr = false;
+    if (!attr) {
+      RTXN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kWgStage));
+      attr = true;
+    }
+    wgrad_lds_kernel<<<dim3((unsigned)((Sp + wl.chunk - 1) / wl.chunk), (unsigned)(L + 1)), kThreads, 2 * kWgStage, s>>>(wl);
+    RTXN_LAUNCH_CHECK("wgrad_lds_kernel");
+  }
   return RTXN_OK;
 }
 
