@@ -96,7 +96,7 @@ def _train_case(oracle, api, torch, W, L, E, act, n, seed, use_freq=False):
 
 
 @pytest.mark.parametrize("W,L,E,act,n", [(64, 4, 48, 1, 1000), (128, 8, 112, 1, 700), (64, 1, 16, 0, 5), (128, 2, 48, 0, 513),
-                                         (64, 5, 112, 1, 256)])
+                                         (64, 5, 112, 1, 256), (128, 3, 112, 1, 5000)])
 def test_mlp_train_forward_and_backward(gpu, oracle, W, L, E, act, n):
     torch = gpu
     from rtx_nerf_amd import api
