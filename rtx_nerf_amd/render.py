@@ -188,7 +188,7 @@ class RenderPipeline:
     # ------------------------------------------------------------------------------------------ frame pipelining
     # A frame is three dependent stages with very different bounds: traversal (two latency-bound passes + scan, ~0.45 ms
     # whatever the ray count), the MLP kernel (MFMA-bound, 96 % of the time) and the compositor (HBM-bound).  render_async
-    # puts them on three HIP streams and alternates between two buffer slots, so that while the MLP kernel of frame i runs,
+    # puts them on three HIP streams and rotates through three buffer slots, so that while the MLP kernel of frame i runs,
     # frame i+1 is traversed and frame i-1 composited on the same CUs: a traversal block (56 VGPRs, 4 KiB LDS) and a
     # compositor block (33 VGPRs, no LDS) fit beside a resident MLP block (2 x 216 VGPRs, 132 of 160 KiB LDS).  The host
     # never synchronises; it simply runs ahead.  Steady-state frame time = the MLP kernel alone, which matters most when
