@@ -189,10 +189,11 @@ class RenderPipeline:
     # A frame is three dependent stages with very different bounds: traversal (two latency-bound passes + scan, ~0.45 ms
     # whatever the ray count), the MLP kernel (MFMA-bound, 96 % of the time) and the compositor (HBM-bound).  render_async
     # puts them on three HIP streams and rotates through three buffer slots, so that while the MLP kernel of frame i runs,
-    # frame i+1 is traversed and frame i-1 composited on the same CUs: a traversal block (56 VGPRs, 4 KiB LDS) and a
-    # compositor block (33 VGPRs, no LDS) fit beside a resident MLP block (2 x 216 VGPRs, 132 of 160 KiB LDS).  The host
-    # never synchronises; it simply runs ahead.  Steady-state frame time = the MLP kernel alone, which matters most when
-    # the frame is sharded over N GPUs (the fixed traversal latency is 16 % of a rank's frame at N = 8).
+    # frame i+1 is traversed and frame i-1 composited: the compositor (33 VGPRs, no LDS) and the scan fit beside a resident
+    # MLP block and run underneath it; the traversal kernel (58 VGPRs, 4 KiB LDS) does so only beside the 214-VGPR MLP
+    # variants -- beside the 227-VGPR segment variant it runs in the gap between two MLP kernels, two frames ahead thanks to
+    # the third slot (DESIGN.md 5.1 has the measurements).  The host never synchronises; it simply runs ahead.  This
+    # matters most when the frame is sharded over N GPUs (the fixed traversal latency is 16 % of a rank's frame at N = 8).
     def _async_state(self):
         if self._async is None:
             import os
