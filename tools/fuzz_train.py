@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Fuzz the MLP training kernels (forward with saved activations, backward chain, weight gradients, d(encoding)) against
+the oracle: random width (64/128), hidden-layer count 1..9, encoded width (multiples of 16 up to 128), output activation,
+batch size around the 256-sample tile and the 1024/2048-sample weight-gradient chunks.
+  python tools/fuzz_train.py [--iters 40] [--seed 0]"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import oracle as O
+from rtx_nerf_amd import api, scenes
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--iters", type=int, default=40)
+ap.add_argument("--seed", type=int, default=0)
+a = ap.parse_args()
+rng = np.random.default_rng(a.seed)
+torch.cuda.set_device(0)
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+bad = 0
+for it in range(a.iters):
+    W = int(rng.choice([64, 128]))
+    L = int(rng.integers(1, 10))
+    E = int(rng.choice([16, 32, 48, 64, 80, 96, 112, 128]))
+    act = int(rng.integers(0, 2))
+    n = int(rng.choice([1, 255, 256, 257, 1023, 1024, 1025, 2047, 2049, 4100, int(rng.integers(1, 6000))]))
+    params = scenes.xavier_params_fp16(W, L, E, seed=it)
+    enc = rng.uniform(-1, 1, (n, E)).astype(np.float16)
+    Sp = api.padded_samples(n)
+    encT = np.zeros((E, Sp), np.float16)
+    encT[:, :n] = enc.T
+    net = api.Network(n_neurons=W, n_hidden_layers=L, n_encoded_features=E, output_activation=act)
+    net.set_params(dev(params))
+    encT_d = dev(encT)
+    ws = net.train_workspace(n)
+    out = net.train_forward(encT_d, n, ws)
+    torch.cuda.synchronize()
+    errs = []
+    o_acts, o_out = O.mlpe_forward(W, L, act, params, enc)
+    got = out.cpu().numpy().astype(np.float32)
+    tol = 1e-2 if act else 3e-2
+    if not (np.isfinite(got).all() and np.abs(got - o_out.astype(np.float32)).max() <= tol):
+        errs.append(f"forward output max err {np.abs(got - o_out.astype(np.float32)).max():.4g}")
+    acts = ws[:L * W * Sp].reshape(L, W, Sp).cpu().numpy()
+    for l in range(L):
+        if np.abs(acts[l, :, :n].T.astype(np.float32) - o_acts[l].astype(np.float32)).max() > 2e-2 or np.any(acts[l, :, n:] != 0):
+            errs.append(f"activations of layer {l}")
+            break
+    dout = (rng.standard_normal((n, 4)) * 0.05).astype(np.float16)
+    dparams = torch.zeros(net.n_params(), device="cuda")
+    dencT = torch.full((E, Sp), 7.0, dtype=torch.float16, device="cuda")
+    net.train_backward(encT_d, out, dev(dout), n, ws, dparams, dencT)
+    torch.cuda.synchronize()
+    acts_sm = np.ascontiguousarray(np.transpose(acts[:, :, :n], (0, 2, 1)))
+    want_dp, want_denc = O.mlpe_backward(W, L, act, params, enc, acts_sm, out.cpu().numpy(), dout)
+    got_dp = dparams.cpu().numpy()
+    scale = np.abs(want_dp).max()
+    if not (scale > 0 and np.abs(got_dp - want_dp).max() < 3e-2 * scale and np.linalg.norm(got_dp - want_dp) < 2e-2 * np.linalg.norm(want_dp)):
+        errs.append(f"weight gradient: max err {np.abs(got_dp - want_dp).max() / max(scale, 1e-30):.3g} of scale")
+    got_denc = dencT.cpu().numpy()[:, :n].T.astype(np.float32)
+    if not (np.linalg.norm(got_denc - want_denc) < 2e-2 * np.linalg.norm(want_denc) + 1e-6 and np.all(dencT.cpu().numpy()[:, n:] == 0)):
+        errs.append("d(encoding)")
+    if errs:
+        bad += 1
+        print(f"MISMATCH it={it} W={W} L={L} E={E} act={act} n={n}: {errs}", flush=True)
+print(f"fuzz_train: {a.iters} cases, {bad} mismatches")
+sys.exit(1 if bad else 0)
