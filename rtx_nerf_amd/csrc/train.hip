@@ -239,6 +239,8 @@ struct TrainArgs {
   long S, Sp;
   const _Float16* encT;     // [E][Sp]
   _Float16* acts;           // [L][W][Sp]
+  unsigned long long* masks; // [L][Sp][2]: bit 8*kk + j of lane-half h's word = (post-ReLU activation != 0) of feature
+                            // perm_feature(kk, h, j): all the backward chain needs of the activations (16 B instead of 2*W B)
   _Float16* out_half;       // [S][16]
   float4* radiance;         // [S] or NULL
   // backward
@@ -320,6 +322,26 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_train_fwd_kernel(TrainArgs a)
 #pragma unroll
         for (int j = 0; j < 8; ++j)
           *row_elem(dst, perm_feature(kk, 0, j), a.Sp, lane_off[ct]) = ok_s[ct] ? v[kk][ct][j] : (_Float16)0.0f;
+    // sign masks for the backward chain (read by mlp_bwd_kernel<64> only, see there): values are post-ReLU (>= 0), so
+    // "> 0" is "the half is not +0"
+    if constexpr (W == 64)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      unsigned long long mk = 0;
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) {
+        const rtxn::int4v w = __builtin_bit_cast(rtxn::int4v, v[kk][ct]);
+        unsigned bits = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned d = (unsigned)w[e];
+          bits |= ((d & 0xffffu) != 0 ? 1u : 0u) << (2 * e);
+          bits |= ((d >> 16) != 0 ? 1u : 0u) << (2 * e + 1);
+        }
+        mk |= (unsigned long long)bits << (8 * kk);
+      }
+      a.masks[((long)l * a.Sp + tile0 + ct * 32 + col) * 2 + h] = mk;
+    }
   };
   save_acts(0, bf);
   // hidden layer on the hand-scheduled pipeline of the inference kernel (accumulators double-buffered by row tile: the
@@ -427,17 +449,38 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_bwd_kernel(TrainArgs a) {
   // One accumulator pair at a time: row tile rt of dA_{l} = W^T dZ is masked with relu'(act_l), rounded to fp16 and packed
   // straight into the B fragments of the next (earlier) layer's MFMAs -- the backward chain stays in registers exactly as the
   // forward does, and no full-layer fp32 dA is ever held (the first version kept one: 128 VGPRs at W = 128, 378 spills).
+  // relu'(act_l) comes from the forward's sign masks: ONE 8-byte load per column tile and layer instead of W/2 two-byte
+  // activation loads (bit 16*rt + e of the lane's word belongs to accumulator element e of row tile rt)
+  // (at W = 128 the mask form makes hipcc spill 165 VGPRs in the layer loop -- 2.6 instead of 2.0 ms per step -- so the
+  // 128-wide kernel still reads the activations themselves; at W = 64 the masks are worth 5 % of the step)
+  constexpr bool kUseMasks = W == 64;
+  unsigned mk[2][2] = {{0, 0}, {0, 0}};   // low / high word of the lane's mask (row tiles 0-1 / 2-3)
+  auto load_masks = [&](int l) {
+    if constexpr (!kUseMasks) return;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const uint2 w = *reinterpret_cast<const uint2*>(a.masks + ((long)l * a.Sp + tile0 + ct * 32 + col) * 2 + h);
+      mk[ct][0] = w.x;
+      mk[ct][1] = w.y;
+    }
+  };
   auto mask_pack_store = [&](int l, int rt, const floatx16 (&acc)[2], half8 (&dst)[KS][2]) {
-    const _Float16* act = a.acts + (long)l * W * a.Sp;
     _Float16* dzl = a.dz + (long)l * W * a.Sp;
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
       floatx16 m;
+      if constexpr (kUseMasks) {
+        const unsigned bits = (mk[ct][rt >> 1] >> (16 * (rt & 1))) & 0xffffu;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int feat0 = 32 * rt + (e & 3) + 8 * (e >> 2);   // + 4h: in lane_off
-        const _Float16 av = *row_elem(act, feat0, a.Sp, lane_off[ct]);
-        m[e] = (float)av > 0.0f ? acc[ct][e] : 0.0f;
+        for (int e = 0; e < 16; ++e) m[e] = (bits >> e) & 1u ? acc[ct][e] : 0.0f;
+      } else {
+        const _Float16* act = a.acts + (long)l * W * a.Sp;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int feat0 = 32 * rt + (e & 3) + 8 * (e >> 2);   // + 4h: in lane_off
+          const _Float16 av = *row_elem(act, feat0, a.Sp, lane_off[ct]);
+          m[e] = (float)av > 0.0f ? acc[ct][e] : 0.0f;
+        }
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -452,6 +495,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_bwd_kernel(TrainArgs a) {
   half8 bz[KS][2], bn[KS][2];
   stage_rt(a.packed, smem, RT * 1024, tid);
   rtxn::staged_barrier();
+  load_masks(L - 1);
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {   // dZ_{L-1}: the output layer's single k-step
     const half8 af = *reinterpret_cast<const half8*>(smem + (rt * 64 + lane) * 16);
@@ -472,6 +516,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_bwd_kernel(TrainArgs a) {
     stage_rt(a.packed + off, smem, RT * KS * 1024, tid);
     rtxn::staged_barrier();
     off += (long)RT * KS * 1024;
+    load_masks(l - 1);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       floatx16 acc[2];
@@ -735,7 +780,7 @@ extern "C" long rtxn_padded_samples(long n_samples) { return n_samples < 0 ? -1 
 extern "C" size_t rtxn_mlp_train_workspace_bytes(const rtxn_mlp* m, long n_samples) {
   if (!m || n_samples < 0) return 0;
   const long Sp = padded(n_samples), W = m->cfg.n_neurons, L = m->cfg.n_hidden_layers;
-  return (size_t)((2 * L * W + 16) * Sp) * sizeof(_Float16);
+  return (size_t)((2 * L * W + 16 + 8 * L) * Sp) * sizeof(_Float16);   // acts | dz | dzL | sign masks (16 B per sample and layer)
 }
 
 extern "C" int rtxn_encode_frequency(const rtxn_mlp* m, const float* input, void* encT, long n_samples,
@@ -773,6 +818,7 @@ extern "C" int rtxn_mlp_train_forward(const rtxn_mlp* m, const void* encT, long 
   a.Sp = Sp;
   a.encT = static_cast<const _Float16*>(encT);
   a.acts = static_cast<_Float16*>(workspace);
+  a.masks = reinterpret_cast<unsigned long long*>(static_cast<_Float16*>(workspace) + (2L * m->cfg.n_hidden_layers * W + 16) * Sp);
   a.out_half = static_cast<_Float16*>(output_half);
   a.radiance = reinterpret_cast<float4*>(radiance);
   const int RT = W / 32, KS = W / 16, KS0 = a.E / 16;
@@ -813,6 +859,7 @@ extern "C" int rtxn_mlp_train_backward(const rtxn_mlp* m, const void* encT, cons
   a.acts = ws;
   a.dz = ws + (long)L * W * Sp;
   a.dzL = ws + 2L * L * W * Sp;
+  a.masks = reinterpret_cast<unsigned long long*>(ws + (2L * L * W + 16) * Sp);
   a.out_half = const_cast<_Float16*>(static_cast<const _Float16*>(output_half));
   a.dout = static_cast<const _Float16*>(dout_half4);
   a.dencT = static_cast<_Float16*>(dencT);
