@@ -19,6 +19,14 @@ Frames are software-pipelined across three HIP streams (render.py, render_async)
 the previous frame's compositing run underneath this frame's MLP kernel; every step still enqueues one whole frame
 of every stage (--serial times the one-stream form).
 
+At N = 1 the same JSON line also carries two more records measured in the same process after the headline loop
+(BASELINE.json configs[2] and configs[4] at full size; --no-extras skips them):
+  "train_config3": one optimisation step of 4096 rays, hash grid (L=16, F=2, T=2^19) + 4x64 MLP, 128^3 grid, with the
+                   per-stage HIP-event split and the hash gather / scatter kernels against the HBM roofline;
+  "config5":       the 1008x756 forward-facing frame, 256^3 sparse grid, 8x256 MLP, with mlp_fwd256_kernel against the
+                   MFMA roofline.
+The headline (metric/value/roofline/cpu_baseline) stays configs[1].
+
 Prints ONE JSON line on rank 0; see DESIGN.md for the roofline arithmetic.
 """
 import argparse
@@ -36,21 +44,169 @@ import torch
 import torch.distributed as dist
 
 MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense
+HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+KERNEL_SOURCES = ("rtx_nerf_amd/csrc/mlp.hip", "rtx_nerf_amd/csrc/mlp_internal.h")
+
+
+def kernel_src_sha16():
+    """Fingerprint of the dominant kernel's source: a PMC summary is only quoted for the kernel it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic(samples_per_launch):
     """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary
     (profiles/rNN/mlp_fwd_pmc.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections applied as
-    MI355X_MICROARCH.md prescribes), scaled to this run's launch size; None if no summary exists."""
+    MI355X_MICROARCH.md prescribes), scaled to this run's launch size.  None if there is no summary OR if it was
+    measured on a different version of the kernel source (kernel_src_sha16): a stale figure is not reported."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "mlp_fwd_pmc.json")))
     if not files or not samples_per_launch:
         return None
     try:
         d = json.load(open(files[-1]))
+        if d.get("kernel_src_sha16") != kernel_src_sha16():
+            return None
         return int(d["hbm_bytes_per_launch_high"] * samples_per_launch / d["samples_per_launch"])
     except Exception:
         return None
+
+
+def time_shade(pipe, poses_d, ray_begin, n_local, steps):
+    """The fused sampler+encode+MLP launch exactly as a frame makes it, bracketed by HIP events on the launch stream;
+    returns (mean kernel ms, mean samples per launch)."""
+    from rtx_nerf_amd import api
+    ms, smp = [], []
+    for i in range(steps):
+        pipe.look_at.copy_(poses_d[i % len(poses_d)], non_blocking=True)
+        nh, idx = pipe.num_hits[:n_local], pipe.indices[:n_local]
+        pipe._trace(ray_begin, n_local, write=False)
+        api.scan_hits(nh, idx, pipe.total, pipe.scan_ws)
+        pipe._trace(ray_begin, n_local, write=True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        pipe._shade(pipe._slots[0])
+        e1.record()
+        torch.cuda.synchronize()
+        ms.append(e0.elapsed_time(e1))
+        smp.append(int(pipe.total.item()) * api.NUM_SAMPLES_PER_SEGMENT)
+    return (float(np.mean(ms)), float(np.mean(smp))) if ms else (None, 0.0)
+
+
+def extra_train_config3(steps, warmup):
+    """BASELINE.json configs[2] at full size: 4096 rays/batch, hash grid L=16 F=2 T=2^19 (base 16, scale 1.5) +
+    Frequency(4) directions + 4x64 MLP, 128^3 Lego stand-in grid, K = 32, corrected ("nerf") compositor, L2 + Adam;
+    targets rendered from an analytic teacher field.  One step = one full optimisation step (main.cu:619-805)."""
+    from rtx_nerf_amd import scenes
+    from rtx_nerf_amd.train import Trainer, camera_rays
+    R, B = 128, 4096
+    dense = scenes.lego_standin_density(R, seed=0)
+    occ = torch.from_numpy(scenes.pack_occupancy(dense).view(np.int32).copy()).cuda()
+    hgd = dict(n_levels=16, n_features=2, log2_hashmap_size=19, base_resolution=16, per_level_scale=1.5)
+    tr = Trainer(R, occ, encoding="hash", n_neurons=64, n_hidden_layers=4, hashgrid=hgd, n_dir_freqs=4,
+                 batch_rays=128 * 128, max_segments=128 * 128 * 24, lr=1e-2, loss_scale=128.0, density_scale=300.0, mode="nerf")
+    focal = scenes.lego_focal_length(True)
+    ro, rd, tg = [], [], []
+    for i in range(8):
+        o, d = camera_rays(scenes.pose_spherical(45.0 * i + 15.0, -30.0, origin_scale=10.0), focal, 128, 128)
+        ro.append(o); rd.append(d); tg.append(tr.render_rays(o, d, radiance_fn=scenes.teacher_field).clone())
+    ro, rd, tg = torch.cat(ro), torch.cat(rd), torch.cat(tg)
+    g = torch.Generator(device="cuda").manual_seed(42)
+
+    def batch():
+        idx = torch.randint(0, ro.shape[0], (B,), device="cuda", generator=g)
+        return ro[idx].contiguous(), rd[idx].contiguous(), tg[idx].contiguous()
+
+    losses, samples = [], 0
+    for _ in range(warmup):
+        losses.append(tr.step(*batch()))
+    torch.cuda.synchronize()
+    first = float(losses[0].item()) if losses else None
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = tr.step(*batch())
+        samples += int(tr.total.item()) * 32     # the step has synchronised on this count already (main.cu:632 does too)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    S = samples / steps
+    stages = tr.time_stages(*batch(), steps=5)
+    # hash-grid kernels against the HBM roofline.  Algorithmic bytes (SURVEY 8d): 16 levels x 8 corners x 2 features x 2 B
+    # = 512 B gathered per sample forward; backward the same 8-corner footprint per level as fp32 atomic adds = 1024 B.
+    L, F = hgd["n_levels"], hgd["n_features"]
+    enc_b, bwd_b = L * 8 * F * 2, L * 8 * F * 4
+    kern = {}
+    for name, bts in (("encode", enc_b), ("hash_bwd", bwd_b)):
+        ms = stages.get(name)
+        if ms:
+            gbs = bts * S / (ms * 1e-3) / 1e9
+            kern[name] = {"ms": round(ms, 4), "bytes_per_sample": bts, "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+    dom = "hash_bwd" if "hash_bwd" in kern else "encode"
+    rec = {
+        "workload": "4096 rays/batch, hash grid L=16 F=2 T=2^19 base 16 x1.5 + Frequency(4) dirs + 4x64 ReLU MLP, 128^3 grid "
+                    f"({100.0 * dense.mean():.1f}% cells), K=32, NeRF compositor, L2 + Adam; analytic teacher targets",
+        "ms_per_step": round(1e3 * dt / steps, 4), "mrays_s": round(B * steps / dt / 1e6, 4), "steps": steps, "warmup": warmup,
+        "samples_per_step": int(S), "loss_first": first, "loss_last": float(loss.item()), "dtype": "f16 MFMA / f32 accumulate",
+        "stage_ms": {k: round(v, 4) for k, v in stages.items()},
+        "roofline": {"kernel": {"hash_bwd": "hashgrid_backward_kernel<lds|wave-aggregated>", "encode": "hashgrid_encode_kernel"}[dom],
+                     "bound": "hbm", "achieved": kern[dom]["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": kern[dom]["frac"], "traffic": None, "kernel_ms": kern[dom]["ms"],
+                     "bytes_per_sample": kern[dom]["bytes_per_sample"], "samples_per_launch": int(S)},
+        "kernels": kern,
+    }
+    mlp_flop = 2 * (tr.E * 64 + 3 * 64 * 64 + 16 * 64)
+    for name, mult in (("mlp_fwd", 1.0), ("mlp_bwd+wgrad", 2.0)):
+        ms = stages.get(name)
+        if ms:
+            tf = mult * mlp_flop * S / (ms * 1e-3) / 1e12
+            rec["kernels"][name] = {"ms": round(ms, 4), "flop_per_sample": int(mult * mlp_flop), "achieved": round(tf, 2),
+                                    "unit": "TFLOP/s", "frac": round(tf / MFMA_F16_DENSE_PEAK_TFLOPS, 4)}
+    del tr
+    torch.cuda.empty_cache()
+    return rec
+
+
+def extra_config5(steps, warmup, kernel_steps):
+    """BASELINE.json configs[4] at full size: 1008x756 forward-facing frame, 256^3 sparse fern-like grid, 8x256 MLP."""
+    from rtx_nerf_amd import api, render, scenes
+    W, H, R = 1008, 756, 256
+    dense = scenes.llff_standin_density(R, seed=3)
+    occ = torch.from_numpy(scenes.pack_occupancy(dense).view(np.int32).copy()).cuda()
+    net = api.Network(n_neurons=256, n_hidden_layers=8)
+    net.set_params(torch.from_numpy(scenes.xavier_params_fp16(256, 8, net.encoded_width(), seed=1337)).cuda())
+    poses = [scenes.pose_forward_facing(0.3 * np.cos(i), 0.2 * np.sin(i)) for i in range(4)]
+    pipe = render.RenderPipeline(net, R, W, H, 1.6, occupancy=occ, max_segments=1024)
+    worst = pipe.calibrate(poses)
+    poses_d = [torch.from_numpy(p.reshape(16)).cuda() for p in poses]
+    out = [torch.empty((W * H, 3), device="cuda") for _ in range(2)]
+    for i in range(warmup):
+        pipe.render_async(poses_d[i % 4], out=out[i & 1])
+    pipe.drain_async()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        pipe.render_async(poses_d[(warmup + i) % 4], out=out[i & 1])
+    pipe.drain_async()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert not pipe.overflowed(), "config5: segment capacity overflow"
+    ms, smp = time_shade(pipe, poses_d, 0, W * H, kernel_steps)
+    flops = net.flops_per_sample()
+    ach = flops * smp / (ms * 1e-3) / 1e12
+    rec = {
+        "workload": f"{W}x{H} inference render, {R}^3 grid (procedural LLFF-fern stand-in, {100.0 * dense.mean():.1f}% cells), "
+                    "8x256 ReLU MLP + Composite-Frequency encoding, 32 samples/segment, 4 forward-facing poses, seeded random fp16 weights",
+        "ms_per_step": round(1e3 * dt / steps, 4), "mrays_s": round(W * H * steps / dt / 1e6, 4), "steps": steps, "warmup": warmup,
+        "rays_per_step": W * H, "segments_per_frame_max": worst, "mean_samples_per_ray": round(smp / (W * H), 2), "dtype": "f16",
+        "roofline": {"kernel": "mlp_fwd256_kernel<3,10,2,12,segments,half4>", "bound": "mfma", "achieved": round(ach, 2),
+                     "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_DENSE_PEAK_TFLOPS, 4),
+                     "traffic": None, "flop_per_sample": flops, "samples_per_launch": smp, "kernel_ms": round(ms, 4)},
+    }
+    del pipe, net
+    torch.cuda.empty_cache()
+    return rec
 
 
 def parse():
@@ -68,6 +224,8 @@ def parse():
                     "llff: forward-facing frustum over a sparse fern-like grid (configs[4], with --grid 256 --neurons 256)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the train_config3 / config5 records (N = 1 only)")
+    ap.add_argument("--extra-steps", type=int, default=30, help="timed steps of each extra record")
     ap.add_argument("--fused", action="store_true", help="per-segment compositing in the MLP epilogue (measured slower: frame is MFMA-bound)")
     ap.add_argument("--kernel-steps", type=int, default=5, help="extra frames with HIP events around the MLP kernel")
     ap.add_argument("--no-compact", action="store_true", help="fp32 float4 radiance + t_vals between the MLP kernel and the compositor "
@@ -203,20 +361,7 @@ def main():
             del full
 
     # ---- dominant kernel (fused sampler+encode+MLP), HIP events on the launch stream ----
-    kern_ms, kern_samples = [], []
-    for i in range(args.kernel_steps):
-        pipe.look_at.copy_(poses_d[i % len(poses_d)], non_blocking=True)
-        nh, idx = pipe.num_hits[:n_local], pipe.indices[:n_local]
-        pipe._trace(ray_begin, n_local, write=False)
-        api.scan_hits(nh, idx, pipe.total, pipe.scan_ws)
-        pipe._trace(ray_begin, n_local, write=True)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        pipe._shade(pipe._slots[0])   # the MLP launch exactly as the frames above make it
-        e1.record()
-        torch.cuda.synchronize()
-        kern_ms.append(e0.elapsed_time(e1))
-        kern_samples.append(int(pipe.total.item()) * api.NUM_SAMPLES_PER_SEGMENT)
+    kern_ms, kern_smp = time_shade(pipe, poses_d, ray_begin, n_local, args.kernel_steps)
 
     rays_per_step = W * H
     value = rays_per_step * args.steps / elapsed / 1e6
@@ -250,8 +395,7 @@ def main():
         out["value"] = None   # one rank's shard only: not a throughput of the workload
     if rank == 0:
         flops = net.flops_per_sample()
-        ms = float(np.mean(kern_ms)) if kern_ms else None
-        smp = float(np.mean(kern_samples)) if kern_samples else 0.0
+        ms, smp = kern_ms, kern_smp
         if ms:
             ach = flops * smp / (ms * 1e-3) / 1e12
             out["roofline"] = {
@@ -263,41 +407,63 @@ def main():
         out["config"]["segments_per_frame_local_max"] = worst
         out["config"]["mean_samples_per_ray"] = round(smp / max(n_local, 1), 2)
 
-    # ---- cpu_baseline + PSNR vs oracle on a bounded ray sample (rank 0, N=1 only) ----
+    # ---- cpu_baseline + PSNR vs oracle on a bounded ray sample spread over ALL bench poses (rank 0, N=1 only) ----
     if rank == 0 and world == 1 and not args.no_cpu:
         import oracle as O   # checker / baseline only
         cfg = O.mlp_cfg(n_neurons=args.neurons, n_hidden_layers=args.layers)
-        pose = poses[0]
-        pipe.look_at.copy_(poses_d[0])
-        gpu_pix = pipe.render(ray_begin=0, ray_count=n_local).cpu().numpy()
 
-        def every(nrays):
+        def every(nrays, phase=0):
             stride = max(1, (W * H) // nrays)
-            return stride, (np.arange(min(nrays, W * H), dtype=np.int64) * stride).astype(np.uint32)
+            ids = (np.arange(min(nrays, W * H), dtype=np.int64) * stride + phase % stride)
+            return stride, ids[ids < W * H].astype(np.uint32)
 
         # probe to size a bounded sample of ~cpu_seconds of work on this host's cores
         _, probe_ids = every(2048)
         t1 = time.perf_counter()
-        O.render(pose, focal, W / H, W, H, R, words, 1, cfg, params, probe_ids)
+        O.render(poses[0], focal, W / H, W, H, R, words, 1, cfg, params, probe_ids)
         probe_s = max(time.perf_counter() - t1, 1e-3)
-        n_cpu = int(min(W * H, max(2048, 2048 * args.cpu_seconds / probe_s)))
-        stride, ray_ids = every(n_cpu)
-        t1 = time.perf_counter()
-        cpu_pix, cpu_samples = O.render(pose, focal, W / H, W, H, R, words, 1, cfg, params, ray_ids)
-        cpu_s = time.perf_counter() - t1
-        mse = float(((gpu_pix[ray_ids] - cpu_pix) ** 2).mean())
+        n_cpu = int(min(W * H * len(poses), max(2048, 2048 * args.cpu_seconds / probe_s)))
+        per_pose = max(256, n_cpu // len(poses))
+        cpu_s, cpu_rays, cpu_samples, sq_err, max_err, stride = 0.0, 0, 0, 0.0, 0.0, 1
+        for pi, pose in enumerate(poses):
+            pipe.look_at.copy_(poses_d[pi])
+            gpu_pix = pipe.render(ray_begin=0, ray_count=n_local).cpu().numpy()
+            stride, ray_ids = every(per_pose, phase=pi * 7919)
+            t1 = time.perf_counter()
+            cpu_pix, ns = O.render(pose, focal, W / H, W, H, R, words, 1, cfg, params, ray_ids)
+            cpu_s += time.perf_counter() - t1
+            cpu_rays += len(ray_ids)
+            cpu_samples += int(ns)
+            diff = gpu_pix[ray_ids] - cpu_pix
+            sq_err += float((diff.astype(np.float64) ** 2).sum())
+            max_err = max(max_err, float(np.abs(diff).max()))
+        mse = sq_err / (3.0 * cpu_rays)
         out["psnr_vs_oracle_db"] = round(10.0 * np.log10(1.0 / max(mse, 1e-20)), 2)
-        out["max_abs_err_vs_oracle"] = float(np.abs(gpu_pix[ray_ids] - cpu_pix).max())
+        out["max_abs_err_vs_oracle"] = max_err
         out["cpu_baseline"] = {
-            "value": round(len(ray_ids) / cpu_s / 1e6, 6), "unit": "Mrays/s", "cores": O.num_threads(),
+            "value": round(cpu_rays / cpu_s / 1e6, 6), "unit": "Mrays/s", "cores": O.num_threads(),
             "kind": "port",
-            "sample": f"{len(ray_ids)} rays (every {stride}th ray of pose 0's frame, {cpu_samples} samples), "
+            "sample": f"{cpu_rays} rays (every {stride}th ray of each of the {len(poses)} bench poses, {cpu_samples} samples), "
                       f"oracle/rtxn_oracle.c orc_render, OpenMP over rays, {cpu_s:.1f} s",
         }
+
+    # ---- configs[2] and configs[4] at full size, same process, after the headline (N = 1 only) ----
+    if rank == 0 and world == 1 and not args.no_extras and not args.emulate_shard_of:
+        del pipe
+        torch.cuda.empty_cache()
+        out["train_config3"] = extra_train_config3(args.extra_steps, 5)
+        out["config5"] = extra_config5(max(8, args.extra_steps // 2), 3, args.kernel_steps)
     if rank == 0:
         print(json.dumps(out), flush=True)
+    bad = gather_check is not None and gather_check.startswith("MISMATCH")
     if world > 1:
+        flag = torch.tensor([1 if bad else 0], dtype=torch.int32, device="cpu" if rehearse else "cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)     # every rank leaves with the same status
+        bad = bool(flag.item())
         dist.destroy_process_group()
+    if bad:
+        print("bench.py: gathered frame differs from the single-GPU frame", file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -7,8 +7,8 @@
  * The reference has no FFI layer; its "operator API" is a handful of C++ free
  * functions and PODs called from main.cu.  Each entry point below names the
  * reference interface it replaces (paths relative to the reference root).  The
- * C++ drop-in headers in include/rtxn/ (sampler.h, vol_render.h, params.h,
- * data_loader.h) keep the reference's own names and argument order and forward
+ * C++ drop-in headers in include/rtxn_dropin/ (sampler/sampler.h, vol_render/vol_render.h,
+ * rtx/include/params.h, loader/data_loader.h) keep the reference's own names and argument order and forward
  * to these symbols.  INTEGRATION.md shows the binding a maintainer would add.
  *
  * Conventions

@@ -759,6 +759,12 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(long n, float* __restric
 
 int check_train(const rtxn_mlp* m, const char* who) {
   if (!m) { rtxn::set_error("%s: NULL model", who); return RTXN_ERR_INVALID; }
+  if (m->cfg.n_neurons != 64 && m->cfg.n_neurons != 128) {
+    // the 256-wide model (config 5) has an inference kernel only; running the 128-wide training kernels over its packing
+    // would silently produce wrong activations and gradients
+    rtxn::set_error("%s: no training kernels for n_neurons = %d (built: 64, 128)", who, m->cfg.n_neurons);
+    return RTXN_ERR_UNSUPPORTED;
+  }
   if (!m->packed_train || !m->packed_t) { rtxn::set_error("%s: rtxn_mlp_set_params has not been called", who); return RTXN_ERR_INVALID; }
   return RTXN_OK;
 }
@@ -904,11 +910,7 @@ extern "C" int rtxn_mlp_train_backward(const rtxn_mlp* m, const void* encT, cons
   if (wa.lds_path) {
     WgradArgs wl = wa;
     wl.chunk = 2048;
-    static bool attr = false;
-    if (!attr) {
-      RTXN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kWgStage));
-      attr = true;
-    }
+    RTXN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kWgStage));
     wgrad_lds_kernel<<<dim3((unsigned)((Sp + wl.chunk - 1) / wl.chunk), (unsigned)(L + 1)), kThreads, 2 * kWgStage, s>>>(wl);
     RTXN_LAUNCH_CHECK("wgrad_lds_kernel");
   }

@@ -138,3 +138,14 @@ def pose_forward_facing(dx=0.0, dy=0.0, dist=2.6, origin_scale=10.0):
     c2w = np.eye(4, dtype=np.float32)
     c2w[:3, 3] = np.array([dx, dy, dist], np.float32) * origin_scale
     return c2w
+
+
+def teacher_field(samples):
+    """Analytic radiance for training benches/tests (torch, on the samples' device): a soft sphere with
+    position-dependent colour; sigma in (0,1) like the student's sigmoid output.  samples: float[S,5] -> float[S,4]."""
+    import torch
+    x = samples[:, :3]
+    r = x.norm(dim=1)
+    sigma = torch.sigmoid(30.0 * (0.5 - r))
+    rgb = 0.5 + 0.5 * torch.sin(4.0 * x + torch.tensor([0.0, 2.0, 4.0], device=x.device))
+    return torch.cat([rgb, sigma[:, None]], dim=1).contiguous()

@@ -29,6 +29,25 @@ import torch.distributed as dist
 from . import api
 
 
+class _Stage:
+    """HIP-event bracket around one stage of Trainer.step on the current stream (Trainer.time_stages)."""
+
+    def __init__(self, tr, name):
+        self.tr, self.name = tr, name
+
+    def __enter__(self):
+        if self.tr._stage_ev is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if self.tr._stage_ev is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.tr._stage_ev.append((self.name, self.e0, e1))
+        return False
+
+
 class Trainer:
     def __init__(self, grid_res, occupancy=None, encoding="hash", n_neurons=64, n_hidden_layers=4,
                  hashgrid=None, n_dir_freqs=4, batch_rays=4096, max_segments=None, lr=1e-3, loss_scale=128.0,
@@ -43,6 +62,7 @@ class Trainer:
         self.mode = mode
         self.lr, self.loss_scale, self.density_scale = lr, loss_scale, density_scale
         self.step_count = 0
+        self._stage_ev = None      # list of (stage, start event, end event) while time_stages() is collecting
         d = self.dev
         # ---- model -------------------------------------------------------------------------------
         self.encoding = encoding
@@ -74,6 +94,8 @@ class Trainer:
         self.view_dirs = torch.empty((B, 2), device=d)
         self.num_hits = torch.empty(B, dtype=torch.int32, device=d)
         self.indices = torch.empty(B, dtype=torch.int32, device=d)
+        self.num_stored = torch.empty(B, dtype=torch.int32, device=d)   # segments actually written per ray (= num_hits unless cut off)
+        self.truncated_steps = 0
         self.total = torch.zeros(1, dtype=torch.int32, device=d)
         # a batch is a small launch: several lanes walk each ray (bit-identical segments, shorter critical path)
         self.sub_rays = api.auto_sub_rays(B)
@@ -99,28 +121,42 @@ class Trainer:
         kw = dict(grid_res=self.R, rays_o=rays_o, rays_d=rays_d, width=n, height=1, ray_begin=0, ray_count=n,
                   occupancy=self.occ, occupancy_coarse=self.coarse, occupancy_bricks=self.bricks, occupancy_super=self.super_mip, mode=api.TRACE_DDA,
                   viewing_direction=self.view_dirs, num_hits=self.num_hits, sub_rays=self.sub_rays, sub_hits=self.sub_hits)
-        api.trace_grid(None, **kw)
-        api.scan_hits(self.num_hits[:n], self.indices[:n], self.total, self.scan_ws)
-        api.trace_grid(None, indices=self.indices, start_points=self.start, end_points=self.end,
-                       segment_capacity=self.max_segments, **kw)
+        with _Stage(self, "trace_count"):
+            api.trace_grid(None, **kw)
+        with _Stage(self, "scan"):
+            api.scan_hits(self.num_hits[:n], self.indices[:n], self.total, self.scan_ws)
+        with _Stage(self, "trace_write"):
+            api.trace_grid(None, indices=self.indices, start_points=self.start, end_points=self.end,
+                           num_stored=self.num_stored, segment_capacity=self.max_segments, **kw)
         P = int(self.total.item())            # the reference synchronises here too (thrust::reduce, main.cu:632)
         if P > self.max_segments:
-            raise RuntimeError(f"batch needs {P} segments, capacity {self.max_segments}")
+            # Rays whose segments do not fit are cut off ON THE DEVICE (num_stored < num_hits, never out of bounds) and
+            # every later stage reads num_stored.  Raising here instead would leave the other ranks of a data-parallel
+            # job waiting in the gradient all-reduce; the cut is counted and reported once.
+            if self.truncated_steps == 0:
+                import warnings
+                warnings.warn(f"Trainer: batch needs {P} segments, capacity {self.max_segments}: rays truncated "
+                              f"(raise max_segments); further truncations are counted in Trainer.truncated_steps")
+            self.truncated_steps += 1
+            P = self.max_segments
         return P
 
     def _sample(self, n, P):
         stype = api.SAMPLING_MIDPOINT_WORLD if self.mode == "nerf" else api.SAMPLING_REGULAR
-        api.launchSampler(self.start, self.end, self.view_dirs, self.t_vals, self.samples, n, self.R, self.num_hits,
-                          self.indices, stype)
-        if self.mode == "nerf" and self.density_scale != 1.0:
-            self.t_vals[:P * api.NUM_SAMPLES_PER_SEGMENT].mul_(self.density_scale)
+        with _Stage(self, "sampler"):
+            api.launchSampler(self.start, self.end, self.view_dirs, self.t_vals, self.samples, n, self.R, self.num_stored,
+                              self.indices, stype)
+            if self.mode == "nerf" and self.density_scale != 1.0:
+                self.t_vals[:P * api.NUM_SAMPLES_PER_SEGMENT].mul_(self.density_scale)
 
     def _forward(self, S):
-        if self.encoding == "hash":
-            self.hg.encode(self.table, self.samples[:S], self.encT)
-        else:
-            self.net.encode_frequency(self.samples[:S], self.encT)
-        self.net.train_forward(self.encT, S, self.ws, self.out, self.radiance)
+        with _Stage(self, "encode"):
+            if self.encoding == "hash":
+                self.hg.encode(self.table, self.samples[:S], self.encT)
+            else:
+                self.net.encode_frequency(self.samples[:S], self.encT)
+        with _Stage(self, "mlp_fwd"):
+            self.net.train_forward(self.encT, S, self.ws, self.out, self.radiance)
 
     def render_rays(self, rays_o, rays_d, radiance_fn=None):
         """Forward only.  radiance_fn(samples[S,5]) -> float[S,4] replaces the network (teacher rendering)."""
@@ -134,50 +170,91 @@ class Trainer:
             else:
                 self.radiance[:S] = radiance_fn(self.samples[:S])
         vr = api.VR_NERF if self.mode == "nerf" else api.VR_COMPAT
-        api.launch_volrender_cuda(None, self.radiance, self.num_hits, self.indices, self.t_vals, n,
+        api.launch_volrender_cuda(None, self.radiance, self.num_stored, self.indices, self.t_vals, n,
                                   api.NUM_SAMPLES_PER_SEGMENT, self.pixels[:n], mode=vr)
         return self.pixels[:n]
 
-    def step(self, rays_o, rays_d, targets):
-        """One optimisation step on a batch of rays; returns the (device) loss scalar."""
+    def gradients(self, rays_o, rays_d, targets):
+        """Everything of a step up to (not including) the optimizer: traversal ... backward.  Leaves the loss-scaled
+        gradient SUMS of this batch in self.dparams (MLP, tcnn layout) and self.dtable (hash grid) and returns the number
+        of samples.  The loss is the mean over THIS batch's 3n pixel components (tcnn L2, main.cu:759)."""
         n = rays_o.shape[0]
         K = api.NUM_SAMPLES_PER_SEGMENT
         vr = api.VR_NERF if self.mode == "nerf" else api.VR_COMPAT
-        self.step_count += 1
         P = self._segments(rays_o, rays_d, n)
         S = P * K
-        self._sample(n, P)
+        with _Stage(self, "zero_grads"):
+            self.dparams.zero_()
+            if self.encoding == "hash":
+                self.dtable.zero_()
         if S == 0:
-            return self.loss.zero_()
+            self.loss.zero_()
+            return 0
+        self._sample(n, P)
         self._forward(S)
-        api.launch_volrender_cuda(None, self.radiance, self.num_hits, self.indices, self.t_vals, n, K, self.pixels[:n],
-                                  mode=vr)
-        api.l2_loss(self.pixels[:n], targets, self.loss_scale, None, self.loss_grads[:n], self.loss)
-        api.launch_volrender_backward_cuda(None, self.loss_grads, self.radiance, self.t_vals, self.num_hits,
-                                           self.indices, n, K, self.dout, mode=vr)
-        self.dparams.zero_()
-        self.net.train_backward(self.encT, self.out, self.dout, S, self.ws, self.dparams, self.dencT)
-        # data parallel over the ray batch (SURVEY 8e): every rank holds B_local rays of the global batch;
-        # gradients are SUMMED across ranks (RCCL all-reduce, issued async so the MLP reduction overlaps the
-        # hash-grid scatter) and the mean over ranks is folded into Adam's loss_scale divisor.
+        with _Stage(self, "composite_fwd"):
+            api.launch_volrender_cuda(None, self.radiance, self.num_stored, self.indices, self.t_vals, n, K,
+                                      self.pixels[:n], mode=vr)
+        with _Stage(self, "l2_loss"):
+            api.l2_loss(self.pixels[:n], targets, self.loss_scale, None, self.loss_grads[:n], self.loss)
+        with _Stage(self, "composite_bwd"):
+            api.launch_volrender_backward_cuda(None, self.loss_grads, self.radiance, self.t_vals, self.num_stored,
+                                               self.indices, n, K, self.dout, mode=vr)
+        with _Stage(self, "mlp_bwd+wgrad"):
+            self.net.train_backward(self.encT, self.out, self.dout, S, self.ws, self.dparams, self.dencT)
+        if self.encoding == "hash":
+            with _Stage(self, "hash_bwd"):
+                self.hg.backward(self.samples[:S], self.dencT, self.dtable)
+        return S
+
+    def apply_gradients(self, grad_divisor=1.0):
+        """optimizer->step (main.cu:787) on self.dparams / self.dtable; grad_divisor: ranks summed into them."""
+        self.step_count += 1
+        with _Stage(self, "adam"):
+            api.adam_step(self.master, self.params, self.dparams, self.adam_m, self.adam_v, self.step_count, lr=self.lr,
+                          loss_scale=self.loss_scale * grad_divisor)
+            self.net.set_params(self.params)
+            if self.encoding == "hash":
+                api.adam_step(self.table_master, self.table, self.dtable, self.table_m, self.table_v, self.step_count,
+                              lr=self.lr * 10.0, eps=1e-15, loss_scale=self.loss_scale * grad_divisor)
+
+    def step(self, rays_o, rays_d, targets):
+        """One optimisation step on a batch of rays; returns the (device) loss scalar.
+
+        Data parallel (torch.distributed initialised, SURVEY 8e): every rank holds B_local rays of the global batch;
+        gradients are SUMMED across ranks and the mean over ranks is folded into Adam's loss_scale divisor.  EVERY rank
+        takes part in the all-reduces and runs Adam in every step -- also a rank whose rays all miss the grid (its
+        gradients are zero) -- so the ranks can neither deadlock nor drift apart in step count."""
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        pending = []
+        S = self.gradients(rays_o, rays_d, targets)
+        if S == 0 and world == 1:
+            return self.loss                  # nothing to learn from: no Adam step, step_count unchanged
         if world > 1:
-            pending.append(dist.all_reduce(self.dparams, async_op=True))
-        if self.encoding == "hash":
-            self.dtable.zero_()
-            self.hg.backward(self.samples[:S], self.dencT, self.dtable)
-            if world > 1:
-                pending.append(dist.all_reduce(self.dtable, async_op=True))
-        for w in pending:
-            w.wait()
-        api.adam_step(self.master, self.params, self.dparams, self.adam_m, self.adam_v, self.step_count, lr=self.lr,
-                      loss_scale=self.loss_scale * world)
-        self.net.set_params(self.params)
-        if self.encoding == "hash":
-            api.adam_step(self.table_master, self.table, self.dtable, self.table_m, self.table_v, self.step_count,
-                          lr=self.lr * 10.0, eps=1e-15, loss_scale=self.loss_scale * world)
+            with _Stage(self, "allreduce"):
+                pending = [dist.all_reduce(self.dparams, async_op=True)]
+                if self.encoding == "hash":
+                    pending.extend(self._allreduce_table_grad())
+                for w in pending:
+                    w.wait()
+        self.apply_gradients(float(world))
         return self.loss
+
+    def _allreduce_table_grad(self):
+        """Sum the hash-grid gradient across ranks; returns the pending work handles."""
+        return [dist.all_reduce(self.dtable, async_op=True)]
+
+    def time_stages(self, rays_o, rays_d, targets, steps=5):
+        """Run `steps` optimisation steps with HIP events around every stage (on the stream the kernels are launched on);
+        returns {stage: mean ms}.  Diagnostic: the events add launches, so the sum exceeds an untimed step slightly."""
+        acc = {}
+        for _ in range(steps):
+            self._stage_ev = []
+            self.step(rays_o, rays_d, targets)
+            torch.cuda.synchronize()
+            for name, e0, e1 in self._stage_ev:
+                acc.setdefault(name, []).append(e0.elapsed_time(e1))
+            self._stage_ev = None
+        return {k: float(np.mean(v)) for k, v in acc.items()}
 
     # ------------------------------------------------------------------------------------------ checkpoint
     # Layout (little endian): b"RTXNCKPT", u32 version, u32 json_len, json header, then for every entry of

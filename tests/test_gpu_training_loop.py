@@ -87,3 +87,61 @@ def test_config3_training_step_matches_oracle_chain(gpu, oracle):
     m, v = np.zeros_like(tmaster0), np.zeros_like(tmaster0)
     O.adam_step(tmaster0, got_dt, m, v, 1, lr=1e-1, eps=1e-15, loss_scale=ls)
     np.testing.assert_allclose(tr.table_master.cpu().numpy(), tmaster0, rtol=0, atol=2e-6)
+
+
+def test_compat_training_step_matches_oracle_chain(gpu, oracle):
+    """The reference's OWN training iteration (main.cu:704-787) end to end, Trainer(mode="compat"): REGULAR sampler ->
+    Composite-Frequency encoding + 128-wide ReLU MLP forward -> COMPAT composite (vol_render.cu:19-73) -> L2 -> COMPAT
+    backward (vol_render.cu:75-143, literally: not the gradient of the forward) -> network backward -> Adam, every
+    stage against the same step chained from oracle functions."""
+    import numpy as np
+    torch = gpu
+    from rtx_nerf_amd import api, scenes
+    from rtx_nerf_amd.train import Trainer, camera_rays
+    R, ls, W, L = 16, 128.0, 128, 3
+    dense = scenes.sphere_density(R, 0.75)
+    words = scenes.pack_occupancy(dense)
+    occ = torch.from_numpy(words.view(np.int32).copy()).cuda()
+    o, d = camera_rays(scenes.pose_spherical(40.0, -30.0, origin_scale=10.0), scenes.lego_focal_length(True), 24, 24)
+    B = o.shape[0]
+    tr = Trainer(R, occ, encoding="freq", n_neurons=W, n_hidden_layers=L, n_dir_freqs=12, batch_rays=B,
+                 max_segments=B * 30, lr=1e-3, loss_scale=ls, mode="compat", seed=3)
+    rng = np.random.default_rng(0)
+    tgt = torch.from_numpy(rng.uniform(0, 1, (B, 3)).astype(np.float32)).cuda()
+    params0, master0 = tr.params.cpu().numpy().copy(), tr.master.cpu().numpy().copy()
+    loss = float(tr.step(o, d, tgt).item())
+    P = int(tr.total.item())
+    S = P * 32
+    assert S > 20_000 and tr.step_count == 1
+
+    O = oracle
+    pk = O.trace_packed(rays_o=o.cpu().numpy(), rays_d=d.cpu().numpy(), R=R, occ=words, mode=1)
+    assert pk["total"] == P
+    samples, t_vals = O.sample(pk["start"], pk["end"], pk["view_dirs"], pk["num_hits"], pk["indices"], 0)   # SAMPLING_REGULAR
+    np.testing.assert_array_equal(tr.samples[:S].cpu().numpy()[:, :3], samples[:, :3])
+    np.testing.assert_array_equal(tr.t_vals[:S].cpu().numpy(), t_vals)
+    samples[:, 3:] = tr.samples[:S].cpu().numpy()[:, 3:]       # (theta, phi): the device's atan2f (2e-6 from glibc's)
+    cfg = O.mlp_cfg(n_neurons=W, n_hidden_layers=L)
+    enc = O.encode_freq(cfg, samples)
+    acts, out = O.mlpe_forward(W, L, 1, params0, enc)
+    rad = out[:, :4].astype(np.float32)
+    np.testing.assert_allclose(tr.radiance[:S].cpu().numpy(), rad, rtol=0, atol=1e-2)
+    pix = O.volrender_fwd(rad, pk["num_hits"], pk["indices"], t_vals)
+    np.testing.assert_allclose(tr.pixels.cpu().numpy(), pix, rtol=0, atol=3e-3)
+    o_loss, _, _, _ = O.l2_loss(pix, tgt.cpu().numpy(), ls)
+    assert abs(loss - o_loss) < 5e-3 * o_loss
+    # backward from the GPU's own forward state, so that the comparison is not dominated by forward rounding
+    rad_g, lg = tr.radiance[:S].cpu().numpy(), tr.loss_grads.cpu().numpy()
+    dout = O.volrender_bwd(lg, rad_g, t_vals, pk["num_hits"], pk["indices"])
+    got_dout = tr.dout[:S].cpu().numpy()
+    assert (got_dout.view(np.uint16) == np.asarray(dout, np.float16).view(np.uint16)).mean() > 0.995   # <= 1 fp16 ulp elsewhere
+    Sp = api.padded_samples(S)
+    acts_g = tr.ws[:L * W * Sp].reshape(L, W, Sp)[:, :, :S].permute(0, 2, 1).contiguous().cpu().numpy()
+    enc_g = tr.encT.reshape(-1)[:tr.E * Sp].reshape(tr.E, Sp)[:, :S].t().contiguous().cpu().numpy()
+    assert np.abs(enc_g.astype(np.float32) - enc.astype(np.float32)).max() < 2e-3
+    dp, _ = O.mlpe_backward(W, L, 1, params0, enc_g, acts_g, tr.out[:S].cpu().numpy(), got_dout, want_denc=False)
+    got_dp = tr.dparams.cpu().numpy()
+    assert np.abs(dp).max() > 0 and np.linalg.norm(got_dp - dp) < 2e-2 * np.linalg.norm(dp)
+    m, v = np.zeros_like(master0), np.zeros_like(master0)
+    O.adam_step(master0, got_dp, m, v, 1, lr=1e-3, loss_scale=ls)
+    np.testing.assert_allclose(tr.master.cpu().numpy(), master0, rtol=0, atol=2e-6)

@@ -122,3 +122,32 @@ def test_cpp_dropin_header_compiles_and_loads(tmp_path):
     want = _stb_loadf(imgs[1]).reshape(-1)[5]
     assert abs(float(out[5]) - want) < 1e-7
     assert abs(float(out[6]) - np.float32(frames[1]["transform_matrix"][1][3])) < 1e-6
+
+
+# ---- pinned by the reference's own decoder -----------------------------------------------------------------------
+# tests/golden/loader_stb.npz: PNG files + what the REFERENCE's vendored loader/stb_image.h returns for
+# stbi_loadf(path, &w, &h, &n, 3) (loader/data_loader.cpp:63), generated in the build container by
+# tests/golden/make_loader_golden.py through oracle/_ref/stb_loadf (the untouched reference header behind a main()).
+_GOLD = np.load(os.path.join(ROOT, "tests", "golden", "loader_stb.npz"))
+
+
+def _one_frame_scene(tmp, png_bytes):
+    os.makedirs(tmp / "train", exist_ok=True)
+    (tmp / "train" / "r_0.png").write_bytes(png_bytes)
+    frames = [{"file_path": "./train/r_0", "transform_matrix": np.eye(4).tolist()}]
+    json.dump({"camera_angle_x": 0.6911112070083618, "frames": frames}, open(tmp / "transforms_train.json", "w"))
+
+
+@pytest.mark.parametrize("name", [str(n) for n in _GOLD["names"]])
+def test_png_decode_is_bit_exact_with_the_references_stb_image(tmp_path, name):
+    ok, w, h, _ = (int(v) for v in _GOLD["hdr_" + name])
+    _one_frame_scene(tmp_path, _GOLD["png_" + name].tobytes())
+    ds = loader.load_images_json(str(tmp_path), "train")
+    if not ok:                                   # stbi_loadf returned NULL -> the reference returns an empty dataset (:74-78)
+        assert ds.images.shape[0] == 0
+        return
+    assert ds.images.shape == (1, h, w, 3), (name, ds.images.shape)
+    want = _GOLD["out_" + name]
+    got = ds.images[0]
+    bad = np.nonzero(got.view(np.uint32) != want.view(np.uint32))
+    assert bad[0].size == 0, f"{name}: {bad[0].size} of {want.size} values differ, e.g. got {got[bad][:4]} want {want[bad][:4]}"

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Builds timing-only variants of librtxn.so (rtx_nerf_amd/librtxn_<tag>.so) with extra -D flags for mlp.hip:
-#   tools/ablate.sh tag1="-DRTXN_ABLATE=1" tag2="-DRTXN_PIPE=2" ...
+#   tools/ablate.sh pipe2="-DRTXN_PIPE=2" noskew="-DRTXN_SKEW=0" ...   (value-preserving knobs only, see mlp.hip)
 # then on the GPU:  RTXN_LIB_PATH=rtx_nerf_amd/librtxn_<tag>.so python tools/mlp_bench.py
 set -e
 cd "$(dirname "$0")/.."

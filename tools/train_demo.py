@@ -16,13 +16,7 @@ from rtx_nerf_amd import scenes
 from rtx_nerf_amd.train import Trainer, camera_rays
 
 
-def teacher_field(samples):
-    """Analytic radiance: a soft sphere with position-dependent colour; sigma in (0,1) like the student's."""
-    x = samples[:, :3]
-    r = x.norm(dim=1)
-    sigma = torch.sigmoid(30.0 * (0.5 - r))
-    rgb = 0.5 + 0.5 * torch.sin(4.0 * x + torch.tensor([0.0, 2.0, 4.0], device=x.device))
-    return torch.cat([rgb, sigma[:, None]], dim=1).contiguous()
+teacher_field = scenes.teacher_field   # kept under this name for the tests that import it from here
 
 
 def run(steps=300, encoding="hash", grid=32, res=64, batch=4096, n_poses=12, seed=0, verbose=True, neurons=64, layers=2,
