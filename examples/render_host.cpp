@@ -29,20 +29,60 @@
     }                                                                                      \
   } while (0)
 
-// main.cu:154-174
-static std::vector<OptixAabb> make_grid(int resolution) {
-  std::vector<OptixAabb> grid;
-  float box_length = 2.0f / (float)resolution;
-  for (int x = 0; x < resolution; x++)
-    for (int y = 0; y < resolution; y++)
-      for (int z = 0; z < resolution; z++) {
-        OptixAabb b;
-        b.minX = -1.0f + (float)x * box_length; b.maxX = -1.0f + x * box_length + box_length;
-        b.minY = -1.0f + y * box_length;        b.maxY = -1.0f + y * box_length + box_length;
-        b.minZ = -1.0f + z * box_length;        b.maxZ = -1.0f + z * box_length + box_length;
-        grid.push_back(b);
-      }
-  return grid;
+// The box of one grid cell: the reference's grid (main.cu:154-174) is R^3 equal cells over [-1,1]^3, numbered
+// x-major / z-minor.  Written here as a function of the flat cell index; only OptixAabb's field names are the contract.
+static OptixAabb cell_box(int cell, int R) {
+  const float edge = 2.0f / (float)R;
+  const int ijk[3] = {cell / (R * R), (cell / R) % R, cell % R};
+  float lo[3], hi[3];
+  for (int a = 0; a < 3; ++a) {
+    lo[a] = -1.0f + (float)ijk[a] * edge;
+    hi[a] = lo[a] + edge;
+  }
+  return OptixAabb{lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]};
+}
+
+static std::vector<OptixAabb> make_grid(int R) {
+  std::vector<OptixAabb> boxes((size_t)R * R * R);
+  for (size_t cell = 0; cell < boxes.size(); ++cell) boxes[cell] = cell_box((int)cell, R);
+  return boxes;
+}
+
+// Launch parameters for one pose (the reference fills the same struct field by field before every optixLaunch,
+// main.cu:481-501): grouped here by what they describe.
+struct LaunchBuffers {
+  float3 *start_points, *end_points, *ray_origins;
+  float *t_start, *t_end;
+  int* num_hits;
+  float2* viewing_direction;
+};
+static Params make_params(unsigned width, unsigned height, int R, float fov_x, const float* d_look_at, OptixAabb* d_aabb,
+                          OptixTraversableHandle gas, const LaunchBuffers& buf) {
+  Params p{};
+  // camera
+  p.look_at = const_cast<float*>(d_look_at);
+  p.width = width;
+  p.height = height;
+  p.aspect_ratio = (float)width / (float)height;
+  p.focal_length = 1.0f / std::tan(0.5f * fov_x);   // corrected Q1: from camera_angle_x, not from the pixel focal
+  // grid
+  const float cell = 2.0f / (float)R;
+  p.delta = make_float3(cell, cell, cell);
+  p.min_point = make_float3(-1.0f, -1.0f, -1.0f);
+  p.max_point = make_float3(1.0f, 1.0f, 1.0f);
+  p.num_primitives = R * R * R;
+  p.intersection_arr_size = 3 * R;                  // slots per ray, main.cu:486
+  p.handle = gas;
+  p.aabb = d_aabb;
+  // outputs
+  p.start_points = buf.start_points;
+  p.end_points = buf.end_points;
+  p.ray_origins = buf.ray_origins;
+  p.t_start = buf.t_start;
+  p.t_end = buf.t_end;
+  p.num_hits = buf.num_hits;
+  p.viewing_direction = buf.viewing_direction;
+  return p;
 }
 
 int main(int argc, char** argv) {
@@ -98,27 +138,8 @@ int main(int argc, char** argv) {
   HIP_CHECK(hipMalloc((void**)&d_view_dir, n_rays * sizeof(float2)));
   HIP_CHECK(hipMemsetAsync(d_num_hits, 0, n_rays * sizeof(int), inference_stream));
 
-  Params params;  // main.cu:481-501
-  float d = 2.0f / grid_resolution;
-  params.delta = make_float3(d, d, d);
-  params.min_point = make_float3(-1, -1, -1);
-  params.max_point = make_float3(1, 1, 1);
-  params.intersection_arr_size = 3 * grid_resolution;
-  params.width = width;
-  params.height = height;
-  params.focal_length = 1.0f / std::tan(0.5f * 0.6911112f);  // corrected Q1: camera_angle_x, not the pixel focal
-  params.aspect_ratio = (float)width / (float)height;
-  params.handle = rtx_dataholder->gas_handle;
-  params.aabb = d_aabb;
-  params.start_points = d_start_points;
-  params.end_points = d_end_points;
-  params.t_start = d_t_start;
-  params.t_end = d_t_end;
-  params.num_hits = d_num_hits;
-  params.num_primitives = (int)grid.size();
-  params.look_at = d_look_at;
-  params.viewing_direction = d_view_dir;
-  params.ray_origins = d_ray_origins;
+  const LaunchBuffers bufs{d_start_points, d_end_points, d_ray_origins, d_t_start, d_t_end, d_num_hits, d_view_dir};
+  Params params = make_params(width, height, grid_resolution, 0.6911112f, d_look_at, d_aabb, rtx_dataholder->gas_handle, bufs);
   rtxnLaunch(params, inference_stream);  // optixLaunch, main.cu:506-508
 
   // compaction (main.cu:631-637) -- on the device, total included

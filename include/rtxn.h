@@ -340,6 +340,14 @@ typedef struct rtxn_image_dataset {
 } rtxn_image_dataset;
 int rtxn_load_images_json(const char* basename, const char* split, int flags, rtxn_image_dataset* out);
 void rtxn_free_image_dataset(rtxn_image_dataset* d);
+/* Fills the stub at loader/data_loader.cpp:140-142 (SceneType::LLFF: the reference sets the directory name and returns an
+ * empty vector).  Reads <basedir>/poses_bounds.npy (float64[N][17]: row-major 3x5 [R | t | (H, W, focal)] in LLFF's
+ * (down, right, back) axes + near/far bounds) and the PNG frames of <basedir>/images_<factor>/ (images/ if factor <= 1)
+ * in name order.  poses: float[N][16] row-major camera-to-world, axes (right, up, back) like the synthetic loader's;
+ * focal is in pixels of the loaded resolution; *bounds (may be NULL): malloc'ed float[N][2] near/far, release with
+ * rtxn_free_llff_bounds.  flags as rtxn_load_images_json. */
+int rtxn_load_llff(const char* basedir, int factor, int flags, rtxn_image_dataset* out, float** bounds);
+void rtxn_free_llff_bounds(float* bounds);
 /* stb_image_write's role (included, never called, main.cu:19-21): 8-bit RGB PNG of a rendered frame. */
 int rtxn_write_png_rgb8(const char* path, const unsigned char* rgb, int width, int height);
 

@@ -2,7 +2,8 @@
 // free functions, implemented over rtxn_load_images_json (librtxn.so) instead of jsoncpp +
 // stb_image.  Behaviour of loader/data_loader.cpp is kept: a missing transforms JSON prints and
 // exit(1)s (:36-39); a frame that fails to load yields an EMPTY dataset (:74-78); only the
-// "train" split is loaded (the `break` at :103); LLFF returns an empty vector (:140-148);
+// "train" split is loaded (the `break` at :103); LLFF -- where the reference stops at the directory name and returns an
+// empty vector (:140-148) -- loads poses_bounds.npy + images_8/*.png when the scene exists and returns empty otherwise;
 // SyntheticName::MATERIALS maps to "fern/" (:128-130, quirk Q12); images are owned by the
 // caller and never freed by the library (the reference leaks them too).
 #ifndef DATA_LOADER_H
@@ -72,6 +73,37 @@ inline std::vector<ImageDataset> load_synthetic_data(std::string directory) {
   return datasets;
 }
 
+// Not in the reference (its LLFF branch is a stub): <directory>/poses_bounds.npy + <directory>/images_<factor>/*.png.
+// bounds (optional): near/far per image, 2 floats each.
+inline std::vector<ImageDataset> load_llff_data(std::string directory, int factor = 8, std::vector<float>* bounds = nullptr) {
+  rtxn_image_dataset d;
+  float* b = nullptr;
+  std::vector<ImageDataset> datasets;
+  if (rtxn_load_llff(directory.c_str(), factor, 0, &d, &b) != RTXN_OK) {
+    std::fprintf(stderr, "%s\n", rtxn_last_error());
+    return datasets;
+  }
+  ImageDataset dataset{};
+  const size_t npx = (size_t)d.image_width * d.image_height * 3;
+  for (int i = 0; i < d.n_images; ++i) {
+    float* image = (float*)std::malloc(npx * sizeof(float));
+    float* pose = new float[16];
+    std::memcpy(image, d.images + (size_t)i * npx, npx * sizeof(float));
+    std::memcpy(pose, d.poses + (size_t)i * 16, 16 * sizeof(float));
+    dataset.images.push_back(image);
+    dataset.poses.push_back(pose);
+  }
+  if (bounds) bounds->assign(b, b + 2 * (size_t)d.n_images);
+  dataset.focal = d.focal;
+  dataset.image_width = d.image_width;
+  dataset.image_height = d.image_height;
+  dataset.image_channels = d.image_channels;
+  rtxn_free_llff_bounds(b);
+  rtxn_free_image_dataset(&d);
+  datasets.push_back(dataset);
+  return datasets;
+}
+
 inline std::vector<ImageDataset> load_data(SceneType type, SyntheticName name) {
   std::string directory, filename;
   switch (name) {
@@ -87,7 +119,7 @@ inline std::vector<ImageDataset> load_data(SceneType type, SyntheticName name) {
   switch (type) {
     case SceneType::LLFF:
       directory = "./data/nerf_llff_data/" + filename;
-      break;
+      return load_llff_data(directory);   // the reference falls through to the empty vector here (:140-142,148)
     case SceneType::SYNTHETIC:
       directory = "./data/nerf_synthetic/" + filename;
       return load_synthetic_data(directory);

@@ -125,6 +125,8 @@ SYMBOLS = {
     "rtxn_adam_step": (_I, [_L, _P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _P]),
     "rtxn_load_images_json": (_I, [C.c_char_p, C.c_char_p, _I, C.POINTER(ImageDataset)]),
     "rtxn_free_image_dataset": (None, [C.POINTER(ImageDataset)]),
+    "rtxn_load_llff": (_I, [C.c_char_p, _I, _I, C.POINTER(ImageDataset), C.POINTER(C.POINTER(C.c_float))]),
+    "rtxn_free_llff_bounds": (None, [C.POINTER(C.c_float)]),
     "rtxn_write_png_rgb8": (_I, [C.c_char_p, _P, _I, _I]),
 }
 

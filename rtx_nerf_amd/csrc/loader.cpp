@@ -5,17 +5,22 @@
 // frames[].file_path, frames[].transform_matrix are read, :47-71) and stb_image's
 // stbi_loadf(path, &w, &h, &n, 3) (:63).  Both are re-implemented here from their published
 // behaviour: a small recursive-descent JSON reader, and a PNG decoder (zlib inflate + the
-// five PNG filters, non-interlaced, 8/16-bit, gray/gray-alpha/RGB/RGBA/palette) followed by
+// five PNG filters, plain and Adam7-interlaced, 1/2/4/8/16-bit, gray/gray-alpha/RGB/RGBA/palette) followed by
 // stb's conversions: channels reduced to 3 by DROPPING alpha (no compositing, quirk Q11),
 // then ldr->hdr  out = (float)pow(v/255.0f, 2.2f)  (stb_image.h v2.28 stbi__ldr_to_hdr).
 // Host-only code; no GPU involvement.
+#include <dirent.h>
 #include <zlib.h>
 
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
+#include <cctype>
 #include <cstring>
+#include <exception>
+#include <new>
 #include <map>
 #include <memory>
 #include <string>
@@ -42,8 +47,10 @@ struct JVal {
 
 struct JParser {
   const char* p;
-  const char* end;
+  const char* end;      // the buffer is NUL-terminated AT end (strncmp/strtod below may look at it)
   std::string err;
+  int depth = 0;        // nesting guard: a hostile file must not overflow the stack
+  static constexpr int kMaxDepth = 64;
   void ws() { while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p; }
   bool fail(const char* m) { if (err.empty()) err = m; return false; }
   bool parse_string(std::string& out) {
@@ -80,6 +87,8 @@ struct JParser {
     return true;
   }
   bool parse(JVal& v) {
+    if (depth >= kMaxDepth) return fail("nesting too deep");
+    struct Scope { int& d; explicit Scope(int& x) : d(x) { ++d; } ~Scope() { --d; } } scope(depth);
     ws();
     if (p >= end) return fail("unexpected end");
     if (*p == '{') {
@@ -119,12 +128,12 @@ struct JParser {
       }
     }
     if (*p == '"') { v.kind = JVal::Str; return parse_string(v.str); }
-    if (!strncmp(p, "true", 4)) { v.kind = JVal::Bool; v.b = true; p += 4; return true; }
-    if (!strncmp(p, "false", 5)) { v.kind = JVal::Bool; v.b = false; p += 5; return true; }
-    if (!strncmp(p, "null", 4)) { v.kind = JVal::Null; p += 4; return true; }
+    if (end - p >= 4 && !strncmp(p, "true", 4)) { v.kind = JVal::Bool; v.b = true; p += 4; return true; }
+    if (end - p >= 5 && !strncmp(p, "false", 5)) { v.kind = JVal::Bool; v.b = false; p += 5; return true; }
+    if (end - p >= 4 && !strncmp(p, "null", 4)) { v.kind = JVal::Null; p += 4; return true; }
     char* q = nullptr;
-    v.num = strtod(p, &q);
-    if (q == p) return fail("bad token");
+    v.num = strtod(p, &q);                     // stops at the terminating NUL at the latest
+    if (q == p || q > end) return fail("bad token");
     v.kind = JVal::Num;
     p = q;
     return true;
@@ -183,7 +192,7 @@ bool decode_png(const std::vector<unsigned char>& file, int& width, int& height,
     pos += 12 + (size_t)len;
   }
   if (!have_ihdr || width <= 0 || height <= 0) { err = "missing IHDR"; return false; }
-  if (interlace) { err = "interlaced PNG not supported"; return false; }
+  if (interlace > 1) { err = "bad interlace method"; return false; }
   int src_ch;
   switch (ctype) {
     case 0: src_ch = 1; break;
@@ -197,50 +206,78 @@ bool decode_png(const std::vector<unsigned char>& file, int& width, int& height,
     err = "unsupported bit depth";
     return false;
   }
+  // Size guard BEFORE any allocation: IHDR is attacker-controlled (up to 2^31 each way).  stb_image refuses images
+  // beyond STBI_MAX_DIMENSIONS = 2^24 per side; the pixel cap below additionally bounds the float image this loader
+  // builds (1 Gpixel = 12 GB of float RGB).
+  if (width > (1 << 24) || height > (1 << 24) || (uint64_t)width * (uint64_t)height > (1ull << 30)) {
+    err = "image too large";
+    return false;
+  }
   const size_t bpp_bits = (size_t)src_ch * depth;
-  const size_t stride = ((size_t)width * bpp_bits + 7) / 8;
   const size_t fbpp = bpp_bits >= 8 ? bpp_bits / 8 : 1;  // filter byte distance
-  std::vector<unsigned char> raw((stride + 1) * (size_t)height);
+  // Adam7 (interlace method 1): seven reduced images, each filtered as an image of its own and scattered to
+  // (x0 + i*dx, y0 + j*dy) -- stb_image.h's stbi__create_png_image does the same
+  static const int kX0[7] = {0, 4, 0, 2, 0, 1, 0}, kY0[7] = {0, 0, 4, 0, 2, 0, 1};
+  static const int kDx[7] = {8, 8, 4, 4, 2, 2, 1}, kDy[7] = {8, 8, 8, 4, 4, 2, 2};
+  const int n_pass = interlace ? 7 : 1;
+  size_t raw_size = 0;
+  for (int ps = 0; ps < n_pass; ++ps) {
+    const int pw = interlace ? (width - kX0[ps] + kDx[ps] - 1) / kDx[ps] : width;
+    const int ph = interlace ? (height - kY0[ps] + kDy[ps] - 1) / kDy[ps] : height;
+    if (pw > 0 && ph > 0) raw_size += (((size_t)pw * bpp_bits + 7) / 8 + 1) * (size_t)ph;
+  }
+  std::vector<unsigned char> raw(raw_size);
   uLongf raw_len = (uLongf)raw.size();
   int zr = uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size());
   if (zr != Z_OK || raw_len != raw.size()) { err = "inflate failed"; return false; }
-  std::vector<unsigned char> img(stride * (size_t)height);
-  for (int y = 0; y < height; ++y) {
-    const unsigned char* in = &raw[(stride + 1) * (size_t)y];
-    const int ft = in[0];
-    ++in;
-    unsigned char* out = &img[stride * (size_t)y];
-    const unsigned char* up = y ? out - stride : nullptr;
-    for (size_t x = 0; x < stride; ++x) {
-      const int a = x >= fbpp ? out[x - fbpp] : 0, b = up ? up[x] : 0, c = (up && x >= fbpp) ? up[x - fbpp] : 0;
-      int v = in[x];
-      switch (ft) {
-        case 0: break;
-        case 1: v += a; break;
-        case 2: v += b; break;
-        case 3: v += (a + b) >> 1; break;
-        case 4: v += paeth(a, b, c); break;
-        default: err = "bad filter"; return false;
-      }
-      out[x] = (unsigned char)v;
-    }
-  }
-  // to 8-bit samples
   const size_t npx = (size_t)width * height;
-  std::vector<unsigned char> s8(npx * src_ch);
-  if (depth == 8) {
-    for (int y = 0; y < height; ++y) memcpy(&s8[(size_t)y * width * src_ch], &img[stride * (size_t)y], (size_t)width * src_ch);
-  } else if (depth == 16) {
-    for (int y = 0; y < height; ++y)
-      for (size_t i = 0; i < (size_t)width * src_ch; ++i) s8[(size_t)y * width * src_ch + i] = img[stride * (size_t)y + 2 * i];  // stb: high byte
-  } else {
-    const int maxv = (1 << depth) - 1;
-    for (int y = 0; y < height; ++y)
-      for (int x = 0; x < width; ++x) {
-        const size_t bit = (size_t)x * depth;
-        int v = (img[stride * (size_t)y + bit / 8] >> (8 - depth - (bit % 8))) & maxv;
-        s8[(size_t)y * width + x] = (unsigned char)(ctype == 3 ? v : v * 255 / maxv);
+  std::vector<unsigned char> s8(npx * src_ch);   // 8-bit samples of the whole image
+  const int maxv = (1 << depth) - 1;
+  size_t raw_pos = 0;
+  std::vector<unsigned char> img;
+  for (int ps = 0; ps < n_pass; ++ps) {
+    const int x0 = interlace ? kX0[ps] : 0, y0 = interlace ? kY0[ps] : 0, dx = interlace ? kDx[ps] : 1, dy = interlace ? kDy[ps] : 1;
+    const int pw = (width - x0 + dx - 1) / dx, ph = (height - y0 + dy - 1) / dy;
+    if (pw <= 0 || ph <= 0) continue;
+    const size_t stride = ((size_t)pw * bpp_bits + 7) / 8;
+    img.assign(stride * (size_t)ph, 0);
+    for (int y = 0; y < ph; ++y) {
+      const unsigned char* in = &raw[raw_pos + (stride + 1) * (size_t)y];
+      const int ft = in[0];
+      ++in;
+      unsigned char* out = &img[stride * (size_t)y];
+      const unsigned char* up = y ? out - stride : nullptr;
+      for (size_t x = 0; x < stride; ++x) {
+        const int a = x >= fbpp ? out[x - fbpp] : 0, b = up ? up[x] : 0, c = (up && x >= fbpp) ? up[x - fbpp] : 0;
+        int v = in[x];
+        switch (ft) {
+          case 0: break;
+          case 1: v += a; break;
+          case 2: v += b; break;
+          case 3: v += (a + b) >> 1; break;
+          case 4: v += paeth(a, b, c); break;
+          default: err = "bad filter"; return false;
+        }
+        out[x] = (unsigned char)v;
       }
+    }
+    raw_pos += (stride + 1) * (size_t)ph;
+    // to 8-bit samples, scattered to the pass's pixel positions
+    for (int y = 0; y < ph; ++y) {
+      const unsigned char* row = &img[stride * (size_t)y];
+      for (int x = 0; x < pw; ++x) {
+        unsigned char* dst = &s8[((size_t)(y0 + y * dy) * width + (size_t)(x0 + x * dx)) * src_ch];
+        if (depth == 8) {
+          for (int k = 0; k < src_ch; ++k) dst[k] = row[(size_t)x * src_ch + k];
+        } else if (depth == 16) {
+          for (int k = 0; k < src_ch; ++k) dst[k] = row[2 * ((size_t)x * src_ch + k)];   // stb: the high byte
+        } else {
+          const size_t bit = (size_t)x * depth;
+          const int v = (row[bit / 8] >> (8 - depth - (bit % 8))) & maxv;
+          dst[0] = (unsigned char)(ctype == 3 ? v : v * 255 / maxv);
+        }
+      }
+    }
   }
   if (ctype == 3) {
     channels = trns.empty() ? 3 : 4;
@@ -279,9 +316,26 @@ void to_float_rgb(const std::vector<unsigned char>& px, int channels, size_t npx
 }  // namespace
 
 // ============================================================================ C ABI
+static int load_images_json_impl(const char* basename, const char* split, int flags, rtxn_image_dataset* out);
+
+// No C++ exception may cross the C ABI (a bad_alloc from a hostile or corrupt file would otherwise terminate the host).
 extern "C" int rtxn_load_images_json(const char* basename, const char* split, int flags, rtxn_image_dataset* out) {
   RTXN_REQUIRE(basename && split && out, "rtxn_load_images_json: NULL argument");
   memset(out, 0, sizeof(*out));
+  try {
+    return load_images_json_impl(basename, split, flags, out);
+  } catch (const std::exception& e) {
+    rtxn::set_error("Failed to load the image set %s (%s): %s", basename, split, e.what());
+  } catch (...) {
+    rtxn::set_error("Failed to load the image set %s (%s)", basename, split);
+  }
+  free(out->images);
+  free(out->poses);
+  memset(out, 0, sizeof(*out));
+  return RTXN_ERR_IO;
+}
+
+static int load_images_json_impl(const char* basename, const char* split, int flags, rtxn_image_dataset* out) {
   const std::string base(basename);
   const std::string json_path = base + "/transforms_" + split + ".json";
   std::vector<unsigned char> text;
@@ -290,7 +344,8 @@ extern "C" int rtxn_load_images_json(const char* basename, const char* split, in
     return RTXN_ERR_IO;
   }
   JVal root;
-  JParser jp{reinterpret_cast<const char*>(text.data()), reinterpret_cast<const char*>(text.data()) + text.size(), {}};
+  text.push_back(0);   // NUL terminator: the number/keyword scanners never read past the buffer
+  JParser jp{reinterpret_cast<const char*>(text.data()), reinterpret_cast<const char*>(text.data()) + text.size() - 1, {}};
   if (!jp.parse(root) || root.kind != JVal::Obj) {
     rtxn::set_error("%s: JSON parse error: %s", json_path.c_str(), jp.err.c_str());
     return RTXN_ERR_IO;
@@ -353,6 +408,146 @@ extern "C" int rtxn_load_images_json(const char* basename, const char* split, in
   if (!poses.empty()) memcpy(out->poses, poses.data(), poses.size() * sizeof(float));
   return RTXN_OK;
 }
+
+// ------------------------------------------------------------------------- LLFF (forward-facing) scenes
+// The reference declares SceneType::LLFF and stops at the directory name (loader/data_loader.cpp:140-142: load_data
+// returns an empty vector).  This fills that stub with the published LLFF layout (Mildenhall et al., "Local Light Field
+// Fusion"; NeRF's load_llff.py): <dir>/poses_bounds.npy = float64[N][17], per image a row-major 3x5 matrix
+// [R | t | (H, W, focal)] in LLFF's (down, right, backwards) camera axes followed by the near/far depth bounds, and the
+// frames themselves in <dir>/images_<factor>/ (PNG; the full-size images/ directory of the published scenes is JPEG,
+// which the reference's stbi path would read but this PNG-only decoder does not).  Output poses use the same convention
+// as the synthetic loader: row-major 4x4 camera-to-world, axes (right, up, backwards).
+namespace {
+
+bool parse_npy_f64_2d(const std::vector<unsigned char>& f, size_t& rows, size_t& cols, const double*& data, std::string& err) {
+  if (f.size() < 10 || memcmp(f.data(), "\x93NUMPY", 6)) { err = "not an .npy file"; return false; }
+  const int major = f[6];
+  size_t hlen, hoff;
+  if (major == 1) { hlen = f[8] | (f[9] << 8); hoff = 10; }
+  else if (major == 2 || major == 3) {
+    if (f.size() < 12) { err = "truncated .npy header"; return false; }
+    hlen = (size_t)f[8] | ((size_t)f[9] << 8) | ((size_t)f[10] << 16) | ((size_t)f[11] << 24); hoff = 12;
+  } else { err = "unsupported .npy version"; return false; }
+  if (hoff + hlen > f.size()) { err = "truncated .npy header"; return false; }
+  const std::string hdr(reinterpret_cast<const char*>(f.data()) + hoff, hlen);
+  if (hdr.find("'<f8'") == std::string::npos && hdr.find("\"<f8\"") == std::string::npos) { err = ".npy dtype is not <f8"; return false; }
+  if (hdr.find("'fortran_order': False") == std::string::npos) { err = ".npy is Fortran-ordered"; return false; }
+  const size_t sp = hdr.find("'shape':");
+  const size_t lp = sp == std::string::npos ? sp : hdr.find('(', sp);
+  if (lp == std::string::npos) { err = ".npy header lacks a shape"; return false; }
+  unsigned long long r = 0, c = 0;
+  if (sscanf(hdr.c_str() + lp, "(%llu, %llu", &r, &c) != 2) { err = ".npy array is not 2-D"; return false; }
+  if (r > (1ull << 24) || c > 4096 || (hoff + hlen + r * c * 8ull) > f.size()) { err = ".npy data shorter than its shape"; return false; }
+  rows = (size_t)r; cols = (size_t)c;
+  data = reinterpret_cast<const double*>(f.data() + hoff + hlen);   // header length keeps the data 16/64-byte aligned
+  return true;
+}
+
+int load_llff_impl(const char* basedir, int factor, int flags, rtxn_image_dataset* out, float** bounds_out) {
+  const std::string base(basedir);
+  std::vector<unsigned char> npy;
+  if (!read_file(base + "/poses_bounds.npy", npy)) {
+    rtxn::set_error("Failed to open %s/poses_bounds.npy", basedir);
+    return RTXN_ERR_IO;
+  }
+  size_t n = 0, cols = 0;
+  const double* pb = nullptr;
+  std::string err;
+  if (!parse_npy_f64_2d(npy, n, cols, pb, err) || cols != 17) {
+    rtxn::set_error("%s/poses_bounds.npy: %s", basedir, err.empty() ? "expected float64[N][17]" : err.c_str());
+    return RTXN_ERR_IO;
+  }
+  // frames: the .png files of images_<factor>/ (images/ for factor <= 1) in lexicographic order, as load_llff.py sorts them
+  const std::string img_dir = base + (factor > 1 ? "/images_" + std::to_string(factor) : std::string("/images"));
+  std::vector<std::string> files;
+  if (DIR* d = opendir(img_dir.c_str())) {
+    while (dirent* e = readdir(d)) {
+      const std::string nm(e->d_name);
+      if (nm.size() > 4) {
+        std::string ext = nm.substr(nm.size() - 4);
+        for (auto& ch : ext) ch = (char)tolower((unsigned char)ch);
+        if (ext == ".png") files.push_back(nm);
+      }
+    }
+    closedir(d);
+  }
+  std::sort(files.begin(), files.end());
+  if (files.size() != n) {
+    rtxn::set_error("%s holds %zu .png frames but poses_bounds.npy has %zu poses", img_dir.c_str(), files.size(), n);
+    return RTXN_ERR_IO;
+  }
+  int W = 0, H = 0;
+  std::vector<float> images, poses(n * 16), bounds(n * 2);
+  for (size_t i = 0; i < n; ++i) {
+    const double* row = pb + i * 17;   // row-major 3x5 then near, far
+    // LLFF camera axes (down, right, back) -> (right, up, back): columns [1, -0, 2]; column 3 = camera position
+    for (int r = 0; r < 3; ++r) {
+      poses[i * 16 + r * 4 + 0] = (float)row[r * 5 + 1];
+      poses[i * 16 + r * 4 + 1] = (float)-row[r * 5 + 0];
+      poses[i * 16 + r * 4 + 2] = (float)row[r * 5 + 2];
+      poses[i * 16 + r * 4 + 3] = (float)row[r * 5 + 3];
+    }
+    poses[i * 16 + 12] = poses[i * 16 + 13] = poses[i * 16 + 14] = 0.0f;
+    poses[i * 16 + 15] = 1.0f;
+    bounds[2 * i] = (float)row[15];
+    bounds[2 * i + 1] = (float)row[16];
+    std::vector<unsigned char> file, px;
+    int w = 0, h = 0, ch = 0;
+    const std::string png_path = img_dir + "/" + files[i];
+    if (!read_file(png_path, file) || !decode_png(file, w, h, ch, px, err)) {
+      rtxn::set_error("Failed to load the image %s%s%s", png_path.c_str(), err.empty() ? "" : ": ", err.c_str());
+      return RTXN_ERR_IO;
+    }
+    if (i == 0) { W = w; H = h; images.resize(n * (size_t)W * H * 3); }
+    if (w != W || h != H) {
+      rtxn::set_error("%s: %dx%d differs from the first frame's %dx%d", png_path.c_str(), w, h, W, H);
+      return RTXN_ERR_IO;
+    }
+    to_float_rgb(px, ch, (size_t)W * H, flags, &images[i * (size_t)W * H * 3]);
+  }
+  const double f_full = n ? pb[14] : 0.0, w_full = n ? pb[9] : 0.0;   // hwf column of the first pose: H = [4], W = [9], focal = [14]
+  out->n_images = (int)n;
+  out->image_width = (unsigned)W;
+  out->image_height = (unsigned)H;
+  out->image_channels = 3;
+  out->focal = (float)(w_full > 0 ? f_full * (double)W / w_full : f_full);   // focal in pixels of the LOADED resolution
+  out->camera_angle_x = out->focal > 0 ? (float)(2.0 * std::atan(0.5 * W / out->focal)) : 0.0f;
+  out->images = (float*)malloc(images.size() * sizeof(float) + 1);
+  out->poses = (float*)malloc(poses.size() * sizeof(float) + 1);
+  float* b = (float*)malloc(bounds.size() * sizeof(float) + 1);
+  if (!out->images || !out->poses || !b) {
+    free(b);
+    throw std::bad_alloc();
+  }
+  memcpy(out->images, images.data(), images.size() * sizeof(float));
+  memcpy(out->poses, poses.data(), poses.size() * sizeof(float));
+  memcpy(b, bounds.data(), bounds.size() * sizeof(float));
+  if (bounds_out) *bounds_out = b; else free(b);
+  return RTXN_OK;
+}
+
+}  // namespace
+
+extern "C" int rtxn_load_llff(const char* basedir, int factor, int flags, rtxn_image_dataset* out, float** bounds) {
+  RTXN_REQUIRE(basedir && out, "rtxn_load_llff: NULL argument");
+  RTXN_REQUIRE(factor >= 0 && factor <= 64, "rtxn_load_llff: factor = %d", factor);
+  memset(out, 0, sizeof(*out));
+  if (bounds) *bounds = nullptr;
+  try {
+    const int rc = load_llff_impl(basedir, factor, flags, out, bounds);
+    if (rc == RTXN_OK) return rc;
+  } catch (const std::exception& e) {
+    rtxn::set_error("Failed to load the LLFF scene %s: %s", basedir, e.what());
+  } catch (...) {
+    rtxn::set_error("Failed to load the LLFF scene %s", basedir);
+  }
+  free(out->images);
+  free(out->poses);
+  memset(out, 0, sizeof(*out));
+  return RTXN_ERR_IO;
+}
+
+extern "C" void rtxn_free_llff_bounds(float* bounds) { free(bounds); }
 
 extern "C" void rtxn_free_image_dataset(rtxn_image_dataset* d) {
   if (!d) return;

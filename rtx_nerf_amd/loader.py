@@ -50,12 +50,33 @@ def load_synthetic_data(directory, flags=0):
     return datasets
 
 
-def load_data(scene_type, name, root="./data", flags=0):
-    """data_loader.cpp:109-149.  scene_type: "SYNTHETIC" | "LLFF" (LLFF returns [] as the reference does)."""
+def load_llff_data(directory, factor=8, flags=0):
+    """Fills the reference's LLFF stub (data_loader.cpp:140-142 sets the directory and returns nothing): poses_bounds.npy
+    + the PNG frames of images_<factor>/ -> [ImageDataset] with `.bounds` float[n,2] (near, far); [] when the scene is
+    absent or unreadable, which is what the reference returns for every LLFF request."""
+    d = _lib.ImageDataset()
+    b = C.POINTER(C.c_float)()
+    rc = _lib.lib().rtxn_load_llff(str(directory).encode(), int(factor), flags, C.byref(d), C.byref(b))
+    if rc != 0:
+        print(_lib.lib().rtxn_last_error().decode(), file=sys.stderr)
+        return []
+    n, w, h = d.n_images, d.image_width, d.image_height
+    images = np.ctypeslib.as_array(d.images, shape=(n, h, w, 3)).copy() if n else np.zeros((0, h, w, 3), np.float32)
+    poses = np.ctypeslib.as_array(d.poses, shape=(n, 16)).copy() if n else np.zeros((0, 16), np.float32)
+    out = ImageDataset(images, poses, d.focal, w, h, d.image_channels, d.camera_angle_x)
+    out.bounds = np.ctypeslib.as_array(b, shape=(n, 2)).copy() if n else np.zeros((0, 2), np.float32)
+    _lib.lib().rtxn_free_llff_bounds(b)
+    _lib.lib().rtxn_free_image_dataset(C.byref(d))
+    return [out]
+
+
+def load_data(scene_type, name, root="./data", flags=0, llff_factor=8):
+    """data_loader.cpp:109-149.  scene_type: "SYNTHETIC" | "LLFF".  The reference stops at the directory name for LLFF
+    (:140-142) and returns []; here the scene is loaded when it exists (load_llff_data) and [] is returned otherwise."""
     filename = SYNTHETIC_NAMES[name]
     if scene_type == "SYNTHETIC":
         return load_synthetic_data(f"{root}/nerf_synthetic/{filename}", flags)
-    return []
+    return load_llff_data(f"{root}/nerf_llff_data/{filename}", llff_factor, flags)
 
 
 def write_png(path, rgb_float):

@@ -21,7 +21,7 @@ from . import api
 class RenderPipeline:
     def __init__(self, network, grid_res, width, height, focal_length, aspect_ratio=None, occupancy=None,
                  max_rays=None, max_segments=None, trace_mode=api.TRACE_DDA, vr_mode=api.VR_COMPAT,
-                 device="cuda", window=(0, 0), fused=False, step_scale=1.0, sub_rays=None, compact=None):
+                 device="cuda", window=(0, 0), fused=False, step_scale=1.0, sub_rays=None, compact=None, on_overflow="raise"):
         self.net = network
         self.R = grid_res
         self.W, self.H = width, height
@@ -46,6 +46,16 @@ class RenderPipeline:
         if self.compact and (fused or vr_mode != api.VR_COMPAT):
             raise ValueError("compact needs the unfused RTXN_VR_COMPAT pipeline")
         self.dev = torch.device(device)
+        # A pose that needs more segments than the buffers hold is cut off ON THE DEVICE (never out of bounds).  So that
+        # this cannot pass unnoticed outside the calibrated pose set, every frame copies its segment count to pinned host
+        # memory (4 bytes, async, no synchronisation) and the NEXT call on that slot -- or drain_async() / finish() --
+        # looks at it: on_overflow = "raise" (default): RuntimeError naming the frame; "grow": re-allocate the segment
+        # buffers at 1.5x the need (a pipeline stall, once) and go on -- the cut frame was delivered truncated either way
+        # and is counted in overflow_frames; "ignore": count only.
+        if on_overflow not in ("raise", "grow", "ignore"):
+            raise ValueError("on_overflow must be 'raise', 'grow' or 'ignore'")
+        self.on_overflow = on_overflow
+        self.overflow_frames = 0
         self.occ = occupancy
         self.coarse = self.bricks = self.super_mip = None
         if occupancy is not None and trace_mode == api.TRACE_DDA and grid_res % 4 == 0:
@@ -80,6 +90,9 @@ class RenderPipeline:
         g.num_hits_c = torch.empty(n, dtype=torch.int32, device=d)
         g.indices = torch.empty(n, dtype=torch.int32, device=d)
         g.total = torch.zeros(1, dtype=torch.int32, device=d)
+        g.total_host = torch.zeros(1, dtype=torch.int32).pin_memory()   # last frame's segment count, copied asynchronously
+        g.total_ev = torch.cuda.Event()
+        g.total_pending = False
         g.sub_hits = torch.zeros(n * self.sub_rays, dtype=torch.int32, device=d) if self.sub_rays > 1 else None
         self._alloc_slot_segments(g)
         return g
@@ -133,6 +146,30 @@ class RenderPipeline:
         self._trace(ray_begin, n, write=False, slot=g)
         api.scan_hits(g.num_hits[:n], g.indices[:n], g.total, self.scan_ws)
         self._trace(ray_begin, n, write=True, slot=g)
+        g.total_host.copy_(g.total, non_blocking=True)    # 4 bytes to pinned memory: the overflow check of the next call
+        if not torch.cuda.is_current_stream_capturing():
+            g.total_ev.record()
+            g.total_pending = True
+
+    def _check_overflow(self, g, wait=False):
+        """Look at the segment count slot g's LAST frame reported (no synchronisation unless `wait`: the caller has then
+        synchronised the device, which also covers frames replayed from a captured hipGraph)."""
+        if torch.cuda.is_current_stream_capturing():
+            return
+        if not wait and not (g.total_pending and g.total_ev.query()):
+            return
+        g.total_pending = False
+        need = int(g.total_host[0])
+        if need <= self.max_segments:
+            return
+        self.overflow_frames += 1
+        if self.on_overflow == "raise":
+            raise RuntimeError(f"RenderPipeline: a frame needed {need} segments but the buffers hold {self.max_segments}: its rays "
+                               f"were truncated.  calibrate() with that pose, raise max_segments, or use on_overflow='grow'")
+        if self.on_overflow == "grow":
+            torch.cuda.synchronize()                      # frames in flight still use the old buffers
+            self.max_segments = int(need * 1.5) + 1024
+            self._alloc_segments()
 
     def _shade(self, g):
         """sampler + encode + MLP (+ per-segment compositing when fused) over slot g's packed segments."""
@@ -180,10 +217,18 @@ class RenderPipeline:
         n = self.max_rays if ray_count is None else ray_count
         pixels = self.pixels[:n] if out is None else out
         g = self._slots[0]
+        self._check_overflow(g)
         self._geometry(g, ray_begin, n)
         self._shade(g)
         self._composite(g, n, pixels)
         return pixels
+
+    def finish(self):
+        """Wait for every enqueued frame and apply the overflow policy to all of them (raises under "raise")."""
+        self.drain_async()
+        torch.cuda.synchronize()
+        for g in self._slots:
+            self._check_overflow(g, wait=True)
 
     # ------------------------------------------------------------------------------------------ frame pipelining
     # A frame is three dependent stages with very different bounds: traversal (two latency-bound passes + scan, ~0.45 ms
@@ -222,6 +267,7 @@ class RenderPipeline:
         b = a.frame % a.n
         a.frame += 1
         g = self._slots[b]
+        self._check_overflow(g)                           # the frame that used this slot three frames ago
         main = torch.cuda.current_stream()
         with torch.cuda.stream(a.geo):
             if a.used[b]:
@@ -260,4 +306,5 @@ class RenderPipeline:
         return g, pixels
 
     def overflowed(self):
-        return any(int(g.total.item()) > self.max_segments for g in self._slots)
+        """True if a frame was ever truncated (synchronises: also looks at the frames still in flight)."""
+        return self.overflow_frames > 0 or any(int(g.total.item()) > self.max_segments for g in self._slots)

@@ -136,3 +136,41 @@ def test_compact_intermediate_gives_identical_pixels(gpu):
     S = int(pipes[0].total.item()) * 32
     assert torch.equal(pipes[0].radiance[:S].float(), pipes[1].radiance[:S])
     assert render.RenderPipeline(net, R, W, H, focal, occupancy=occ, vr_mode=api.VR_NERF).compact is False
+
+
+@pytest.mark.gpu
+def test_overflow_outside_the_calibrated_poses_is_reported_without_polling(gpu):
+    """A pose that needs more segments than calibrate() provided is truncated on the device; the pipeline must say so by
+    itself: 'raise' fails the next call on that slot / finish(), 'grow' re-allocates and the
+    re-rendered frame equals a properly sized pipeline's."""
+    torch = gpu
+    from rtx_nerf_amd import api, render, scenes
+    R, W, H = 64, 96, 96
+    occ = torch.from_numpy(scenes.pack_occupancy(scenes.lego_standin_density(R, seed=0)).view(np.int32).copy()).cuda()
+    net = api.Network(n_neurons=64, n_hidden_layers=2)
+    net.set_params(torch.from_numpy(scenes.xavier_params_fp16(64, 2, net.encoded_width(), seed=7)).cuda())
+    focal = scenes.lego_focal_length(True)
+    far = scenes.pose_spherical(10.0, -30.0, radius=40.0, origin_scale=10.0)    # tiny object in the frame: few segments
+    near = scenes.pose_spherical(10.0, -30.0, origin_scale=10.0)
+    ref = render.RenderPipeline(net, R, W, H, focal, occupancy=occ, max_segments=1024)
+    ref.calibrate([near])
+    ref.set_pose(near)
+    want = ref.render().clone()
+    # raise
+    pipe = render.RenderPipeline(net, R, W, H, focal, occupancy=occ, max_segments=1024)
+    pipe.calibrate([far])
+    assert pipe.max_segments < ref.max_segments // 2
+    pipe.set_pose(near)
+    cut = pipe.render().clone()                      # delivered, truncated
+    with pytest.raises(RuntimeError, match="truncated"):
+        pipe.finish()
+    assert pipe.overflow_frames == 1 and pipe.overflowed() and not torch.equal(cut, want)
+    # grow
+    pipe = render.RenderPipeline(net, R, W, H, focal, occupancy=occ, max_segments=1024, on_overflow="grow")
+    pipe.calibrate([far])
+    pipe.set_pose(near)
+    pipe.render()
+    torch.cuda.synchronize()
+    again = pipe.render().clone()                    # the check of this call sees the cut frame and grows the buffers first
+    pipe.finish()
+    assert pipe.overflow_frames == 1 and pipe.max_segments > ref.max_segments and torch.equal(again, want)

@@ -151,3 +151,69 @@ def test_png_decode_is_bit_exact_with_the_references_stb_image(tmp_path, name):
     got = ds.images[0]
     bad = np.nonzero(got.view(np.uint32) != want.view(np.uint32))
     assert bad[0].size == 0, f"{name}: {bad[0].size} of {want.size} values differ, e.g. got {got[bad][:4]} want {want[bad][:4]}"
+
+
+# ---- LLFF: the stub at data_loader.cpp:140-148 filled in -----------------------------------------------------------
+def _make_llff(tmp, n=4, w=12, h=9, factor=8, seed=0):
+    rng = np.random.default_rng(seed)
+    os.makedirs(tmp / f"images_{factor}", exist_ok=True)
+    pb = np.zeros((n, 17))
+    imgs = []
+    for i in range(n):
+        q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+        pb[i, :15] = np.concatenate([q, rng.standard_normal((3, 1)), np.array([[h * factor], [w * factor], [0.9 * w * factor]])], 1).reshape(-1)
+        pb[i, 15:] = [1.2 + i, 9.5 + i]
+        arr = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        Image.fromarray(arr, "RGB").save(tmp / f"images_{factor}" / f"image{(n - 1 - i):03d}.png")   # written out of order
+        imgs.append(arr)
+    np.save(tmp / "poses_bounds.npy", pb)
+    return pb, imgs[::-1]   # frames are taken in NAME order
+
+
+def test_llff_poses_bounds_and_frames(tmp_path):
+    pb, imgs = _make_llff(tmp_path)
+    sets = loader.load_llff_data(str(tmp_path), factor=8)
+    assert len(sets) == 1
+    ds = sets[0]
+    assert ds.images.shape == (4, 9, 12, 3) and ds.image_width == 12 and ds.image_height == 9
+    for i in range(4):
+        np.testing.assert_array_equal(ds.images[i], _stb_loadf(imgs[i]))
+        m = pb[i, :15].reshape(3, 5)
+        want = np.eye(4)
+        want[:3, :4] = np.concatenate([m[:, 1:2], -m[:, 0:1], m[:, 2:3], m[:, 3:4]], 1)   # (down,right,back) -> (right,up,back)
+        np.testing.assert_array_equal(ds.poses[i].reshape(4, 4), want.astype(np.float32))
+        c2w = ds.poses[i].reshape(4, 4)[:3, :3].astype(np.float64)
+        assert abs(np.linalg.det(c2w) - 1.0) < 1e-5                                      # still a proper rotation
+    np.testing.assert_array_equal(ds.bounds, pb[:, 15:].astype(np.float32))
+    assert abs(ds.focal - 0.9 * 12) < 1e-5                                               # focal scaled to the loaded resolution
+    assert abs(ds.camera_angle_x - 2 * np.arctan(0.5 * 12 / (0.9 * 12))) < 1e-6
+
+
+def test_llff_errors_give_the_references_empty_vector(tmp_path, capfd):
+    assert loader.load_llff_data(str(tmp_path / "absent")) == []                         # what the reference returns for LLFF
+    assert "poses_bounds.npy" in capfd.readouterr().err
+    _make_llff(tmp_path, n=3)
+    os.remove(tmp_path / "images_8" / "image001.png")
+    assert loader.load_llff_data(str(tmp_path)) == []
+    assert "2 .png frames but poses_bounds.npy has 3 poses" in capfd.readouterr().err
+    np.save(tmp_path / "poses_bounds.npy", np.zeros((3, 16)))
+    assert loader.load_llff_data(str(tmp_path)) == []
+    assert loader.load_data("LLFF", "LEGO", root=str(tmp_path / "nowhere")) == []
+
+
+# ---- hostile / corrupt inputs must come back as errors, never as a crash of the host process -----------
+def test_loader_survives_hostile_files(tmp_path, capfd):
+    good = _GOLD["png_rgb8"].tobytes()
+    huge = bytearray(good)
+    huge[16:24] = (0x7fffffff).to_bytes(4, "big") * 2                                    # IHDR 2^31-1 x 2^31-1
+    _one_frame_scene(tmp_path, bytes(huge))
+    assert loader.load_images_json(str(tmp_path), "train").images.shape[0] == 0
+    assert "too large" in capfd.readouterr().err
+    _one_frame_scene(tmp_path, good)
+    (tmp_path / "transforms_train.json").write_text('{"camera_angle_x": 0.69, "frames": ' + "[" * 100000)
+    assert loader.load_images_json(str(tmp_path), "train").images.shape[0] == 0
+    assert "nesting too deep" in capfd.readouterr().err
+    (tmp_path / "transforms_train.json").write_text('{"camera_angle_x": 0.6911112')      # truncated inside a number
+    assert loader.load_images_json(str(tmp_path), "train").images.shape[0] == 0
+    (tmp_path / "transforms_train.json").write_text('{"camera_angle_x": tru')             # truncated inside a keyword
+    assert loader.load_images_json(str(tmp_path), "train").images.shape[0] == 0

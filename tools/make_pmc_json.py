@@ -4,9 +4,21 @@
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts a wide coalesced read at half its bytes
 (MI355X_MICROARCH.md, HBM): the read side is therefore quoted as the interval [1x, 2x] and bench.py reports the high end."""
 import csv
+import hashlib
 import json
+import os
 import sys
 from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_src_sha16():
+    """Same fingerprint bench.py computes: the summary is only quoted for the kernel source it was measured on."""
+    h = hashlib.sha256()
+    for f in ("rtx_nerf_amd/csrc/mlp.hip", "rtx_nerf_amd/csrc/mlp_internal.h"):
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def means(path, pat="mlp_fwd_kernel"):
@@ -27,6 +39,7 @@ s, ms, _ = means(sq)
 cycles = s["GRBM_GUI_ACTIVE"] / 8
 d = {
     "source": note,
+    "kernel_src_sha16": kernel_src_sha16(),
     "kernel": name,
     "samples_per_launch": int(samples),
     "FETCH_SIZE_KiB_avg": round(f["FETCH_SIZE"], 2),
