@@ -128,6 +128,56 @@ __device__ __forceinline__ float4 seg_composite(float r, float g, float b, float
 // MODE 2 (training backward, TRANSPOSED layers, stored in backward order out, L-1, ..., 0):
 //   layer l  : element = Wl[perm_feature(kk,h,j)][32rt + r], rows = in_width(l) padded to 32, K = out rows
 //              (16 for the output layer: one k-step; W otherwise).
+// MODE 3 (inference on v_mfma_f32_16x16x32_f16, mlp_fwd16_kernel): fragments are 16 rows x 32 k, lane l = (r = l&15,
+//   g = l>>4) at byte 16*l, chunks [rowtile16][kstep32];
+//   layer 0  : element (r,g ; kk ; j) = W0[16rt + r][enc16_feature(8kk + j, g>>1, g&1)]  (0 where there is none), K = k0_16
+//   others   : element = Wl[16rt + r][perm_feature16(kk,g,j)]                             (output layer: one 16-row tile)
+struct Enc16Dims { int PD, PF, DD, DF, E, k0; };
+// Layer-0 input order of the 16x16x32 kernel.  Lane group g = 2q + h: h selects sin/cos, q the upper half of the
+// frequencies -- j-slot u of a k-step names one (dimension, frequency f0) and the four lane groups hold
+// sin/cos(2^(f0 + q*F/2) pi x): direction slots first (DD*DF/2), then position (PD*PF/2), then the 1.0 padding, then
+// nothing.  Returns the tcnn feature index (Composite: position block, then direction block, then padding) or -1.
+__host__ __device__ inline int enc16_feature(const Enc16Dims& d, int u, int q, int h) {
+  const int ND = d.DD * d.DF / 2, NP = d.PD * d.PF / 2, width = 2 * (d.PD * d.PF + d.DD * d.DF), NPAD = (d.E - width) / 4;
+  if (u < ND) { const int dd = u / (d.DF / 2), f = u % (d.DF / 2) + q * (d.DF / 2); return 2 * d.PD * d.PF + (dd * d.DF + f) * 2 + h; }
+  if (u < ND + NP) { const int v = u - ND, dim = v / (d.PF / 2), f = v % (d.PF / 2) + q * (d.PF / 2); return (dim * d.PF + f) * 2 + h; }
+  if (u < ND + NP + NPAD) return width + 4 * (u - ND - NP) + 2 * q + h;
+  return -1;
+}
+
+//   output layer: FOUR variants of its single 16-row tile, [variant v][kstep]: variant 0 is the layer as it is (all 16
+//   rows; what OUT_MODE 0 uses for every column tile); variant v > 0 holds output rows 0..3 at tile rows 4v..4v+3 and zeros
+//   elsewhere, so that column tile v's MFMA leaves ITS (r, g, b, sigma) in lane group v -- the matrix core does the
+//   transposition that lets all 64 lanes of a wave run the sigmoid epilogue on one sample each.
+__global__ void pack16_kernel(const _Float16* __restrict__ params, _Float16* __restrict__ packed, int W, int n_hidden, Enc16Dims d) {
+  const int RT = W / 16, KS = W / 32, KS0 = d.k0 / 32, E = d.E;
+  const long l0 = (long)KS0 * RT * 512, hid = (long)KS * RT * 512, outl = 4L * KS * 512;
+  const long total = l0 + (long)(n_hidden - 1) * hid + outl;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    int layer;
+    long q = e;
+    if (q < l0) layer = 0;
+    else {
+      q -= l0;
+      layer = 1 + (int)(q / hid);
+      if (layer >= n_hidden) { layer = n_hidden; q -= (long)(n_hidden - 1) * hid; } else q -= (long)(layer - 1) * hid;
+    }
+    const int j = (int)(q & 7), lane = (int)((q >> 3) & 63);
+    const long chunk = q >> 9;
+    const int r = lane & 15, g = lane >> 4;
+    const int ks_count = layer == 0 ? KS0 : KS;
+    const int kk = (int)(chunk % ks_count), rt = (int)(chunk / ks_count);   // output layer: rt = rotation variant
+    const int in_w = layer == 0 ? E : W, rows = layer == n_hidden ? 16 : W;
+    int row = 16 * rt + r;
+    if (layer == n_hidden) row = rt == 0 ? r : ((r >> 2) == rt ? (r & 3) : rows);   // variant v: rows 4v..4v+3 <- outputs 0..3
+    const int feat = layer == 0 ? enc16_feature(d, 8 * kk + j, g >> 1, g & 1) : rtxn::perm_feature16(kk, g, j);
+    const long base = layer == 0 ? 0 : (long)W * E + (long)(layer - 1) * W * W;
+    _Float16 v = (_Float16)0.0f;
+    if (row < rows && feat >= 0 && feat < in_w) v = params[base + (long)row * in_w + feat];
+    packed[e] = v;
+  }
+}
+
 __global__ void pack_kernel(const _Float16* __restrict__ params, _Float16* __restrict__ packed, int W, int E, int k0,
                             int n_hidden, int mode) {
   const int RT = W / 32;
@@ -616,6 +666,401 @@ __global__ __launch_bounds__(64 * RTXN_NW, CT == 2 ? 2 : 1) void mlp_fwd_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// The 64/128-wide kernel on v_mfma_f32_16x16x32_f16 (mlp_internal.h, pipe_layer16)
+// ---------------------------------------------------------------------------
+// Same block geometry, LDS plan, staging protocol and wave-group skew as mlp_fwd_kernel; what changes is the fragment
+// shape and with it who holds what: lane (c = l & 15, g = l >> 4) owns sample 16 ct + c of the wave's four 16-column tiles
+// and, of every 32 features, the eight perm_feature16 gives its lane group.  In layer 0 lane group g = 2q + h computes
+// sin (h = 0) / cos (h = 1) of the LOWER (q = 0) / UPPER (q = 1) half of each dimension's frequencies: the inputs are
+// pre-scaled once per tile by 2^(q F/2) (exact), after which j-slot u of a k-step is one compile-time (dimension, f0)
+// for all four groups and the per-slot instructions are those of the 32x32 kernel, bit-identical values included.
+template <int PD, int PF, int DD, int DF>
+struct EncSpec16 {
+  static_assert(PF % 2 == 0 && DF % 2 == 0, "the lane-group split halves each dimension's frequencies");
+  static constexpr int enc_width = 2 * (PD * PF + DD * DF);
+  static constexpr int enc_padded = (enc_width + 15) / 16 * 16;
+  static constexpr int ND = DD * DF / 2, NP = PD * PF / 2, NPAD = (enc_padded - enc_width) / 4;
+  static constexpr int n_jslots = ND + NP + NPAD;
+  static constexpr int k0 = (n_jslots + 7) / 8 * 32;   // first-layer K as staged (32 per k-step)
+};
+
+// value of j-slot U for this lane (plain code: padding slots and the odd real slot next to one)
+template <class ES, int PD, int PF, int DD, int DF, int U>
+__device__ __forceinline__ _Float16 encode_slot16(const float (&xq)[5], float phase) {
+  if constexpr (U < ES::ND) {
+    constexpr int dd = U / (DF / 2), f0 = U % (DF / 2);
+    return (_Float16)__builtin_amdgcn_sinf(__builtin_amdgcn_fractf(xq[PD + dd] * (0.5f * (float)(1u << f0))) + phase);
+  } else if constexpr (U < ES::ND + ES::NP) {
+    constexpr int v = U - ES::ND, dim = v / (PF / 2), f0 = v % (PF / 2);
+    return (_Float16)__builtin_amdgcn_sinf(__builtin_amdgcn_fractf(xq[dim] * (0.5f * (float)(1u << f0))) + phase);
+  } else if constexpr (U < ES::n_jslots) {
+    return (_Float16)1.0f;
+  }
+  return (_Float16)0.0f;
+}
+
+template <int PD, int PF, int DD, int DF>
+struct DirShare16 {
+  static constexpr bool possible = DD == 2 && (DD * DF / 2) % 2 == 0 && DD * DF / 2 <= 16;
+  static constexpr int n_dwords = possible ? DD * DF / 4 : 1;
+};
+
+// Segment input: a segment is TWO adjacent 16-column tiles and its direction features are the same for all 32 samples.
+// Lane (c, g) computes direction j-slot c of its own lane group (q, h) once, neighbours pack with a DPP move, and
+// DD*DF/4 ds_bpermute broadcasts give every lane of the group the finished B-fragment dwords (cf. share_direction).
+// theta / phi come in already scaled by 2^(q DF/2).
+template <int PD, int PF, int DD, int DF>
+__device__ __forceinline__ void share_direction16(float theta_q, float phi_q, float phase, int lane,
+                                                  int (&dirs)[DirShare16<PD, PF, DD, DF>::n_dwords]) {
+  const int c = lane & 15;
+  const int u = c < DD * DF / 2 ? c : 0;
+  const float xs = u >= DF / 2 ? phi_q : theta_q;
+  const float rev = __builtin_amdgcn_fractf(xs * ldexpf(0.5f, u % (DF / 2))) + phase;
+  const float v = __builtin_amdgcn_sinf(rev);
+  const float w = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  float2v pr = {v, w};
+  const int packed = __builtin_bit_cast(int, __builtin_convertvector(pr, half2v));
+#pragma unroll
+  for (int j = 0; j < DirShare16<PD, PF, DD, DF>::n_dwords; ++j)
+    dirs[j] = __builtin_amdgcn_ds_bpermute(4 * ((lane & 48) + 2 * j), packed);
+}
+
+// dword E (0..3) of the B fragment of k-step KK for one column tile: j-slots 8 KK + 2 E, + 1
+template <class ES, int PD, int PF, int DD, int DF, bool SHARE, int KK, int E>
+__device__ __forceinline__ int encode_unit16(const float (&xq)[5], float phase, const int (&dirs)[DirShare16<PD, PF, DD, DF>::n_dwords]) {
+  constexpr int u0 = 8 * KK + 2 * E, u1 = u0 + 1;
+  if constexpr (SHARE && u1 < ES::ND) {
+    return dirs[u0 / 2];
+  } else if constexpr (u1 < ES::ND + ES::NP && (u0 >= ES::ND || u1 < ES::ND)) {   // two real slots of one kind
+    constexpr bool dir = u1 < ES::ND;
+    constexpr int v0 = dir ? u0 : u0 - ES::ND, v1 = v0 + 1, H = dir ? DF / 2 : PF / 2, base = dir ? PD : 0;
+    constexpr int d0 = base + v0 / H, d1 = base + v1 / H;
+    const float c0 = 0.5f * (float)(1u << (v0 % H)), c1 = 0.5f * (float)(1u << (v1 % H));
+    int r;
+    float t0, t1;
+    asm volatile(
+        "v_mul_f32 %1, %4, %3\n\t"
+        "v_mul_f32 %2, %6, %5\n\t"
+        "v_fract_f32 %1, %1\n\t"
+        "v_fract_f32 %2, %2\n\t"
+        "v_add_f32 %1, %1, %7\n\t"
+        "v_add_f32 %2, %2, %7\n\t"
+        "v_sin_f32 %1, %1\n\t"
+        "v_sin_f32 %2, %2\n\t"
+        "s_nop 0\n\t"
+        "v_cvt_pk_f16_f32 %0, %1, %2"
+        : "=v"(r), "=&v"(t0), "=&v"(t1)
+        : "v"(xq[d0]), "s"(c0), "v"(xq[d1]), "s"(c1), "v"(phase));
+    return r;
+  } else {
+    half2v v;
+    v[0] = encode_slot16<ES, PD, PF, DD, DF, u0>(xq, phase);
+    v[1] = encode_slot16<ES, PD, PF, DD, DF, u1>(xq, phase);
+    return __builtin_bit_cast(int, v);
+  }
+}
+// WHICH: 0 every unit; 1 only the shared direction dwords (plain register moves); 2 everything but those
+template <class ES, int PD, int PF, int DD, int DF, int CT, bool SHARE, int KK, int U0, int U1, int WHICH = 0>
+__device__ __forceinline__ void encode_units16(const float (&xq)[CT][5], float phase, half8 (&b)[CT],
+                                               const int (&dirs)[CT / 2][DirShare16<PD, PF, DD, DF>::n_dwords]) {
+  if constexpr (U0 < U1) {   // unit U: column tile U / 4, dword U % 4
+    constexpr int ct = U0 / 4, e = U0 % 4;
+    constexpr bool shared = SHARE && 8 * KK + 2 * e + 1 < ES::ND;
+    if constexpr (WHICH == 0 || (WHICH == 1) == shared) {
+      rtxn::int4v t = __builtin_bit_cast(rtxn::int4v, b[ct]);
+      t[e] = encode_unit16<ES, PD, PF, DD, DF, SHARE, KK, e>(xq[ct], phase, dirs[ct / 2]);
+      b[ct] = __builtin_bit_cast(half8, t);
+    }
+    encode_units16<ES, PD, PF, DD, DF, CT, SHARE, KK, U0 + 1, U1, WHICH>(xq, phase, b, dirs);
+  }
+}
+
+// The shared direction dwords (k-steps 0 and, for the reference model, 1) are in place before the first step: the pipeline
+// itself encodes position / padding slots only and carries no direction table (12 VGPRs fewer under the 128 accumulators).
+template <class ES, int PD, int PF, int DD, int DF, int RT, int KS0, int NB, int CT, bool SHARE, int I>
+struct Layer0Step16 {
+  using DirTab = int[CT / 2][DirShare16<PD, PF, DD, DF>::n_dwords];
+  static constexpr int D = RTXN_PIPE16, N = RT * KS0, WAVES = RTXN_NW;
+  static constexpr int CHUNKS = N < 32 / WAVES ? N : 32 / WAVES;
+  static constexpr int UE = (4 * CT + RT - 1) / RT;   // encode units per (kk, rt) sub-step
+  __device__ static __forceinline__ void run(unsigned addr, const float (&xq)[CT][5], float phase, half8 (&b)[2][CT],
+                                             half8 (&out)[NB][CT], half8 (&ring)[D], rtxn::floatx4 (&acc)[RT][CT],
+                                             const rtxn::StageJob& sj, int wave_u, int lane, const DirTab& dirs) {
+    constexpr int kk = I / RT, rt = I % RT, cur = kk & 1;
+    constexpr int outstanding = (N - 1 - I) < (D - 1) ? (N - 1 - I) : (D - 1);
+    rtxn::lds_wait<outstanding>();
+    const half8 a = ring[I % D];
+    if (kk == 0) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[rt][ct][e] = 0.0f;
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[cur][ct], acc[rt][ct], 0, 0, 0);
+    if constexpr (kk + 1 < KS0) {
+      constexpr int u0 = rt * UE < 4 * CT ? rt * UE : 4 * CT, u1 = (rt + 1) * UE < 4 * CT ? (rt + 1) * UE : 4 * CT;
+      encode_units16<ES, PD, PF, DD, DF, CT, SHARE, kk + 1, u0, u1, (SHARE && kk + 1 < 2) ? 2 : 0>(xq, phase, b[cur ^ 1], dirs);
+    } else if constexpr (rt > 0) {
+      rtxn::convert_units16<NB, CT, rt - 1, 0, 2 * CT>(acc[rt - 1], out);   // last k-step: row tile rt-1 is complete
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (I + D < N) rtxn::lds_read_frag<(((I + D) % RT) * KS0 + (I + D) / RT) * 1024>(ring[I % D], addr);
+    if constexpr (I < CHUNKS) {
+      rtxn::stage_chunk<I, WAVES>(sj, wave_u, lane);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (I + 1 < N)
+      Layer0Step16<ES, PD, PF, DD, DF, RT, KS0, NB, CT, SHARE, I + 1>::run(addr, xq, phase, b, out, ring, acc, sj, wave_u, lane, dirs);
+  }
+};
+
+template <class ES, int PD, int PF, int DD, int DF, int RT, int KS0, int NB, int CT, bool SHARE>
+__device__ __forceinline__ void pipe_layer0_16(const uint8_t* lds_buf, const rtxn::StageJob& sj, const float (&xq)[CT][5], float phase,
+                                               const int (&dirs)[CT / 2][DirShare16<PD, PF, DD, DF>::n_dwords],
+                                               half8 (&out)[NB][CT], rtxn::floatx4 (&pend)[CT], int wave_u, int lane) {
+  constexpr int D = RTXN_PIPE16, N = RT * KS0;
+  static_assert(N * 1024 <= 65535 + 1024, "fragment offsets must fit the 16-bit ds offset");
+  static_assert(RT % 2 == 0, "the pending row tile is the odd tile of its pair");
+  half8 ring[D];
+  const unsigned addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) uint8_t*)lds_buf + lane * 16;
+  rtxn::lds_read_frag<0>(ring[0], addr);
+  if constexpr (D > 1) rtxn::lds_read_frag<((1 % RT) * KS0 + 1 / RT) * 1024>(ring[1 % D], addr);
+  if constexpr (D > 2) rtxn::lds_read_frag<((2 % RT) * KS0 + 2 / RT) * 1024>(ring[2 % D], addr);
+  if constexpr (D > 3) rtxn::lds_read_frag<((3 % RT) * KS0 + 3 / RT) * 1024>(ring[3 % D], addr);
+  static_assert(!SHARE || ES::ND <= 16, "shared direction slots must lie in k-steps 0 and 1");
+  half8 b[2][CT];
+  encode_units16<ES, PD, PF, DD, DF, CT, SHARE, 0, 0, 4 * CT>(xq, phase, b[0], dirs);   // k-step 0: nothing to hide behind yet
+  if constexpr (SHARE && KS0 > 1) encode_units16<ES, PD, PF, DD, DF, CT, SHARE, 1, 0, 4 * CT, 1>(xq, phase, b[1], dirs);
+  // Segment input: the two column tiles of a segment get IDENTICAL k-step-0 fragments when that k-step holds direction
+  // slots only, and hipcc then merges their MFMAs (one result feeding both accumulator chains: an out-of-place MFMA for one
+  // tile, in-place for the other).  Legal for the compiler -- but that kernel came out wrong on the hardware, and not
+  // reproducibly so (first column tile of a wave's first segment; tools/scratch notes in DESIGN.md 3.4), while every build
+  // that keeps the four accumulator chains separate is exact and bit-deterministic.  The hand-placed asm slices of this
+  // pipeline rely on the chains being what the source says, so the fragments are made opaque to value numbering.
+  if constexpr (SHARE) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) asm volatile("" : "+v"(b[0][ct]));
+  }
+  rtxn::floatx4 acc[RT][CT];
+  Layer0Step16<ES, PD, PF, DD, DF, RT, KS0, NB, CT, SHARE, 0>::run(addr, xq, phase, b, out, ring, acc, sj, wave_u, lane, dirs);
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) pend[ct] = acc[RT - 1][ct];
+}
+
+// OUT_MODE 0: half[n][16]; 1: float4 radiance (+ t_vals); 3: compact half4.  (The per-segment compositor epilogue,
+// OUT_MODE 2, exists only in the 32x32 kernel.)
+template <int W, int PD, int PF, int DD, int DF, int IN_MODE, int OUT_MODE>
+__global__ __launch_bounds__(512, 2) void mlp_fwd16_kernel(FwdArgs a) {
+  static_assert(RTXN_NW == 8, "8-wave blocks");
+  static_assert(OUT_MODE != 2, "segment-composite epilogue: 32x32 kernel only");
+  constexpr int CT = 4, THREADS = 512;
+  constexpr int TILE = 512, TILE_SEGS = 16;             // samples / segments per block per iteration
+  using ES = EncSpec16<PD, PF, DD, DF>;
+  constexpr int RT = W / 16, KS = W / 32, KS0 = ES::k0 / 32;
+  constexpr int NB = KS0 > KS ? KS0 : KS;
+  constexpr int L0_BYTES = KS0 * RT * 1024, HID_BYTES = KS * RT * 1024, OUT_BYTES = 4 * KS * 1024;
+  constexpr int RES_BYTES = L0_BYTES + OUT_BYTES;       // [layer 0 | output layer x 4 rotations | 3 x HID_BYTES]
+  constexpr bool ROT = OUT_MODE != 0;                   // 4-output epilogue: column tile v's outputs land in lane group v
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4, q = g >> 1;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  // Tile bookkeeping in 32-bit scalars: gfx950 has no 64-bit scalar compare, so `long` counters put every uniform loop
+  // and fetch decision through VCC and the staging jobs behind vector branches (measured: +35 % VALU instructions).
+  long total_seg = 0;
+  int n_tiles;
+  if (IN_MODE == 1) {
+    total_seg = *a.total_segments;
+    if (total_seg > a.max_segments) total_seg = a.max_segments;
+    n_tiles = (int)((total_seg + TILE_SEGS - 1) / TILE_SEGS);
+  } else {
+    n_tiles = (int)((a.n + TILE - 1) / TILE);
+  }
+  n_tiles = __builtin_amdgcn_readfirstlane(n_tiles);
+  const int tile_step = (int)gridDim.x;
+  if ((int)blockIdx.x >= n_tiles) return;
+
+  const int n_layers = a.n_hidden + 1;
+  auto layer_off = [&](int l) -> unsigned { return l == 0 ? 0u : (unsigned)L0_BYTES + (unsigned)(l - 1) * HID_BYTES; };
+  const int grp = wave_u >> 2;              // 0: leading wave group, 1: one stage behind (see mlp_fwd_kernel, SKEW)
+  const int n_hid = n_layers - 2;
+  stage<L0_BYTES, THREADS>(a.packed, smem, tid);
+  stage<OUT_BYTES, THREADS>(a.packed + layer_off(n_layers - 1), smem + L0_BYTES, tid);
+  int qs = 0;                               // hidden stages this wave has begun (ring slot = qs % 3)
+
+  const float pos_scale = q ? (float)(1u << (PF / 2)) : 1.0f, dir_scale = q ? (float)(1u << (DF / 2)) : 1.0f;
+  float xq[CT][5];                          // inputs of the lane's four samples, already scaled for its lane group
+  auto sample_of = [&](int tile, int ct, bool& valid) -> long {
+    if (IN_MODE == 1) {
+      const long seg = (long)tile * TILE_SEGS + wave_u * 2 + (ct >> 1);
+      valid = seg < total_seg;
+      return seg * 32 + 16 * (ct & 1) + c;
+    }
+    const long sidx = (long)tile * TILE + wave_u * 64 + ct * 16 + c;
+    valid = sidx < a.n;
+    return sidx;
+  };
+  auto load_inputs = [&](int tile) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      bool valid_in;
+      const long samp_in = sample_of(tile, ct, valid_in);
+      if (IN_MODE == 1) {
+        const long sg = valid_in ? (samp_in >> 5) : 0;
+        const float t = (float)(16 * (ct & 1) + c) * (1.0f / 32);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float og = a.start[3 * sg + k];
+          xq[ct][k] = fmaf(t, a.end[3 * sg + k] - og, og) * pos_scale;   // REGULAR sample, sampler.cu:52-66; exact scaling
+        }
+        xq[ct][3] = a.seg_view[2 * sg] * dir_scale;
+        xq[ct][4] = a.seg_view[2 * sg + 1] * dir_scale;
+      } else {
+        const long sidx = valid_in ? samp_in : 0;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) xq[ct][k] = a.input[5 * sidx + k] * (k < PD ? pos_scale : dir_scale);
+      }
+    }
+  };
+  load_inputs((int)blockIdx.x);
+
+  if (grp == 1) {
+    if (n_hid > 0) {
+      rtxn::StageJob sj0{a.packed + layer_off(1), smem + RES_BYTES, HID_BYTES / 1024};
+      rtxn::stage_chunk<0, 8>(sj0, wave_u, lane);
+      rtxn::stage_chunk<1, 8>(sj0, wave_u, lane);
+      rtxn::stage_chunk<2, 8>(sj0, wave_u, lane);
+      rtxn::stage_chunk<3, 8>(sj0, wave_u, lane);
+    }
+    rtxn::staged_barrier();
+  }
+  for (int tile = (int)blockIdx.x; tile < n_tiles; tile += tile_step) {
+    const float phase = 0.25f * (float)(g & 1);
+    const bool more = tile + tile_step < n_tiles;       // this block has another tile after this one
+    if (IN_MODE == 1 && OUT_MODE == 1 && a.t_vals) {
+      // REGULAR t_vals (sampler.cu:65: post-increment) of the wave's 64 samples, one per lane: lane l is sample l of the two
+      // segments.  The lane index goes through an empty asm so that the per-lane address is formed here, not hoisted out of
+      // the tile loop and carried in VGPRs through layer 0's register peak (it was, and got spilled).
+      int lane_t = lane;
+      asm volatile("" : "+v"(lane_t));
+      const long seg = (long)tile * TILE_SEGS + wave_u * 2 + (lane_t >> 5);
+      if (seg < total_seg) a.t_vals[seg * 32 + (lane_t & 31)] = (float)((lane_t & 31) + 1) * (1.0f / 32);
+    }
+    constexpr bool SHARE = RTXN_SHARE_DIR && IN_MODE == 1 && DirShare16<PD, PF, DD, DF>::possible;
+    int dirs[CT / 2][DirShare16<PD, PF, DD, DF>::n_dwords];
+    if constexpr (SHARE) {
+#pragma unroll
+      for (int sg = 0; sg < CT / 2; ++sg) share_direction16<PD, PF, DD, DF>(xq[2 * sg][PD], xq[2 * sg][PD + 1], phase, lane, dirs[sg]);
+    }
+
+    half8 bf[NB][CT], bg[NB][CT];
+    rtxn::floatx4 acc2[2][CT];
+    rtxn::StageJob sj;
+    auto begin_stage = [&](int l) -> const uint8_t* {
+      rtxn::staged_barrier();
+      const bool hidden = l > 0 && l < n_layers - 1;
+      const uint8_t* cur = l == 0 ? smem : (hidden ? smem + RES_BYTES + (qs % 3) * HID_BYTES : smem + L0_BYTES);
+      const int h0 = l == 0 ? 0 : (hidden ? l - 1 : n_hid);
+      int lk = l + 1 + grp, inst = qs - h0;
+      bool exists = true;
+      if (lk >= n_layers) { lk -= n_layers; inst += n_hid; exists = more; }
+      const bool fetch = exists && lk > 0 && lk < n_layers - 1;
+      // everything in the job is wave-uniform, and says so: scalar registers, scalar branches around the fetches
+      sj.g = a.packed + (unsigned)__builtin_amdgcn_readfirstlane((int)layer_off(fetch ? lk : 0));
+      sj.lds = smem + RES_BYTES + (unsigned)__builtin_amdgcn_readfirstlane(((inst + lk - 1) % 3) * HID_BYTES);
+      sj.nfrags = __builtin_amdgcn_readfirstlane(fetch ? HID_BYTES / 1024 : 0);
+      if (hidden) ++qs;
+      if (l == 1 && more) load_inputs(tile + tile_step);
+      return cur;
+    };
+    auto finish = [&](half8 (&in)[NB][CT], half8 (&other)[NB][CT]) {
+      const uint8_t* w = begin_stage(n_layers - 1);
+      if constexpr (!ROT) {
+        rtxn::pipe_layer16<0, KS, NB, CT, true>(w, sj, in, other, acc2, wave_u, lane);
+        // output rows 4g .. 4g+3 of sample (ct, c) are this lane's four accumulator registers
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          bool valid;
+          const long samp = sample_of(tile, ct, valid);
+          if (valid) {
+            half4v o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float z = acc2[0][ct][e];
+              o[e] = (_Float16)(a.out_act == RTXN_ACT_SIGMOID ? 1.0f / (1.0f + __expf(-z)) : z);
+            }
+            *reinterpret_cast<half4v*>(a.out_half + samp * 16 + 4 * g) = o;
+          }
+        }
+      } else {
+        // Rotated output layer: column tile ct multiplies by variant ct of the layer (pack16_kernel), so its four outputs
+        // arrive in lane group ct.  16 of the layer stack's 1040 MFMAs: compiler-scheduled, the pending tile converted up front.
+        rtxn::stage_chunk<0, 8>(sj, wave_u, lane);
+        rtxn::stage_chunk<1, 8>(sj, wave_u, lane);
+        rtxn::stage_chunk<2, 8>(sj, wave_u, lane);
+        rtxn::stage_chunk<3, 8>(sj, wave_u, lane);
+        rtxn::convert_units16<NB, CT, 2 * KS - 1, 0, 2 * CT>(acc2[1], in);
+        rtxn::floatx4 z4[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) z4[ct][e] = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) {
+            const half8 af = *reinterpret_cast<const half8*>(w + ((ct * KS + kk) * 64 + lane) * 16);
+            z4[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, in[kk][ct], z4[ct], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);   // one k-step's four fragments in flight at a time (all 16 hoisted = 64 VGPRs: spills)
+        }
+        // lane (c, g): sample 16 g + c of the wave's 64 -- consecutive lanes, consecutive samples
+        rtxn::floatx4 z = g == 0 ? z4[0] : (g == 1 ? z4[1] : (g == 2 ? z4[2] : z4[3]));
+        bool valid;
+        long samp;
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));   // form the store address HERE (see t_vals above): not a loop invariant to carry around
+        if (IN_MODE == 1) {
+          const long seg = (long)tile * TILE_SEGS + wave_u * 2 + (lane_e >> 5);
+          valid = seg < total_seg;
+          samp = seg * 32 + (lane_e & 31);
+        } else {
+          samp = (long)tile * TILE + wave_u * 64 + lane_e;
+          valid = samp < a.n;
+        }
+        if (valid) {
+          half4v o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (_Float16)(a.out_act == RTXN_ACT_SIGMOID ? 1.0f / (1.0f + __expf(-z[e])) : z[e]);
+          if (OUT_MODE == 3) *reinterpret_cast<half4v*>(a.out_half + samp * 4) = o;
+          else a.radiance[samp] = make_float4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
+        }
+      }
+    };
+    {
+      const uint8_t* w = begin_stage(0);
+      pipe_layer0_16<ES, PD, PF, DD, DF, RT, KS0, NB, CT, SHARE>(w, sj, xq, phase, dirs, bg, acc2[1], wave_u, lane);
+    }
+    int l = 1;
+    for (; l + 1 < n_layers - 1; l += 2) {
+      const uint8_t* w = begin_stage(l);
+      rtxn::pipe_layer16<RT, KS, NB, CT, true>(w, sj, bg, bf, acc2, wave_u, lane);
+      w = begin_stage(l + 1);
+      rtxn::pipe_layer16<RT, KS, NB, CT, true>(w, sj, bf, bg, acc2, wave_u, lane);
+    }
+    if (l < n_layers - 1) {
+      const uint8_t* w = begin_stage(l);
+      rtxn::pipe_layer16<RT, KS, NB, CT, true>(w, sj, bg, bf, acc2, wave_u, lane);
+      finish(bf, bg);
+    } else {
+      finish(bg, bf);
+    }
+  }
+  if (grp == 0) rtxn::staged_barrier();
+}
+
+// ---------------------------------------------------------------------------
 // 256-wide variant (BASELINE config 5: 8x256)
 // ---------------------------------------------------------------------------
 // One 256x256 layer is 128 KiB of A fragments -- it cannot be double-buffered in 160 KiB of LDS.
@@ -833,6 +1278,10 @@ struct Variant {
   int threads;        // block size
   int blocks_per_cu;  // persistent grid = CUs x this
   int tile;           // samples per block per iteration (segments: tile / 32)
+  // the same model on v_mfma_f32_16x16x32_f16 (mlp_fwd16_kernel; none for the 256-wide variant): [IN_MODE][OUT_MODE], no OUT_MODE 2
+  fwd_fn fn16[2][4];
+  int k0_16;          // first-layer K as staged for that kernel
+  size_t lds16;
 };
 
 #ifndef RTXN_CT
@@ -858,6 +1307,21 @@ Variant make_variant() {
   v.threads = 64 * RTXN_NW;
   v.blocks_per_cu = (CT == 2 ? 2 : 1) * 4 / RTXN_NW;
   v.tile = 32 * RTXN_NW * CT;
+  memset(v.fn16, 0, sizeof(v.fn16));
+  v.k0_16 = 0;
+  v.lds16 = 0;
+  // same 512-sample tiles per block as the 32x32 kernel.  Not built for the 128-wide model with fewer than 8 direction slots
+  // (DF = 4): its compact segment variant needs two VGPRs more than the 256 of two waves per SIMD and would spill.
+  if constexpr (RTXN_NW == 8 && CT == 2 && PF % 2 == 0 && DF % 2 == 0 && (W == 64 || DD * DF / 2 >= 8)) {
+    using ES16 = EncSpec16<PD, PF, DD, DF>;
+    v.fn16[0][0] = mlp_fwd16_kernel<W, PD, PF, DD, DF, 0, 0>;
+    v.fn16[0][1] = mlp_fwd16_kernel<W, PD, PF, DD, DF, 0, 1>;
+    v.fn16[1][0] = mlp_fwd16_kernel<W, PD, PF, DD, DF, 1, 0>;
+    v.fn16[1][1] = mlp_fwd16_kernel<W, PD, PF, DD, DF, 1, 1>;
+    v.fn16[1][3] = mlp_fwd16_kernel<W, PD, PF, DD, DF, 1, 3>;
+    v.k0_16 = ES16::k0;
+    v.lds16 = (size_t)(ES16::k0 / 32) * (W / 16) * 1024 + 4 * (size_t)(W / 32) * 1024 + 3 * (size_t)(W / 32) * (W / 16) * 1024;
+  }
   return v;
 }
 
@@ -879,6 +1343,9 @@ Variant make_variant256() {
   v.threads = kThreads256;
   v.blocks_per_cu = 1;
   v.tile = 256;
+  memset(v.fn16, 0, sizeof(v.fn16));
+  v.k0_16 = 0;
+  v.lds16 = 0;
   return v;
 }
 
@@ -922,7 +1389,8 @@ int launch_fwd(const rtxn_mlp* m, FwdArgs& a, int in_mode, int out_mode, long n_
   const Variant& v = variants()[m->variant];
   const long per_tile = in_mode == 1 ? v.tile / 32 : v.tile;
   const long n_tiles = (n_units + per_tile - 1) / per_tile;
-  a.packed = static_cast<const uint8_t*>(m->packed);
+  const bool use16 = m->mfma16 && v.fn16[in_mode][out_mode] != nullptr;   // same tile size, grid and block shape either way
+  a.packed = static_cast<const uint8_t*>(use16 ? m->packed16 : m->packed);
   a.n_hidden = m->cfg.n_hidden_layers;
   a.out_act = m->cfg.output_activation;
   // CU count and the dynamic-LDS attribute are per DEVICE: a process may drive several GPUs (and they need not be alike)
@@ -933,20 +1401,20 @@ int launch_fwd(const rtxn_mlp* m, FwdArgs& a, int in_mode, int out_mode, long n_
   const int cus = n_cu - m->reserved_cus > 1 ? n_cu - m->reserved_cus : 1;
   long grid = n_tiles < (long)cus * v.blocks_per_cu ? n_tiles : (long)cus * v.blocks_per_cu;  // persistent grid
   if (grid < 1) grid = 1;
-  fwd_fn fn = v.fn[in_mode][out_mode];
+  fwd_fn fn = use16 ? v.fn16[in_mode][out_mode] : v.fn[in_mode][out_mode];
+  const size_t lds = use16 ? v.lds16 : v.lds;
   {
     constexpr int kMaxDev = 64;
     static std::mutex mu;
-    static bool attr_set[kMaxDev][16][2][4] = {};
+    static bool attr_set[kMaxDev][16][2][2][4] = {};
     std::lock_guard<std::mutex> lock(mu);
-    const bool known = dev >= 0 && dev < kMaxDev && attr_set[dev][m->variant][in_mode][out_mode];
+    const bool known = dev >= 0 && dev < kMaxDev && attr_set[dev][m->variant][use16][in_mode][out_mode];
     if (!known) {
-      RTXN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)v.lds));
-      if (dev >= 0 && dev < kMaxDev) attr_set[dev][m->variant][in_mode][out_mode] = true;
+      RTXN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      if (dev >= 0 && dev < kMaxDev) attr_set[dev][m->variant][use16][in_mode][out_mode] = true;
     }
   }
-  hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3((unsigned)v.threads), v.lds, s, a);
+  hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3((unsigned)v.threads), lds, s, a);
   RTXN_LAUNCH_CHECK("mlp_fwd_kernel");
   return RTXN_OK;
 }
@@ -998,6 +1466,16 @@ extern "C" int rtxn_mlp_create(const rtxn_mlp_config* cfg, rtxn_mlp** out) {
   m->n_params = W * E + (L - 1) * W * W + 16 * W;
   const long RT = W / 32, KS = W / 16;
   m->packed_bytes = variant >= 0 ? (size_t)((m->k0 / 16) * RT + (L - 1) * KS * RT + KS) * 1024 : 0;
+  // MFMA shape of the fused inference kernel: 16x16x32 where the variant has it, unless RTXN_MFMA_SHAPE=32 asks for the
+  // 32x32x16 kernel (kept for A/B runs and for the per-segment compositor epilogue); read when the model is created
+  m->mfma16 = 0;
+  m->packed16 = nullptr;
+  m->packed16_bytes = 0;
+  if (variant >= 0 && vs[variant].k0_16 > 0) {
+    const char* shape = getenv("RTXN_MFMA_SHAPE");
+    m->mfma16 = !(shape && atoi(shape) == 32);
+    m->packed16_bytes = (size_t)((vs[variant].k0_16 / 32) * (W / 16) + (L - 1) * (W / 32) * (W / 16) + 4 * (W / 32)) * 1024;
+  }
   m->packed_train_bytes = (size_t)((E / 16) * RT + (L - 1) * KS * RT + KS) * 1024;
   m->packed_t_bytes = (size_t)(RT + (L - 1) * RT * KS + ((E + 31) / 32) * KS) * 1024;
   m->packed = m->packed_train = m->packed_t = nullptr;
@@ -1010,6 +1488,7 @@ extern "C" int rtxn_mlp_destroy(rtxn_mlp* m) {
   if (m->packed) (void)hipFree(m->packed);
   if (m->packed_train) (void)hipFree(m->packed_train);
   if (m->packed_t) (void)hipFree(m->packed_t);
+  if (m->packed16) (void)hipFree(m->packed16);
   delete m;
   return RTXN_OK;
 }
@@ -1056,6 +1535,17 @@ extern "C" int rtxn_mlp_set_params(rtxn_mlp* m, const void* params_fp16, rtxn_st
                                                              static_cast<_Float16*>(dst[mode]), m->cfg.n_neurons,
                                                              m->enc_padded, m->k0, m->cfg.n_hidden_layers, mode);
     RTXN_LAUNCH_CHECK("pack_kernel");
+  }
+  if (m->packed16_bytes) {
+    if (!m->packed16) RTXN_HIP(hipMalloc(&m->packed16, m->packed16_bytes));
+    const long total = (long)(m->packed16_bytes / 2);
+    const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+    const Enc16Dims d{m->cfg.n_pos_dims, m->cfg.n_pos_freqs, m->cfg.n_dir_dims, m->cfg.n_dir_freqs, m->enc_padded,
+                      variants()[m->variant].k0_16};
+    pack16_kernel<<<blocks, 256, 0, rtxn::as_stream(stream)>>>(static_cast<const _Float16*>(params_fp16),
+                                                               static_cast<_Float16*>(m->packed16), m->cfg.n_neurons,
+                                                               m->cfg.n_hidden_layers, d);
+    RTXN_LAUNCH_CHECK("pack16_kernel");
   }
   return RTXN_OK;
 }

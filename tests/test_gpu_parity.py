@@ -310,6 +310,14 @@ def test_volrender_nerf_mode(gpu, oracle):
 
 
 # ------------------------------------------------------------------ MLP
+@pytest.fixture(params=["16", "32"])
+def mfma_shape(request, monkeypatch):
+    """Both fused inference kernels: mlp_fwd16_kernel (v_mfma_f32_16x16x32_f16, the default) and mlp_fwd_kernel
+    (32x32x16); rtxn_mlp_create reads the switch.  The 256-wide model has one kernel and ignores it."""
+    monkeypatch.setenv("RTXN_MFMA_SHAPE", request.param)
+    return request.param
+
+
 def _mlp_case(oracle, W, nh, n, seed, dir_freqs=12):
     cfg = oracle.mlp_cfg(n_neurons=W, n_hidden_layers=nh, n_dir_freqs=dir_freqs)
     params = scenes.xavier_params_fp16(W, nh, oracle.mlp_enc_padded(cfg), seed=seed)
@@ -322,7 +330,7 @@ def _mlp_case(oracle, W, nh, n, seed, dir_freqs=12):
 @pytest.mark.parametrize("W,nh,n,dir_freqs", [(128, 8, 1000, 12), (64, 2, 777, 12), (128, 1, 256, 12), (64, 4, 3, 12),
                                               (128, 3, 515, 4), (64, 3, 300, 4), (256, 8, 900, 12), (256, 1, 33, 12),
                                               (256, 2, 256, 12), (256, 3, 2500, 12)])
-def test_mlp_forward_half_output(gpu, oracle, W, nh, n, dir_freqs):
+def test_mlp_forward_half_output(gpu, oracle, W, nh, n, dir_freqs, mfma_shape):
     torch = gpu
     from rtx_nerf_amd import api
     cfg, params, x = _mlp_case(oracle, W, nh, n, seed=W + nh, dir_freqs=dir_freqs)
@@ -340,7 +348,7 @@ def test_mlp_forward_half_output(gpu, oracle, W, nh, n, dir_freqs):
     assert want[:, :4].std() > 0.01
 
 
-def test_mlp_forward_radiance_and_no_activation(gpu, oracle):
+def test_mlp_forward_radiance_and_no_activation(gpu, oracle, mfma_shape):
     torch = gpu
     from rtx_nerf_amd import api
     cfg, params, x = _mlp_case(oracle, 128, 8, 2049, seed=5)
@@ -359,7 +367,7 @@ def test_mlp_forward_radiance_and_no_activation(gpu, oracle):
     np.testing.assert_allclose(out, want2, rtol=0, atol=2e-2)
 
 
-def test_mlp_identity_weights_expose_layouts(gpu, oracle):
+def test_mlp_identity_weights_expose_layouts(gpu, oracle, mfma_shape):
     """Structured weights (one 1.0 per row at an asymmetric position) make the output an exact copy
     of chosen encoding features: catches any transposed/permuted MFMA fragment map outright."""
     torch = gpu
@@ -397,8 +405,8 @@ def test_mlp_identity_weights_expose_layouts(gpu, oracle):
     assert len(set(src.tolist())) > 8 and want.std() > 0.1
 
 
-@pytest.mark.parametrize("W", [128, 256])
-def test_mlp_forward_segments_equals_sampler_plus_forward(gpu, oracle, W):
+@pytest.mark.parametrize("W", [64, 128, 256])
+def test_mlp_forward_segments_equals_sampler_plus_forward(gpu, oracle, W, mfma_shape):
     torch = gpu
     from rtx_nerf_amd import api
     rng = np.random.default_rng(4)
@@ -509,9 +517,10 @@ def test_config5_forward_facing_256_grid_8x256(gpu, oracle):
 
 
 @pytest.mark.parametrize("W", [64, 128, 256])
-def test_fused_compositor_equals_staged_and_oracle(gpu, oracle, W):
+def test_fused_compositor_equals_staged_and_oracle(gpu, oracle, W, monkeypatch):
     """The per-segment compositing epilogue + per-ray combine == per-sample radiance + launch_volrender_cuda
     (COMPAT), both == the oracle; NERF mode == midpoint sampler + forward + NERF volume render."""
+    monkeypatch.setenv("RTXN_MFMA_SHAPE", "32")   # the epilogue exists in the 32x32x16 kernel only: "same arithmetic" needs both sides on it
     torch = gpu
     from rtx_nerf_amd import api, render
     R, Wd, H = 32, 40, 30
