@@ -399,7 +399,10 @@ def main():
         if ms:
             ach = flops * smp / (ms * 1e-3) / 1e12
             out["roofline"] = {
-                "kernel": f"mlp_fwd_kernel<{args.neurons},3,10,2,12,segments,{'segment-composite' if args.fused else ('half4' if pipe.compact else 'radiance')}>",
+                "kernel": (f"mlp_fwd16_kernel<{args.neurons},3,10,2,12,segments," if net.mfma_shape() == 16 and not args.fused
+                           else f"mlp_fwd{'256' if args.neurons == 256 else ''}_kernel<{args.neurons},3,10,2,12,segments,")
+                          + f"{'segment-composite' if args.fused else ('half4' if pipe.compact else 'radiance')}>",
+                "mfma": "v_mfma_f32_16x16x32_f16" if net.mfma_shape() == 16 and not args.fused else "v_mfma_f32_32x32x16_f16",
                 "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": pmc_traffic(smp),
                 "flop_per_sample": flops, "samples_per_launch": smp, "kernel_ms": round(ms, 4),

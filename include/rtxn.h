@@ -223,6 +223,10 @@ int rtxn_mlp_destroy(rtxn_mlp* m);
  * co-resides only if it fits the CU's left-over registers/LDS (this library's traversal, scan and compositor kernels do);
  * a collective library's kernels may not.  n_cus > 0 keeps that many CUs free of MLP blocks (default 0). */
 int rtxn_mlp_set_reserved_cus(rtxn_mlp* m, int n_cus);
+/* Which fused inference kernel the model runs: 16 = mlp_fwd16_kernel (v_mfma_f32_16x16x32_f16, the default for the 64- and
+ * 128-wide models), 32 = the 32x32x16 kernels (the 256-wide model; the per-segment compositor epilogue; or any model
+ * created while the environment has RTXN_MFMA_SHAPE=32, the A/B switch); 0 = no fused inference kernel (RTXN_ENC_EXTERNAL). */
+int rtxn_mlp_mfma_shape(const rtxn_mlp* m);
 long rtxn_mlp_n_params(const rtxn_mlp* m);
 int rtxn_mlp_padded_output_width(const rtxn_mlp* m); /* 16 (main.cu:715) */
 int rtxn_mlp_encoded_width(const rtxn_mlp* m);       /* padded to a multiple of 16 */

@@ -100,6 +100,7 @@ SYMBOLS = {
     "rtxn_mlp_n_params": (_L, [_P]),
     "rtxn_mlp_padded_output_width": (_I, [_P]),
     "rtxn_mlp_set_reserved_cus": (_I, [_P, _I]),
+    "rtxn_mlp_mfma_shape": (_I, [_P]),
     "rtxn_mlp_encoded_width": (_I, [_P]),
     "rtxn_mlp_initialize_params": (_I, [_P, C.c_uint64, _P]),
     "rtxn_mlp_set_params": (_I, [_P, _P, _P]),

@@ -208,6 +208,10 @@ class Network:
     def encoded_width(self):
         return int(_lib.lib().rtxn_mlp_encoded_width(self._h))
 
+    def mfma_shape(self):
+        """16: mlp_fwd16_kernel (v_mfma_f32_16x16x32_f16); 32: the 32x32x16 kernels; 0: no fused inference kernel."""
+        return int(_lib.lib().rtxn_mlp_mfma_shape(self._h))
+
     def flops_per_sample(self):
         w, p, nh = self.cfg.n_neurons, self.encoded_width(), self.cfg.n_hidden_layers
         return 2 * (p * w + (nh - 1) * w * w + 16 * w)

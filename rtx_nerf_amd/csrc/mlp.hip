@@ -1500,6 +1500,11 @@ extern "C" int rtxn_mlp_set_reserved_cus(rtxn_mlp* m, int n_cus) {
   return RTXN_OK;
 }
 
+extern "C" int rtxn_mlp_mfma_shape(const rtxn_mlp* m) {
+  if (!m || m->variant < 0) return 0;
+  return m->mfma16 ? 16 : 32;
+}
+
 extern "C" long rtxn_mlp_n_params(const rtxn_mlp* m) { return m ? m->n_params : -1; }
 extern "C" int rtxn_mlp_padded_output_width(const rtxn_mlp* m) { return m ? 16 : -1; }
 extern "C" int rtxn_mlp_encoded_width(const rtxn_mlp* m) { return m ? m->enc_padded : -1; }
