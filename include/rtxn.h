@@ -301,6 +301,11 @@ int rtxn_hashgrid_create(const rtxn_hashgrid_config* cfg, rtxn_hashgrid** out);
 int rtxn_hashgrid_destroy(rtxn_hashgrid* g);
 long rtxn_hashgrid_n_params(const rtxn_hashgrid* g);                 /* fp16 table entries */
 int rtxn_hashgrid_encoded_width(const rtxn_hashgrid* g, int n_dir_freqs);
+/* Table layout for callers that treat levels differently (the data-parallel gradient exchange): offset of a level in
+ * PARAMETERS (entries x n_features; level == n_levels gives the total), and whether the level is hashed (its dense size
+ * exceeds 2^log2_hashmap_size) or stored densely.  Dense levels come first. */
+long rtxn_hashgrid_level_offset(const rtxn_hashgrid* g, int level);
+int rtxn_hashgrid_level_is_hashed(const rtxn_hashgrid* g, int level);
 int rtxn_hashgrid_encode(const rtxn_hashgrid* g, int n_dir_freqs, const void* table_fp16, const float* input,
                          void* encT, long n_samples, rtxn_stream_t stream);
 /* dtable (fp32, table layout) += scatter of dencT; the caller zeroes dtable per step. */
@@ -327,6 +332,11 @@ int rtxn_l2_loss(const float* pred, const float* target, long n, float loss_scal
 /* optimizer->step (tcnn "Adam", main.cu:40-46,787): fp32 master weights + fp16 copy, fp32 gradients. */
 int rtxn_adam_step(long n, float* master, void* params_fp16, const float* grads, float* m, float* v, int step,
                    float lr, float beta1, float beta2, float eps, float loss_scale, rtxn_stream_t stream);
+
+/* fp32 <-> fp16 copies of a gradient block on the device (no counterpart in the reference, which is single-GPU): the
+ * data-parallel exchange sends the hashed levels' gradient in fp16 -- tiny-cuda-nn holds that gradient in fp16 throughout. */
+int rtxn_convert_f32_to_f16(const float* src, void* dst_half, long n, rtxn_stream_t stream);
+int rtxn_convert_f16_to_f32(const void* src_half, float* dst, long n, rtxn_stream_t stream);
 
 /* ---- dataset loader (host only) ------------------------------------------------------- */
 /* Replaces load_images_json (loader/data_loader.cpp:34-94; jsoncpp + stb_image's stbi_loadf).

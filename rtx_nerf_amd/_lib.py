@@ -117,6 +117,10 @@ SYMBOLS = {
     "rtxn_hashgrid_destroy": (_I, [_P]),
     "rtxn_hashgrid_n_params": (_L, [_P]),
     "rtxn_hashgrid_encoded_width": (_I, [_P, _I]),
+    "rtxn_hashgrid_level_offset": (_L, [_P, _I]),
+    "rtxn_hashgrid_level_is_hashed": (_I, [_P, _I]),
+    "rtxn_convert_f32_to_f16": (_I, [_P, _P, _L, _P]),
+    "rtxn_convert_f16_to_f32": (_I, [_P, _P, _L, _P]),
     "rtxn_hashgrid_encode": (_I, [_P, _I, _P, _P, _P, _L, _P]),
     "rtxn_hashgrid_backward": (_I, [_P, _P, _P, _L, _P, _P]),
     "rtxn_mlp_train_workspace_bytes": (C.c_size_t, [_P, _L]),

@@ -329,6 +329,17 @@ class HashGrid:
     def encoded_width(self):
         return int(_lib.lib().rtxn_hashgrid_encoded_width(self._h, self.n_dir_freqs))
 
+    def level_offset(self, level):
+        """Offset of `level` in table parameters (entries x features); level == n_levels: the total."""
+        return int(_lib.lib().rtxn_hashgrid_level_offset(self._h, level))
+
+    def hashed_offset(self):
+        """Parameters before the first hashed level: the leading, densely stored levels (a few hundred KB)."""
+        for l in range(self.cfg.n_levels):
+            if _lib.lib().rtxn_hashgrid_level_is_hashed(self._h, l):
+                return self.level_offset(l)
+        return self.n_params()
+
     def encode(self, table_fp16, inputs, encT=None):
         n = inputs.numel() // 5
         if encT is None:
@@ -400,3 +411,13 @@ def adam_step(master, params_fp16, grads, m, v, step, lr=1e-3, beta1=0.9, beta2=
                                     _ptr(params_fp16, torch.float16, "params"), _ptr(grads, torch.float32, "grads"),
                                     _ptr(m, torch.float32, "m"), _ptr(v, torch.float32, "v"), step, lr, beta1, beta2, eps,
                                     loss_scale, _stream()), "rtxn_adam_step")
+
+
+def convert_f32_to_f16(src, dst):
+    check(_lib.lib().rtxn_convert_f32_to_f16(_ptr(src, torch.float32, "src"), _ptr(dst, torch.float16, "dst"), src.numel(), _stream()),
+          "rtxn_convert_f32_to_f16")
+
+
+def convert_f16_to_f32(src, dst):
+    check(_lib.lib().rtxn_convert_f16_to_f32(_ptr(src, torch.float16, "src"), _ptr(dst, torch.float32, "dst"), src.numel(), _stream()),
+          "rtxn_convert_f16_to_f32")

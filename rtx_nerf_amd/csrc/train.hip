@@ -757,6 +757,29 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(long n, float* __restric
   }
 }
 
+// fp32 <-> fp16 copies of a gradient block (8 elements per thread): the data-parallel exchange of the hashed levels' gradient
+// travels in fp16 (tcnn keeps that gradient in fp16 to begin with), see rtx_nerf_amd/train.py
+__global__ __launch_bounds__(kThreads) void f32_to_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, long n) {
+  const long i = ((long)blockIdx.x * kThreads + threadIdx.x) * 8;
+  if (i + 8 <= n && ((uintptr_t)(src + i) & 15) == 0 && ((uintptr_t)(dst + i) & 15) == 0) {
+    const float4 a = *reinterpret_cast<const float4*>(src + i), b = *reinterpret_cast<const float4*>(src + i + 4);
+    half8 o = {(_Float16)a.x, (_Float16)a.y, (_Float16)a.z, (_Float16)a.w, (_Float16)b.x, (_Float16)b.y, (_Float16)b.z, (_Float16)b.w};
+    *reinterpret_cast<half8*>(dst + i) = o;
+  } else {
+    for (long k = i; k < n && k < i + 8; ++k) dst[k] = (_Float16)src[k];
+  }
+}
+__global__ __launch_bounds__(kThreads) void f16_to_f32_kernel(const _Float16* __restrict__ src, float* __restrict__ dst, long n) {
+  const long i = ((long)blockIdx.x * kThreads + threadIdx.x) * 8;
+  if (i + 8 <= n && ((uintptr_t)(src + i) & 15) == 0 && ((uintptr_t)(dst + i) & 15) == 0) {
+    const half8 v = *reinterpret_cast<const half8*>(src + i);
+    *reinterpret_cast<float4*>(dst + i) = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+    *reinterpret_cast<float4*>(dst + i + 4) = make_float4((float)v[4], (float)v[5], (float)v[6], (float)v[7]);
+  } else {
+    for (long k = i; k < n && k < i + 8; ++k) dst[k] = (float)src[k];
+  }
+}
+
 int check_train(const rtxn_mlp* m, const char* who) {
   if (!m) { rtxn::set_error("%s: NULL model", who); return RTXN_ERR_INVALID; }
   if (m->cfg.n_neurons != 64 && m->cfg.n_neurons != 128) {
@@ -944,6 +967,40 @@ extern "C" int rtxn_hashgrid_create(const rtxn_hashgrid_config* cfg, rtxn_hashgr
 }
 
 extern "C" int rtxn_hashgrid_destroy(rtxn_hashgrid* g) { delete g; return RTXN_OK; }
+
+extern "C" long rtxn_hashgrid_level_offset(const rtxn_hashgrid* g, int level) {
+  if (!g || level < 0 || level > g->cfg.n_levels) return -1;
+  if (level == g->cfg.n_levels) return g->n_params;
+  return (long)g->offset[level] * g->cfg.n_features;
+}
+
+extern "C" int rtxn_hashgrid_level_is_hashed(const rtxn_hashgrid* g, int level) {
+  if (!g || level < 0 || level >= g->cfg.n_levels) return -1;
+  const unsigned long long r = g->res[level];
+  return r * r * r > (unsigned long long)g->size[level] ? 1 : 0;
+}
+
+extern "C" int rtxn_convert_f32_to_f16(const float* src, void* dst_half, long n, rtxn_stream_t stream) {
+  RTXN_REQUIRE(n >= 0, "rtxn_convert_f32_to_f16: n = %ld < 0", n);
+  RTXN_DEVICE_OR_FAIL();
+  if (n == 0) return RTXN_OK;
+  RTXN_REQUIRE(src && dst_half, "rtxn_convert_f32_to_f16: NULL buffer");
+  f32_to_f16_kernel<<<(unsigned)((n + 8L * kThreads - 1) / (8L * kThreads)), kThreads, 0, rtxn::as_stream(stream)>>>(
+      src, static_cast<_Float16*>(dst_half), n);
+  RTXN_LAUNCH_CHECK("f32_to_f16_kernel");
+  return RTXN_OK;
+}
+
+extern "C" int rtxn_convert_f16_to_f32(const void* src_half, float* dst, long n, rtxn_stream_t stream) {
+  RTXN_REQUIRE(n >= 0, "rtxn_convert_f16_to_f32: n = %ld < 0", n);
+  RTXN_DEVICE_OR_FAIL();
+  if (n == 0) return RTXN_OK;
+  RTXN_REQUIRE(src_half && dst, "rtxn_convert_f16_to_f32: NULL buffer");
+  f16_to_f32_kernel<<<(unsigned)((n + 8L * kThreads - 1) / (8L * kThreads)), kThreads, 0, rtxn::as_stream(stream)>>>(
+      static_cast<const _Float16*>(src_half), dst, n);
+  RTXN_LAUNCH_CHECK("f16_to_f32_kernel");
+  return RTXN_OK;
+}
 extern "C" long rtxn_hashgrid_n_params(const rtxn_hashgrid* g) { return g ? g->n_params : -1; }
 extern "C" int rtxn_hashgrid_encoded_width(const rtxn_hashgrid* g, int n_dir_freqs) {
   if (!g || n_dir_freqs < 0) return -1;

@@ -82,6 +82,23 @@ def test_data_parallel_equals_single_process(gpu, tmp_path):
     assert np.median(np.abs(pa - pb)) < 1e-4 and (np.abs(pa - pb) < 1e-2).mean() > 0.97
 
 
+def test_data_parallel_rank_without_samples_keeps_in_step(gpu, tmp_path):
+    """a rank whose rays all miss the grid used to return before the gradient all-reduce (the others then hung)
+    with its Adam step index out of line.  Rank 1 of 2 gets only missing rays in every step: both ranks must finish, with
+    equal step counts and bit-identical parameters, and match one process training on the same global batches."""
+    env = dict(os.environ, RTXN_REHEARSE_ON_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    ref, dp = str(tmp_path / "ref.npy"), str(tmp_path / "dp.npy")
+    tool = os.path.join(ROOT, "tools", "train_dp_check.py")
+    subprocess.check_call([sys.executable, tool, "--out", ref, "--empty-odd", "--steps", "3"], env=env, timeout=600)
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                           "--master-addr", "127.0.0.1", "--master-port", "29541", tool, "--out", dp, "--empty-odd", "--steps", "3"],
+                          env=env, timeout=600)     # a deadlock shows up as this timeout
+    a, b = np.load(ref), np.load(dp)
+    ga, gb = a[0], b[0]
+    assert np.abs(ga).max() > 0 and np.isfinite(b).all()
+    assert np.linalg.norm(ga - gb) < 1e-2 * np.linalg.norm(ga)
+
+
 @pytest.mark.gpu
 def test_pipelined_frames_equal_serial_frames(gpu):
     """render_async (three streams, two buffer slots, frames overlapping) must produce exactly the frames render() does."""

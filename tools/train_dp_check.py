@@ -17,12 +17,14 @@ from rtx_nerf_amd import scenes
 from rtx_nerf_amd.train import Trainer, camera_rays
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from train_demo import teacher_field
+teacher_field = scenes.teacher_field
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--out", required=True)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--encoding", default="hash")
+ap.add_argument("--empty-odd", action="store_true", help="every odd ray of the global batch (= all of rank 1's share in a 2-rank run) "
+                "points away from the grid: that rank has NO samples and must still take part in every collective and Adam step")
 a = ap.parse_args()
 rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 rehearse = os.environ.get("RTXN_REHEARSE_ON_ONE_GPU") == "1"
@@ -43,10 +45,20 @@ g = torch.Generator().manual_seed(1)
 for it in range(a.steps):
     idx = torch.randint(0, o.shape[0], (B,), generator=g).cuda()       # the same global batch on every rank
     mine = idx[rank::world].contiguous()                                # this rank's share
-    tr.step(o[mine].contiguous(), d[mine].contiguous(), tgt[mine].contiguous())
+    dm = d[mine].contiguous()
+    if a.empty_odd:
+        odd = (torch.arange(mine.numel(), device="cuda") * world + rank) % 2 == 1   # position in the GLOBAL batch
+        dm[odd] = -dm[odd]
+    tr.step(o[mine].contiguous(), dm, tgt[mine].contiguous())
     if it == 0:   # gradients of the first step (summed over ranks -> mean), before Adam's normalisation amplifies noise
         g0 = torch.cat([tr.dparams, tr.dtable if a.encoding == "hash" else tr.dparams[:0]]).cpu().numpy() / world
 torch.cuda.synchronize()
+assert tr.step_count == a.steps, (rank, tr.step_count)                  # every rank ran Adam in every step
+if world > 1:                                                           # ... and they all hold the same parameters
+    mine_p = tr.master.clone()
+    ref_p = mine_p.clone()
+    dist.broadcast(ref_p, src=0)
+    assert torch.equal(mine_p, ref_p), f"rank {rank}: parameters diverged from rank 0"
 if rank == 0:
     np.save(a.out, np.stack([g0, np.concatenate([tr.master.cpu().numpy(),
                                                  tr.table_master.cpu().numpy() if a.encoding == "hash" else []])]))
