@@ -325,6 +325,19 @@ int rtxn_mlp_train_forward(const rtxn_mlp* m, const void* encT, long n_samples, 
 int rtxn_mlp_train_backward(const rtxn_mlp* m, const void* encT, const void* output_half, const void* dout_half4,
                             long n_samples, void* workspace, float* dparams, void* dencT, rtxn_stream_t stream);
 
+/* Recompute path for models whose whole gradient fits on the chip (64 wide, <= 4 hidden layers, encoded width <= 64:
+ * BASELINE configs[2]).  network->forward (main.cu:721) WITHOUT saved activations, and network->backward (main.cu:781) as ONE
+ * kernel that rebuilds the activations in registers from encT, runs the dgrad chain and accumulates every layer's weight
+ * gradient on the chip (LDS-transposed operands, one pass of atomics per wave): no per-sample, per-layer tensor touches HBM
+ * and no workspace is needed.  Same results as rtxn_mlp_train_forward + rtxn_mlp_train_backward up to fp32 summation order.
+ * rtxn_mlp_train_recompute_supported: 1 if this model can use the pair, else 0 (backward_recompute then returns
+ * RTXN_ERR_UNSUPPORTED; forward_outputs works for every trainable width). */
+int rtxn_mlp_train_recompute_supported(const rtxn_mlp* m);
+int rtxn_mlp_train_forward_outputs(const rtxn_mlp* m, const void* encT, long n_samples, void* output_half, float* radiance,
+                                   rtxn_stream_t stream);
+int rtxn_mlp_train_backward_recompute(const rtxn_mlp* m, const void* encT, const void* output_half, const void* dout_half4,
+                                      long n_samples, float* dparams, void* dencT, rtxn_stream_t stream);
+
 /* loss->evaluate (tcnn "L2", main.cu:36-38,759): values[i] = d^2/n, grads[i] = loss_scale*2d/n (half),
  * *loss_sum (device float) = sum of values.  values/grads/loss_sum may each be NULL. */
 int rtxn_l2_loss(const float* pred, const float* target, long n, float loss_scale, float* values, void* grads_half,

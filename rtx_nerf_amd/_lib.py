@@ -126,6 +126,9 @@ SYMBOLS = {
     "rtxn_mlp_train_workspace_bytes": (C.c_size_t, [_P, _L]),
     "rtxn_mlp_train_forward": (_I, [_P, _P, _L, _P, _P, _P, _P]),
     "rtxn_mlp_train_backward": (_I, [_P, _P, _P, _P, _L, _P, _P, _P, _P]),
+    "rtxn_mlp_train_recompute_supported": (_I, [_P]),
+    "rtxn_mlp_train_forward_outputs": (_I, [_P, _P, _L, _P, _P, _P]),
+    "rtxn_mlp_train_backward_recompute": (_I, [_P, _P, _P, _P, _L, _P, _P, _P]),
     "rtxn_l2_loss": (_I, [_P, _P, _L, _F, _P, _P, _P, _P]),
     "rtxn_adam_step": (_I, [_L, _P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _P]),
     "rtxn_load_images_json": (_I, [C.c_char_p, C.c_char_p, _I, C.POINTER(ImageDataset)]),

@@ -391,6 +391,33 @@ def _net_train_backward(self, encT, output, dout, n, workspace, dparams, dencT=N
     return dparams
 
 
+def _net_recompute_supported(self):
+    """True for models whose backward can run as the fused recompute kernel (64 wide, <= 4 layers, encoded width <= 64)."""
+    return bool(_lib.lib().rtxn_mlp_train_recompute_supported(self._h))
+
+
+def _net_train_forward_outputs(self, encT, n, output=None, radiance=None):
+    """network->forward without saved activations (the forward half of the recompute path)."""
+    if output is None:
+        output = torch.empty((n, 16), dtype=torch.float16, device=encT.device)
+    check(_lib.lib().rtxn_mlp_train_forward_outputs(self._h, _ptr(encT, torch.float16, "encT"), n, _ptr(output, torch.float16),
+                                                    _ptr(radiance, torch.float32, "radiance"), _stream()),
+          "rtxn_mlp_train_forward_outputs")
+    return output
+
+
+def _net_train_backward_recompute(self, encT, output, dout, n, dparams, dencT=None):
+    """network->backward as one kernel: activations rebuilt from encT, every weight gradient accumulated on the chip."""
+    check(_lib.lib().rtxn_mlp_train_backward_recompute(self._h, _ptr(encT, torch.float16, "encT"), _ptr(output, torch.float16, "output"),
+                                                       _ptr(dout, torch.float16, "dout"), n, _ptr(dparams, torch.float32, "dparams"),
+                                                       _ptr(dencT, torch.float16, "dencT"), _stream()),
+          "rtxn_mlp_train_backward_recompute")
+    return dparams
+
+
+Network.recompute_supported = _net_recompute_supported
+Network.train_forward_outputs = _net_train_forward_outputs
+Network.train_backward_recompute = _net_train_backward_recompute
 Network.encode_frequency = _net_encode_frequency
 Network.train_workspace = _net_train_workspace
 Network.train_forward = _net_train_forward

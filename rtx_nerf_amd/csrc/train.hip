@@ -261,7 +261,9 @@ __device__ __forceinline__ const _Float16* row_elem(const _Float16* X, int f0, l
   return reinterpret_cast<const _Float16*>(reinterpret_cast<const char*>(X + (long)f0 * Sp) + lane_off);
 }
 
-template <int W>
+// SAVE = false: outputs only (no activations, no masks): the forward half of the recompute path, whose backward
+// (mlp_bwd_fused64_kernel) rebuilds the activations in registers from the encoded input.
+template <int W, bool SAVE = true>
 __global__ __launch_bounds__(kThreads, 2) void mlp_train_fwd_kernel(TrainArgs a) {
   constexpr int RT = W / 32, KS = W / 16;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -314,6 +316,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_train_fwd_kernel(TrainArgs a)
     off += (long)KS0 * RT * 1024;
   }
   auto save_acts = [&](int l, const half8 (&v)[KS][2]) {
+    if constexpr (!SAVE) return;
     _Float16* dst = a.acts + (long)l * W * a.Sp;
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk)
@@ -564,6 +567,323 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_bwd_kernel(TrainArgs a) {
         const int feat0 = 32 * rt + (e & 3) + 8 * (e >> 2);
         if (feat0 + 4 * h < a.E) *row_elem(a.dencT, feat0, a.Sp, lane_off[ct]) = ok ? (_Float16)acc[ct][e] : (_Float16)0.0f;
       }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------- fused backward, 64-wide models
+// network->backward for models whose whole gradient fits on the chip (64 wide, <= 4 hidden layers, encoded width <= 64:
+// BASELINE configs[2], hash grid + 4x64).  The separate kernels above move every layer's activations and dZ through HBM
+// three times (forward writes the activations, the dgrad chain reads them and writes dZ, the weight-gradient GEMM reads
+// both): 2 x 2 B x W per sample and layer, which is what bounded them.  Here NOTHING per-sample and per-layer touches
+// memory:
+//   * the forward is RECOMPUTED from the encoded input (48-64 features per sample, read once) with the activations of all
+//     layers kept in registers as the B fragments they already are -- the MFMA work is a few percent of the old kernels'
+//     memory time;
+//   * the dgrad chain runs in registers as before (accumulator -> next B operand);
+//   * the weight gradient dW_l = dZ_l X_l^T contracts over SAMPLES, the lane index of those fragments, so each wave drops its
+//     dZ_l / X_l tile into a [sample][feature] LDS image (136-byte rows) and the operands come back through
+//     ds_read_b64_tr_b16, the hardware-transposing LDS read (probe: tools/probe/tr_probe.hip).  Wave w of the block owns
+//     quadrant (w >> 1, w & 1) of every layer's 64x64 gradient and accumulates it in registers over ALL the block's samples
+//     and over all its tiles (persistent grid); one pass of fp32 atomics per wave at the very end;
+//   * all weights, forward-packed and transposed, are staged in LDS once per block (64-68 KiB) and stay.
+// One wave per SIMD (the register file holds 4 layers of activations, 5 gradient quadrants and the chain's fragments:
+// <= 512 VGPRs), 4 waves per block, one block per CU.
+constexpr int kImgStride = 136;                 // bytes per sample row of an image: 64 features x 2 B + 8 (ds_write banks)
+constexpr int kImgBytes = 64 * kImgStride;
+constexpr int kFusedMaxL = 4;
+
+struct FusedArgs {
+  const uint8_t* packed_fwd;   // packed_train: layers 0 .. L-1 (the output layer is not recomputed)
+  const uint8_t* packed_t;     // transposed layers in backward order: out, L-1, ..., 1, 0
+  int L, KS0, out_act, E;
+  long S, Sp;
+  int n_tiles;                 // 256-sample block tiles
+  const _Float16* encT;        // [E][Sp]
+  const _Float16* out_half;    // [S][16]
+  const _Float16* dout;        // [S][4]
+  _Float16* dencT;             // [E][Sp] or NULL
+  float* dparams;              // tcnn layout, accumulated into
+};
+
+typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+
+// A/B operand of v_mfma_f32_32x32x16_f16 for a product that sums over SAMPLES: lane (r = l & 31, hh = l >> 5) gets
+// image[sample 16 ks + 8 hh + j][feature 32 t + r], j = 0..7, as two transposing reads of 4 samples x 16 features per
+// 16-lane group.  lane_tr = this lane's fixed part of the address (see the kernel).
+__device__ __forceinline__ half8 tr_operand(const uint8_t* image, unsigned lane_tr, int t, int ks) {
+  const uint8_t* p = image + lane_tr + (16 * ks) * kImgStride + 64 * t;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * kImgStride));
+  const half4v l4 = __builtin_bit_cast(half4v, lo), h4 = __builtin_bit_cast(half4v, hi);
+  return __builtin_shufflevector(l4, h4, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ __launch_bounds__(kThreads, 1) void mlp_bwd_fused64_kernel(FusedArgs a) {
+  constexpr int W = 64, RT = 2, KS = 4;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int L = a.L, KS0 = a.KS0;
+  const int rt_e = (a.E + 31) / 32;
+  const int fwd_bytes = (KS0 * RT + (L - 1) * KS * RT) * 1024;
+  const int t_bytes = (RT + (L - 1) * RT * KS + rt_e * KS) * 1024;
+  uint8_t* wF = smem;
+  uint8_t* wT = smem + fwd_bytes;
+  uint8_t* img = wT + t_bytes;                         // [wave][0: dZ | 1: X][kImgBytes]
+  stage_rt(a.packed_fwd, wF, fwd_bytes, tid);
+  stage_rt(a.packed_t, wT, t_bytes, tid);
+  rtxn::staged_barrier();
+  uint8_t* my_dz = img + (wave * 2) * kImgBytes;
+  uint8_t* my_x = my_dz + kImgBytes;
+  const int rt_w = wave >> 1, ct_w = wave & 1;         // this wave's quadrant of every layer's gradient
+  // transposing-read address, fixed part: within a 16-lane group lane 4q+p supplies row q (a sample), columns 4p..4p+3
+  // (features); groups 0/1 take features 0-15 / 16-31 of the 32-wide tile, lane half h the upper 8 samples of the k-step
+  const unsigned lane_tr = (unsigned)((8 * h + ((lane & 15) >> 2)) * kImgStride + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2);
+  // image store address, fixed part: sample (ct 32 + col) row, features 4h.. of a 16-feature k-step group
+  const unsigned lane_wr = (unsigned)(col * kImgStride + 8 * h);
+
+  floatx16 acc[kFusedMaxL], accL;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) accL[e] = 0.0f;
+#pragma unroll
+  for (int l = 0; l < kFusedMaxL; ++l)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[l][e] = 0.0f;
+
+  auto write_frag = [&](uint8_t* image, int kk, int ct, const half8& v) {
+    uint8_t* p = image + lane_wr + ct * 32 * kImgStride + kk * 32;
+    *reinterpret_cast<half4v*>(p) = __builtin_shufflevector(v, v, 0, 1, 2, 3);            // features 16kk + 4h + 0..3
+    *reinterpret_cast<half4v*>(p + 16) = __builtin_shufflevector(v, v, 4, 5, 6, 7);       // features 16kk + 8 + 4h + 0..3
+  };
+  auto wgrad = [&](floatx16& q, int a_tile, int b_tile) {   // q += dZ[a_tile rows] X^T[b_tile cols] over the block's 256 samples
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const half8 af = tr_operand(img + (v * 2) * kImgBytes, lane_tr, a_tile, ks);
+        const half8 bf = tr_operand(img + (v * 2 + 1) * kImgBytes, lane_tr, b_tile, ks);
+        q = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, q, 0, 0, 0);
+      }
+  };
+
+  for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    const long tile0 = (long)tile * kTile + wave * 64;
+    unsigned lane_off[2];
+    bool ok_s[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const long sidx = tile0 + ct * 32 + col;
+      ok_s[ct] = sidx < a.S;
+      lane_off[ct] = (unsigned)((sidx + 4L * h * a.Sp) * 2);
+    }
+    // ---- encoded input as layer-0 B fragments (X_0); read again for layer 0's weight gradient (a cache hit) rather than
+    // held in 32 VGPRs through the whole backward chain ----
+    auto load_x0 = [&](half8 (&x)[KS][2]) {
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          half8 v;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.0f;
+          if (kk < KS0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = *row_elem(a.encT, perm_feature(kk, 0, j), a.Sp, lane_off[ct]);
+          }
+          x[kk][ct] = v;
+        }
+    };
+    // ---- forward, recomputed: post-ReLU activations of every hidden layer stay in registers ----
+    half8 act[kFusedMaxL][KS][2];
+    {
+      half8 x0[KS][2];
+      load_x0(x0);
+      floatx16 f[RT][2];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) f[rt][ct][e] = 0.0f;
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk)
+        if (kk < KS0) {
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) {
+            const half8 af = *reinterpret_cast<const half8*>(wF + ((rt * KS0 + kk) * 64 + lane) * 16);
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) f[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, x0[kk][ct], f[rt][ct], 0, 0, 0);
+          }
+        }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) act[0][2 * rt + s2][ct] = pack8<true>(f[rt][ct], s2);
+    }
+    int foff = KS0 * RT * 1024;
+#pragma unroll
+    for (int l = 1; l < kFusedMaxL; ++l)
+      if (l < L) {
+        layer_mma<RT, KS, KS, 2>(wF + foff, act[l - 1], act[l], lane);
+        foff += KS * RT * 1024;
+      }
+    // ---- output layer: dZ_out = dout (*) act'(out) ----
+    half8 bo[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      half8 v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.0f;
+      const long sidx = tile0 + ct * 32 + col;
+      if (ok_s[ct] && h == 0) {
+        const half4v g = *reinterpret_cast<const half4v*>(a.dout + sidx * 4);
+        const half4v y = *reinterpret_cast<const half4v*>(a.out_half + sidx * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float gg = (float)g[j];
+          if (a.out_act == RTXN_ACT_SIGMOID) { const float yy = (float)y[j]; gg = gg * yy * (1.0f - yy); }
+          v[j] = (_Float16)gg;
+        }
+      }
+      bo[ct] = v;
+    }
+    half8 zero8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) zero8[j] = (_Float16)0.0f;
+
+    // dZ_l (accumulator tile rt of W_{l+1}^T dZ_{l+1}) masked with relu'(act) and packed as the next chain fragment
+    auto mask_pack = [&](const floatx16 (&d)[2], int rt, const half8 (&actl)[KS][2], half8 (&dst)[KS][2]) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        floatx16 m;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) m[e] = (float)actl[2 * rt + (e >> 3)][ct][e & 7] > 0.0f ? d[ct][e] : 0.0f;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) dst[2 * rt + s2][ct] = pack8<false>(m, s2);
+      }
+    };
+
+    // ---- output layer: weight gradient dW_L[16 x 64] = dZ_out act_{L-1}^T, then dZ_{L-1} ----
+    half8 bz[KS][2], bn[KS][2];
+    __syncthreads();                                   // the previous tile's last weight-gradient pass is done with the images
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      write_frag(my_dz, 0, ct, bo[ct]);                // rows 0..15 (4..15 are zero)
+      write_frag(my_dz, 1, ct, zero8);                 // rows 16..31 of the 32-row operand tile
+    }
+#pragma unroll
+    for (int l = 0; l < kFusedMaxL; ++l)
+      if (l == L - 1) {
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) write_frag(my_x, kk, ct, act[l][kk][ct]);
+      }
+    __syncthreads();
+    if (rt_w == 0) wgrad(accL, 0, ct_w);
+#pragma unroll
+    for (int l = 0; l < kFusedMaxL; ++l)
+      if (l == L - 1) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const half8 af = *reinterpret_cast<const half8*>(wT + (rt * 64 + lane) * 16);
+          floatx16 d[2];
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) {
+            floatx16 z;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) z[e] = 0.0f;
+            d[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bo[ct], z, 0, 0, 0);
+          }
+          mask_pack(d, rt, act[l], bz);
+        }
+      }
+    int toff = RT * 1024;
+    // ---- hidden layers L-1 .. 0: bz = dZ_l ----
+#pragma unroll
+    for (int li = 0; li < kFusedMaxL; ++li) {
+      const int l = kFusedMaxL - 1 - li;               // compile-time: 3, 2, 1, 0
+      if (l < L) {
+        half8 x0[KS][2];
+        if (l == 0) load_x0(x0);                       // issued before the barrier: in flight while the others catch up
+        __syncthreads();                               // everyone is done reading the images of the layer above
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) {
+            write_frag(my_dz, kk, ct, bz[kk][ct]);
+            if (l == 0) write_frag(my_x, kk, ct, x0[kk][ct]);
+            else write_frag(my_x, kk, ct, act[l > 0 ? l - 1 : 0][kk][ct]);
+          }
+        __syncthreads();
+        wgrad(acc[l], rt_w, ct_w);
+        if (l > 0) {                                   // dZ_{l-1} = relu'(act_{l-1}) (*) W_l^T dZ_l
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) {
+            floatx16 d[2];
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+              for (int e = 0; e < 16; ++e) d[ct][e] = 0.0f;
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+              const half8 af = *reinterpret_cast<const half8*>(wT + toff + ((rt * KS + kk) * 64 + lane) * 16);
+#pragma unroll
+              for (int ct = 0; ct < 2; ++ct) d[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bz[kk][ct], d[ct], 0, 0, 0);
+            }
+            mask_pack(d, rt, act[l > 0 ? l - 1 : 0], bn);
+          }
+#pragma unroll
+          for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) bz[kk][ct] = bn[kk][ct];
+          toff += RT * KS * 1024;
+        } else if (a.dencT) {                          // d(encoding) = W_0^T dZ_0 (hash-grid models)
+          for (int rt = 0; rt < rt_e; ++rt) {
+            floatx16 d[2];
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+              for (int e = 0; e < 16; ++e) d[ct][e] = 0.0f;
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+              const half8 af = *reinterpret_cast<const half8*>(wT + toff + ((rt * KS + kk) * 64 + lane) * 16);
+#pragma unroll
+              for (int ct = 0; ct < 2; ++ct) d[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bz[kk][ct], d[ct], 0, 0, 0);
+            }
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+              for (int e = 0; e < 16; ++e) {
+                const int feat0 = 32 * rt + (e & 3) + 8 * (e >> 2);
+                if (feat0 + 4 * h < a.E) *row_elem(a.dencT, feat0, a.Sp, lane_off[ct]) = ok_s[ct] ? (_Float16)d[ct][e] : (_Float16)0.0f;
+              }
+          }
+        }
+      }
+    }
+  }
+  // ---- one pass of atomics per wave: its quadrant of every layer ----
+  float* dW = a.dparams;
+#pragma unroll
+  for (int l = 0; l < kFusedMaxL; ++l)
+    if (l < L) {
+      const int N = l == 0 ? a.E : W;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int o = 32 * rt_w + (e & 3) + 8 * (e >> 2) + 4 * h, c = 32 * ct_w + col;
+        if (c < N && acc[l][e] != 0.0f) atomicAdd(&dW[(long)o * N + c], acc[l][e]);
+      }
+      dW += (long)W * N;
+    }
+  if (rt_w == 0) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int o = (e & 3) + 8 * (e >> 2) + 4 * h, c = 32 * ct_w + col;
+      if (o < 16 && accL[e] != 0.0f) atomicAdd(&dW[(long)o * W + c], accL[e]);
     }
   }
 }
@@ -937,6 +1257,93 @@ extern "C" int rtxn_mlp_train_backward(const rtxn_mlp* m, const void* encT, cons
     wgrad_lds_kernel<<<dim3((unsigned)((Sp + wl.chunk - 1) / wl.chunk), (unsigned)(L + 1)), kThreads, 2 * kWgStage, s>>>(wl);
     RTXN_LAUNCH_CHECK("wgrad_lds_kernel");
   }
+  return RTXN_OK;
+}
+
+// ---- recompute path (64-wide models): forward without saved activations + fused backward ----
+extern "C" int rtxn_mlp_train_recompute_supported(const rtxn_mlp* m) {
+  if (!m) return 0;
+  return m->cfg.n_neurons == 64 && m->cfg.n_hidden_layers <= kFusedMaxL && m->enc_padded <= 64 && m->enc_padded % 16 == 0;
+}
+
+extern "C" int rtxn_mlp_train_forward_outputs(const rtxn_mlp* m, const void* encT, long n_samples, void* output_half,
+                                              float* radiance, rtxn_stream_t stream) {
+  int rc = check_train(m, "rtxn_mlp_train_forward_outputs");
+  if (rc != RTXN_OK) return rc;
+  RTXN_REQUIRE(n_samples >= 0 && n_samples <= kMaxTrainSamples, "rtxn_mlp_train_forward_outputs: n_samples = %ld out of [0, %ld]", n_samples, kMaxTrainSamples);
+  RTXN_DEVICE_OR_FAIL();
+  if (n_samples == 0) return RTXN_OK;
+  RTXN_REQUIRE(encT && output_half, "rtxn_mlp_train_forward_outputs: NULL buffer");
+  const int W = m->cfg.n_neurons;
+  const long Sp = padded(n_samples);
+  TrainArgs a;
+  memset(&a, 0, sizeof(a));
+  a.packed = static_cast<const uint8_t*>(m->packed_train);
+  a.n_hidden = m->cfg.n_hidden_layers;
+  a.out_act = m->cfg.output_activation;
+  a.E = m->enc_padded;
+  a.S = n_samples;
+  a.Sp = Sp;
+  a.encT = static_cast<const _Float16*>(encT);
+  a.out_half = static_cast<_Float16*>(output_half);
+  a.radiance = reinterpret_cast<float4*>(radiance);
+  const int RT = W / 32, KS = W / 16, KS0 = a.E / 16;
+  const size_t lds = (size_t)(KS0 > KS ? KS0 : KS) * RT * 1024;
+  hipStream_t s = rtxn::as_stream(stream);
+  if (W == 64) {
+    RTXN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_train_fwd_kernel<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((mlp_train_fwd_kernel<64, false>), dim3((unsigned)(Sp / kTile)), dim3(kThreads), lds, s, a);
+  } else {
+    RTXN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_train_fwd_kernel<128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((mlp_train_fwd_kernel<128, false>), dim3((unsigned)(Sp / kTile)), dim3(kThreads), lds, s, a);
+  }
+  RTXN_LAUNCH_CHECK("mlp_train_fwd_kernel<outputs only>");
+  return RTXN_OK;
+}
+
+extern "C" int rtxn_mlp_train_backward_recompute(const rtxn_mlp* m, const void* encT, const void* output_half,
+                                                 const void* dout_half4, long n_samples, float* dparams, void* dencT,
+                                                 rtxn_stream_t stream) {
+  int rc = check_train(m, "rtxn_mlp_train_backward_recompute");
+  if (rc != RTXN_OK) return rc;
+  if (!rtxn_mlp_train_recompute_supported(m)) {
+    rtxn::set_error("rtxn_mlp_train_backward_recompute: built for 64-wide models with <= %d hidden layers and an encoded width <= 64 "
+                    "(this model: %d wide, %d layers, %d features); use rtxn_mlp_train_forward + rtxn_mlp_train_backward",
+                    kFusedMaxL, m->cfg.n_neurons, m->cfg.n_hidden_layers, m->enc_padded);
+    return RTXN_ERR_UNSUPPORTED;
+  }
+  RTXN_REQUIRE(n_samples >= 0 && n_samples <= kMaxTrainSamples, "rtxn_mlp_train_backward_recompute: n_samples = %ld out of [0, %ld]", n_samples, kMaxTrainSamples);
+  RTXN_DEVICE_OR_FAIL();
+  if (n_samples == 0) return RTXN_OK;
+  RTXN_REQUIRE(encT && output_half && dout_half4 && dparams, "rtxn_mlp_train_backward_recompute: NULL buffer");
+  const int L = m->cfg.n_hidden_layers, E = m->enc_padded;
+  FusedArgs a;
+  memset(&a, 0, sizeof(a));
+  a.packed_fwd = static_cast<const uint8_t*>(m->packed_train);
+  a.packed_t = static_cast<const uint8_t*>(m->packed_t);
+  a.L = L;
+  a.KS0 = E / 16;
+  a.out_act = m->cfg.output_activation;
+  a.E = E;
+  a.S = n_samples;
+  a.Sp = padded(n_samples);
+  a.n_tiles = (int)(a.Sp / kTile);
+  a.encT = static_cast<const _Float16*>(encT);
+  a.out_half = static_cast<const _Float16*>(output_half);
+  a.dout = static_cast<const _Float16*>(dout_half4);
+  a.dencT = static_cast<_Float16*>(dencT);
+  a.dparams = dparams;
+  const int RT = 2, KS = 4;
+  const size_t lds = (size_t)(a.KS0 * RT + (L - 1) * KS * RT) * 1024 + (size_t)(RT + (L - 1) * RT * KS + ((E + 31) / 32) * KS) * 1024 +
+                     8 * (size_t)kImgBytes;
+  int dev = 0, n_cu = 0;
+  RTXN_HIP(hipGetDevice(&dev));
+  RTXN_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  if (n_cu <= 0) n_cu = 256;
+  const int grid = a.n_tiles < n_cu ? a.n_tiles : n_cu;   // persistent: one block per CU (LDS- and register-bound)
+  RTXN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_fused64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(mlp_bwd_fused64_kernel, dim3((unsigned)grid), dim3(kThreads), lds, rtxn::as_stream(stream), a);
+  RTXN_LAUNCH_CHECK("mlp_bwd_fused64_kernel");
   return RTXN_OK;
 }
 

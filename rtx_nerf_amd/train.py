@@ -90,6 +90,11 @@ class Trainer:
         self.adam_v = torch.zeros_like(self.master)
         self.dparams = torch.zeros_like(self.master)
         self.net.set_params(self.params)
+        # 64-wide models (configs[2]): forward without saved activations + ONE fused backward kernel that recomputes them and
+        # keeps every weight gradient on the chip (librtxn: mlp_bwd_fused64_kernel).  RTXN_TRAIN_RECOMPUTE=0 selects the
+        # three-kernel path (saved activations, dgrad chain, weight-gradient GEMM) for A/B runs.
+        import os
+        self.recompute = self.net.recompute_supported() and os.environ.get("RTXN_TRAIN_RECOMPUTE", "1") != "0"
         # ---- per-step buffers at capacity ---------------------------------------------------------
         B = batch_rays
         self.max_segments = int(max_segments) if max_segments else 64 * B
@@ -111,7 +116,7 @@ class Trainer:
         Sp = api.padded_samples(M * K)
         self.encT = torch.empty((E, Sp), dtype=torch.float16, device=d)
         self.dencT = torch.empty((E, Sp), dtype=torch.float16, device=d) if encoding == "hash" else None
-        self.ws = self.net.train_workspace(M * K, device=d)
+        self.ws = None if self.recompute else self.net.train_workspace(M * K, device=d)   # saved activations | dZ | masks
         self.out = torch.empty((M * K, 16), dtype=torch.float16, device=d)
         self.radiance = torch.empty((M * K, 4), device=d)
         self.dout = torch.empty((M * K, 4), dtype=torch.float16, device=d)
@@ -159,7 +164,10 @@ class Trainer:
             else:
                 self.net.encode_frequency(self.samples[:S], self.encT)
         with _Stage(self, "mlp_fwd"):
-            self.net.train_forward(self.encT, S, self.ws, self.out, self.radiance)
+            if self.recompute:
+                self.net.train_forward_outputs(self.encT, S, self.out, self.radiance)
+            else:
+                self.net.train_forward(self.encT, S, self.ws, self.out, self.radiance)
 
     def render_rays(self, rays_o, rays_d, radiance_fn=None):
         """Forward only.  radiance_fn(samples[S,5]) -> float[S,4] replaces the network (teacher rendering)."""
@@ -204,7 +212,10 @@ class Trainer:
             api.launch_volrender_backward_cuda(None, self.loss_grads, self.radiance, self.t_vals, self.num_stored,
                                                self.indices, n, K, self.dout, mode=vr)
         with _Stage(self, "mlp_bwd+wgrad"):
-            self.net.train_backward(self.encT, self.out, self.dout, S, self.ws, self.dparams, self.dencT)
+            if self.recompute:
+                self.net.train_backward_recompute(self.encT, self.out, self.dout, S, self.dparams, self.dencT)
+            else:
+                self.net.train_backward(self.encT, self.out, self.dout, S, self.ws, self.dparams, self.dencT)
         if self.encoding == "hash":
             with _Stage(self, "hash_bwd"):
                 self.hg.backward(self.samples[:S], self.dencT, self.dtable)
@@ -356,7 +367,7 @@ class Trainer:
                 self.hg.encode(self.table, pts, self.encT)
             else:
                 self.net.encode_frequency(pts, self.encT)
-            self.net.train_forward(self.encT, m, self.ws, self.out, self.radiance)
+            self.net.train_forward_outputs(self.encT, m, self.out, self.radiance)
             sigma[s0:s0 + m] = self.radiance[:m, 3]
         thick = sigma * (self.density_scale * 2.0 / R)
         self.occ = api.occupancy_from_density(thick, threshold, R)

@@ -184,3 +184,62 @@ def test_l2_loss_and_adam(gpu, oracle):
     np.testing.assert_allclose(md.cpu().numpy(), master, rtol=2e-6, atol=1e-7)
     np.testing.assert_allclose(vv.cpu().numpy(), v, rtol=1e-5, atol=1e-30)
     assert (p16d.cpu().numpy() == p16).mean() > 0.9999
+
+
+@pytest.mark.parametrize("L,E,act,n", [(4, 48, 1, 5000), (4, 48, 1, 256), (1, 16, 0, 5), (2, 32, 1, 777), (3, 64, 0, 2049), (4, 64, 1, 70000)])
+def test_recompute_path_matches_oracle_and_three_kernel_path(gpu, oracle, L, E, act, n):
+    """The 64-wide recompute path (forward without saved activations + mlp_bwd_fused64_kernel: activations rebuilt in
+    registers, weight gradients accumulated on the chip through LDS-transposed operands) against the oracle and against the
+    saved-activation kernels on the same inputs, ragged sizes and several persistent-loop depths included."""
+    torch = gpu
+    from rtx_nerf_amd import api
+    W = 64
+    net, params, enc, encT_d, Sp = _train_case(oracle, api, torch, W, L, E, act, n, seed=L * 100 + E + n)
+    assert net.recompute_supported()
+    rad = torch.zeros((n, 4), device="cuda")
+    out = net.train_forward_outputs(encT_d, n, radiance=rad)
+    ws = net.train_workspace(n)
+    out_ref = net.train_forward(encT_d, n, ws)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out_ref)                                       # the same forward arithmetic, with and without saving
+    np.testing.assert_array_equal(rad.cpu().numpy(), out.cpu().numpy().astype(np.float32)[:, :4])
+    rng = np.random.default_rng(11)
+    dout = (rng.standard_normal((n, 4)) * 0.05).astype(np.float16)
+    dout_d = _dev(torch, dout)
+    dp, dp_ref = torch.zeros(net.n_params(), device="cuda"), torch.zeros(net.n_params(), device="cuda")
+    de = torch.full((E, Sp), 7.0, dtype=torch.float16, device="cuda")
+    de_ref = torch.full((E, Sp), 7.0, dtype=torch.float16, device="cuda")
+    net.train_backward_recompute(encT_d, out, dout_d, n, dp, de)
+    net.train_backward(encT_d, out, dout_d, n, ws, dp_ref, de_ref)
+    torch.cuda.synchronize()
+    o_acts, _ = oracle.mlpe_forward(W, L, act, params, enc)
+    want_dp, want_denc = oracle.mlpe_backward(W, L, act, params, enc, o_acts, out.cpu().numpy(), dout)
+    got_dp, ref_dp = dp.cpu().numpy(), dp_ref.cpu().numpy()
+    scale = np.abs(want_dp).max()
+    assert scale > 0 and np.isfinite(got_dp).all()
+    assert np.abs(got_dp - want_dp).max() < 3e-2 * scale and np.linalg.norm(got_dp - want_dp) < 2e-2 * np.linalg.norm(want_dp)
+    # against the three-kernel path: the same fp16 dZ values, only the fp32 summation order differs
+    assert np.linalg.norm(got_dp - ref_dp) < 2e-3 * np.linalg.norm(ref_dp)
+    assert np.all(got_dp[-16 * W:].reshape(16, W)[4:] == 0)
+    assert torch.equal(de, de_ref)                                         # d(encoding): the identical dgrad chain
+    got_denc = de.cpu().numpy()[:, :n].T.astype(np.float32)
+    assert np.linalg.norm(got_denc - want_denc) < 2e-2 * np.linalg.norm(want_denc) + 1e-6
+    assert np.all(de.cpu().numpy()[:, n:] == 0)
+    net.train_backward_recompute(encT_d, out, dout_d, n, dp, None)          # accumulate semantics
+    np.testing.assert_allclose(dp.cpu().numpy(), 2 * got_dp, rtol=1e-3, atol=1e-6 * scale + 1e-9)
+
+
+def test_recompute_path_is_refused_where_it_does_not_fit(gpu):
+    torch = gpu
+    from rtx_nerf_amd import _lib, api
+    for kw in (dict(n_neurons=128, n_hidden_layers=2, n_encoded_features=48), dict(n_neurons=64, n_hidden_layers=5, n_encoded_features=48),
+               dict(n_neurons=64, n_hidden_layers=2, n_encoded_features=112)):
+        net = api.Network(**kw)
+        net.set_params(torch.zeros(net.n_params(), dtype=torch.float16, device="cuda"))
+        assert not net.recompute_supported()
+        E = kw["n_encoded_features"]
+        with pytest.raises(_lib.RtxnError, match="use rtxn_mlp_train_forward"):
+            net.train_backward_recompute(torch.zeros((E, 256), dtype=torch.float16, device="cuda"),
+                                         torch.zeros((256, 16), dtype=torch.float16, device="cuda"),
+                                         torch.zeros((256, 4), dtype=torch.float16, device="cuda"), 256,
+                                         torch.zeros(net.n_params(), device="cuda"))
