@@ -312,6 +312,13 @@ int rtxn_hashgrid_encode(const rtxn_hashgrid* g, int n_dir_freqs, const void* ta
 int rtxn_hashgrid_backward(const rtxn_hashgrid* g, const float* input, const void* dencT, long n_samples,
                            float* dtable, rtxn_stream_t stream);
 
+/* As rtxn_hashgrid_backward, with the HASHED levels' gradient accumulated in fp16 (n_features == 2: one
+ * global_atomic_pk_add_f16 per corner instead of two fp32 atomics -- the scatter is bound by atomic instructions -- and what
+ * tiny-cuda-nn does: its grid gradient is __half2).  dtable: fp32, whole-table layout, receives the densely stored levels;
+ * dtable_hashed_half: fp16, the parameters from rtxn_hashgrid_level_offset(first hashed level) on.  Both accumulated into. */
+int rtxn_hashgrid_backward_mixed(const rtxn_hashgrid* g, const float* input, const void* dencT, long n_samples,
+                                 float* dtable, void* dtable_hashed_half, rtxn_stream_t stream);
+
 /* network->forward with saved activations (main.cu:721).  workspace: at least
  * rtxn_mlp_train_workspace_bytes(m, S) bytes, shared with the backward call.
  * output_half: half[S][16]; radiance: float[S][4] or NULL (the glue of main.cu:723-728). */

@@ -123,6 +123,7 @@ SYMBOLS = {
     "rtxn_convert_f16_to_f32": (_I, [_P, _P, _L, _P]),
     "rtxn_hashgrid_encode": (_I, [_P, _I, _P, _P, _P, _L, _P]),
     "rtxn_hashgrid_backward": (_I, [_P, _P, _P, _L, _P, _P]),
+    "rtxn_hashgrid_backward_mixed": (_I, [_P, _P, _P, _L, _P, _P, _P]),
     "rtxn_mlp_train_workspace_bytes": (C.c_size_t, [_P, _L]),
     "rtxn_mlp_train_forward": (_I, [_P, _P, _L, _P, _P, _P, _P]),
     "rtxn_mlp_train_backward": (_I, [_P, _P, _P, _P, _L, _P, _P, _P, _P]),

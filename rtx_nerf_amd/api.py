@@ -349,6 +349,15 @@ class HashGrid:
                                               n, _stream()), "rtxn_hashgrid_encode")
         return encT
 
+    def backward_mixed(self, inputs, dencT, dtable, dtable_hashed_half):
+        """backward with the hashed levels' gradient accumulated in fp16 (packed atomics; n_features == 2)."""
+        n = inputs.numel() // 5
+        check(_lib.lib().rtxn_hashgrid_backward_mixed(self._h, _ptr(inputs, torch.float32, "inputs"), _ptr(dencT, torch.float16, "dencT"),
+                                                      n, _ptr(dtable, torch.float32, "dtable"),
+                                                      _ptr(dtable_hashed_half, torch.float16, "dtable_hashed_half"), _stream()),
+              "rtxn_hashgrid_backward_mixed")
+        return dtable
+
     def backward(self, inputs, dencT, dtable):
         n = inputs.numel() // 5
         check(_lib.lib().rtxn_hashgrid_backward(self._h, _ptr(inputs, torch.float32, "inputs"),

@@ -25,6 +25,7 @@
 //   l2_loss_kernel, adam_kernel
 #include "mlp_internal.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -140,18 +141,24 @@ __global__ __launch_bounds__(kThreads) void hashgrid_encode_kernel(HgLevels lv, 
 // global float atomics on a few hot lines run an order of magnitude below their spread-out rate
 // (MI355X_MICROARCH.md, Global float atomics: contention), so those levels are first reduced in
 // an LDS copy of the level (ds_add_f32) per 8192-sample chunk and flushed once per block.
-constexpr int kHgLdsFloats = 16384;
+constexpr int kHgLdsFloats = 32768;   // 128 KiB: one block per CU; covers the two coarsest levels of the config-3 grid
 constexpr int kHgChunk = 8192;
 
-template <bool LDS>
+// PK (hashed levels, two features per entry): both features of a corner go out as ONE global_atomic_pk_add_f16 into an fp16
+// gradient table -- the scatter is bound by the number of atomic wave-instructions, not by bytes, and tiny-cuda-nn keeps this
+// gradient in fp16 as well (__half2 atomicAdd).  Entries of the hashed levels receive ~10 contributions each, so the fp16
+// accumulation costs ~1e-3 relative; the coarse levels, which receive thousands, stay fp32 (LDS / fp32 atomics).
+template <bool LDS, bool PK = false>
 __global__ __launch_bounds__(kThreads) void hashgrid_backward_kernel(HgLevels lv, int level0, const float* __restrict__ in,
                                                                      const _Float16* __restrict__ dencT, long S, long Sp,
-                                                                     float* __restrict__ dtable) {
+                                                                     float* __restrict__ dtable, _Float16* __restrict__ dtable_h,
+                                                                     long hashed_lo) {
   extern __shared__ float hist[];
   const int l = level0 + blockIdx.y;
   const int F = lv.n_features;
   const int n_entries = (int)lv.size[l] * F;
   float* gdst = dtable + (size_t)lv.offset[l] * F;
+  half2v* gdst_h = reinterpret_cast<half2v*>(dtable_h + ((size_t)lv.offset[l] * F - (size_t)hashed_lo));   // PK: F == 2
   if (LDS) {
     for (int i = threadIdx.x; i < n_entries; i += kThreads) hist[i] = 0.0f;
     __syncthreads();
@@ -206,6 +213,21 @@ __global__ __launch_bounds__(kThreads) void hashgrid_backward_kernel(HgLevels lv
         p[a] = g[a] + (unsigned)hi;
       }
       const unsigned idx = hg_index(p[0], p[1], p[2], lv.res[l], lv.size[l]);
+      if (PK) {
+        float v0 = w * d[0], v1 = w * d[1];
+        if (aggregate) {
+#pragma unroll
+          for (int dlt = 1; dlt < 64; dlt <<= 1) {
+            const float t0 = __shfl_up(v0, dlt, 64), t1 = __shfl_up(v1, dlt, 64);
+            if (lane - dlt >= run_start) { v0 += t0; v1 += t1; }
+          }
+        }
+        if (ok && run_last && (v0 != 0.0f || v1 != 0.0f)) {
+          const half2v hv = {(_Float16)v0, (_Float16)v1};
+          __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) half2v*)(gdst_h + idx), hv);
+        }
+        continue;
+      }
       for (int f = 0; f < F && f < 8; ++f) {
         float v = w * d[f];
         if (LDS) {
@@ -1429,6 +1451,47 @@ extern "C" int rtxn_hashgrid_encode(const rtxn_hashgrid* g, int n_dir_freqs, con
   return RTXN_OK;
 }
 
+// dtable_hashed_half == NULL: every level into the fp32 table.  Otherwise (n_features == 2): the hashed levels go to the fp16
+// buffer, which holds the parameters from the first hashed level on.
+static int hashgrid_backward_impl(const rtxn_hashgrid* g, const float* input, const void* dencT, long n_samples,
+                                  float* dtable, void* dtable_hashed_half, rtxn_stream_t stream, const char* who) {
+  const long Sp = padded(n_samples);
+  const int NL = g->cfg.n_levels, F = g->cfg.n_features;
+  int n_small = 0;
+  while (n_small < NL && (long)g->size[n_small] * F <= kHgLdsFloats) ++n_small;
+  int first_hashed = NL;
+  for (int l = NL - 1; l >= 0; --l)
+    if ((unsigned long long)g->res[l] * g->res[l] * g->res[l] > g->size[l]) first_hashed = l;
+  const long hashed_lo = first_hashed < NL ? (long)g->offset[first_hashed] * F : g->n_params;
+  if (!dtable_hashed_half) first_hashed = NL;          // everything fp32
+  if (n_small > first_hashed) n_small = first_hashed;  // mixed form: a hashed level goes to the fp16 table even when it would fit in LDS
+  hipStream_t st = rtxn::as_stream(stream);
+  const HgLevels lv = levels_of(g);
+  const _Float16* de = static_cast<const _Float16*>(dencT);
+  _Float16* dh = static_cast<_Float16*>(dtable_hashed_half);
+  if (n_small > 0) {
+    size_t lds = 0;
+    for (int l = 0; l < n_small; ++l) lds = std::max(lds, (size_t)g->size[l] * F * sizeof(float));
+    RTXN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hashgrid_backward_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hashgrid_backward_kernel<true, false><<<dim3((unsigned)((n_samples + kHgChunk - 1) / kHgChunk), (unsigned)n_small), kThreads, lds, st>>>(
+        lv, 0, input, de, n_samples, Sp, dtable, nullptr, 0);
+    RTXN_LAUNCH_CHECK("hashgrid_backward_kernel<lds>");
+  }
+  const unsigned sblocks = (unsigned)((n_samples + kThreads - 1) / kThreads);
+  if (first_hashed > n_small) {
+    hashgrid_backward_kernel<false, false><<<dim3(sblocks, (unsigned)(first_hashed - n_small)), kThreads, 0, st>>>(
+        lv, n_small, input, de, n_samples, Sp, dtable, nullptr, 0);
+    RTXN_LAUNCH_CHECK("hashgrid_backward_kernel");
+  }
+  if (first_hashed < NL) {
+    hashgrid_backward_kernel<false, true><<<dim3(sblocks, (unsigned)(NL - first_hashed)), kThreads, 0, st>>>(
+        lv, first_hashed, input, de, n_samples, Sp, dtable, dh, hashed_lo);
+    RTXN_LAUNCH_CHECK("hashgrid_backward_kernel<pk_f16>");
+  }
+  (void)who;
+  return RTXN_OK;
+}
+
 extern "C" int rtxn_hashgrid_backward(const rtxn_hashgrid* g, const float* input, const void* dencT, long n_samples,
                                       float* dtable, rtxn_stream_t stream) {
   RTXN_REQUIRE(g, "rtxn_hashgrid_backward: NULL grid");
@@ -1436,23 +1499,19 @@ extern "C" int rtxn_hashgrid_backward(const rtxn_hashgrid* g, const float* input
   RTXN_DEVICE_OR_FAIL();
   if (n_samples == 0) return RTXN_OK;
   RTXN_REQUIRE(input && dencT && dtable, "rtxn_hashgrid_backward: NULL buffer");
-  const long Sp = padded(n_samples);
-  int n_small = 0;
-  while (n_small < g->cfg.n_levels && (long)g->size[n_small] * g->cfg.n_features <= kHgLdsFloats) ++n_small;
-  hipStream_t st = rtxn::as_stream(stream);
-  const HgLevels lv = levels_of(g);
-  if (n_small > 0) {
-    hashgrid_backward_kernel<true><<<dim3((unsigned)((n_samples + kHgChunk - 1) / kHgChunk), (unsigned)n_small), kThreads,
-                                     kHgLdsFloats * sizeof(float), st>>>(lv, 0, input, static_cast<const _Float16*>(dencT),
-                                                                         n_samples, Sp, dtable);
-    RTXN_LAUNCH_CHECK("hashgrid_backward_kernel<lds>");
-  }
-  if (n_small < g->cfg.n_levels)
-    hashgrid_backward_kernel<false><<<dim3((unsigned)((n_samples + kThreads - 1) / kThreads), (unsigned)(g->cfg.n_levels - n_small)),
-                                      kThreads, 0, st>>>(lv, n_small, input, static_cast<const _Float16*>(dencT), n_samples, Sp,
-                                                         dtable);
-  RTXN_LAUNCH_CHECK("hashgrid_backward_kernel");
-  return RTXN_OK;
+  return hashgrid_backward_impl(g, input, dencT, n_samples, dtable, nullptr, stream, "rtxn_hashgrid_backward");
+}
+
+extern "C" int rtxn_hashgrid_backward_mixed(const rtxn_hashgrid* g, const float* input, const void* dencT, long n_samples,
+                                            float* dtable, void* dtable_hashed_half, rtxn_stream_t stream) {
+  RTXN_REQUIRE(g, "rtxn_hashgrid_backward_mixed: NULL grid");
+  RTXN_REQUIRE(n_samples >= 0, "rtxn_hashgrid_backward_mixed: n_samples = %ld < 0", n_samples);
+  RTXN_REQUIRE(g->cfg.n_features == 2, "rtxn_hashgrid_backward_mixed: packed fp16 atomics need n_features == 2 (got %d)", g->cfg.n_features);
+  RTXN_DEVICE_OR_FAIL();
+  if (n_samples == 0) return RTXN_OK;
+  RTXN_REQUIRE(input && dencT && dtable && dtable_hashed_half, "rtxn_hashgrid_backward_mixed: NULL buffer");
+  RTXN_REQUIRE(((uintptr_t)dtable_hashed_half & 3) == 0, "rtxn_hashgrid_backward_mixed: fp16 table must be 4-byte aligned");
+  return hashgrid_backward_impl(g, input, dencT, n_samples, dtable, dtable_hashed_half, stream, "rtxn_hashgrid_backward_mixed");
 }
 
 extern "C" int rtxn_l2_loss(const float* pred, const float* target, long n, float loss_scale, float* values,

@@ -76,9 +76,16 @@ class Trainer:
             self.table_m = torch.zeros_like(self.table_master)
             self.table_v = torch.zeros_like(self.table_master)
             self.dtable = torch.zeros_like(self.table_master)
-            # data-parallel exchange (step): the densely stored leading levels travel in fp32, the hashed levels in fp16
+            # The hashed levels' gradient lives in fp16 (dtable_h = parameters hashed_lo..): the scatter writes both features
+            # of a corner with one packed fp16 atomic (tiny-cuda-nn's grid gradient is __half2 too), the data-parallel
+            # exchange sends it as it is, and it is widened into dtable[hashed_lo:] for Adam.  The densely stored leading
+            # levels (thousands of contributions per entry) stay fp32.  RTXN_HASH_GRAD_FP16=0: everything fp32.
+            import os
             self.hashed_lo = self.hg.hashed_offset()
-            self.dtable_h = None      # fp16 staging of dtable[hashed_lo:], allocated when a process group exists
+            self.hash_fp16 = (self.hg.cfg.n_features == 2 and self.hashed_lo < self.hg.n_params()
+                              and os.environ.get("RTXN_HASH_GRAD_FP16", "1") != "0")
+            self.dtable_h = (torch.zeros(self.hg.n_params() - self.hashed_lo, dtype=torch.float16, device=d)
+                             if self.hash_fp16 else None)
         else:
             self.hg = None
             self.net = api.Network(n_neurons=n_neurons, n_hidden_layers=n_hidden_layers)
@@ -185,10 +192,11 @@ class Trainer:
                                   api.NUM_SAMPLES_PER_SEGMENT, self.pixels[:n], mode=vr)
         return self.pixels[:n]
 
-    def gradients(self, rays_o, rays_d, targets):
+    def gradients(self, rays_o, rays_d, targets, finish=True):
         """Everything of a step up to (not including) the optimizer: traversal ... backward.  Leaves the loss-scaled
         gradient SUMS of this batch in self.dparams (MLP, tcnn layout) and self.dtable (hash grid) and returns the number
-        of samples.  The loss is the mean over THIS batch's 3n pixel components (tcnn L2, main.cu:759)."""
+        of samples.  The loss is the mean over THIS batch's 3n pixel components (tcnn L2, main.cu:759).
+        finish=False (the data-parallel step): the hashed levels' gradient is left in self.dtable_h (fp16) for the exchange."""
         n = rays_o.shape[0]
         K = api.NUM_SAMPLES_PER_SEGMENT
         vr = api.VR_NERF if self.mode == "nerf" else api.VR_COMPAT
@@ -197,9 +205,15 @@ class Trainer:
         with _Stage(self, "zero_grads"):
             self.dparams.zero_()
             if self.encoding == "hash":
-                self.dtable.zero_()
+                if self.hash_fp16:
+                    self.dtable[:self.hashed_lo].zero_()
+                    self.dtable_h.zero_()
+                else:
+                    self.dtable.zero_()
         if S == 0:
             self.loss.zero_()
+            if finish and self.encoding == "hash":
+                self._finish_table_grad()
             return 0
         self._sample(n, P)
         self._forward(S)
@@ -218,7 +232,12 @@ class Trainer:
                 self.net.train_backward(self.encT, self.out, self.dout, S, self.ws, self.dparams, self.dencT)
         if self.encoding == "hash":
             with _Stage(self, "hash_bwd"):
-                self.hg.backward(self.samples[:S], self.dencT, self.dtable)
+                if self.hash_fp16:
+                    self.hg.backward_mixed(self.samples[:S], self.dencT, self.dtable, self.dtable_h)
+                else:
+                    self.hg.backward(self.samples[:S], self.dencT, self.dtable)
+                if finish:
+                    self._finish_table_grad()
         return S
 
     def apply_gradients(self, grad_divisor=1.0):
@@ -240,7 +259,7 @@ class Trainer:
         takes part in the all-reduces and runs Adam in every step -- also a rank whose rays all miss the grid (its
         gradients are zero) -- so the ranks can neither deadlock nor drift apart in step count."""
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        S = self.gradients(rays_o, rays_d, targets)
+        S = self.gradients(rays_o, rays_d, targets, finish=world == 1)
         if S == 0 and world == 1:
             return self.loss                  # nothing to learn from: no Adam step, step_count unchanged
         if world > 1:
@@ -269,13 +288,15 @@ class Trainer:
         if lo > 0:
             pending.append(dist.all_reduce(self.dtable[:lo], async_op=True))
         if n > lo:
-            if self.dtable_h is None:
-                self.dtable_h = torch.empty(n - lo, dtype=torch.float16, device=self.dev)
-            api.convert_f32_to_f16(self.dtable[lo:], self.dtable_h)
+            if not self.hash_fp16:      # fp32 scatter (F != 2 or switched off): stage the hashed part in fp16 for the wire
+                if self.dtable_h is None:
+                    self.dtable_h = torch.empty(n - lo, dtype=torch.float16, device=self.dev)
+                api.convert_f32_to_f16(self.dtable[lo:], self.dtable_h)
             pending.append(dist.all_reduce(self.dtable_h, async_op=True))
         return pending
 
     def _finish_table_grad(self):
+        """Widen the fp16 gradient of the hashed levels into dtable[hashed_lo:] (what Adam reads)."""
         if self.dtable_h is not None:
             api.convert_f16_to_f32(self.dtable_h, self.dtable[self.hashed_lo:])
 

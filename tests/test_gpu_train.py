@@ -80,6 +80,21 @@ def test_hashgrid_encode_and_backward(gpu, oracle, levels, feat, log2, base, sca
     got_g = dtable.cpu().numpy()
     assert np.abs(got_g - want_g).max() < 1e-4 * max(1.0, np.abs(want_g).max())
     assert np.count_nonzero(want_g) > 0
+    if feat == 2:
+        # mixed form: densely stored levels fp32 as above, hashed levels through packed fp16 atomics into an fp16 table
+        lo = hg.hashed_offset()
+        assert 0 < lo <= hg.n_params() and lo == sum(min((int(np.ceil(base * scale ** l - 1)) + 1) ** 3 // 8 * 8 + (8 if ((int(np.ceil(base * scale ** l - 1)) + 1) ** 3) % 8 else 0), 2 ** log2)
+                                                     for l in range(levels) if (int(np.ceil(base * scale ** l - 1)) + 1) ** 3 <= 2 ** log2) * feat
+        dt32 = torch.zeros(hg.n_params(), device="cuda")
+        dt16 = torch.zeros(hg.n_params() - lo, dtype=torch.float16, device="cuda")
+        hg.backward_mixed(_dev(torch, x), _dev(torch, denc), dt32, dt16)
+        got32, got16 = dt32.cpu().numpy(), dt16.cpu().numpy().astype(np.float32)
+        assert np.all(got32[lo:] == 0)
+        assert np.abs(got32[:lo] - want_g[:lo]).max() < 1e-4 * max(1.0, np.abs(want_g).max())
+        if lo < hg.n_params():
+            # fp16 accumulation: each of an entry's few contributions rounded to 11 bits
+            assert np.abs(got16 - want_g[lo:]).max() < 3e-3 * max(1.0, np.abs(want_g[lo:]).max())
+            assert np.linalg.norm(got16 - want_g[lo:]) < 1e-3 * np.linalg.norm(want_g[lo:])
 
 
 def _train_case(oracle, api, torch, W, L, E, act, n, seed, use_freq=False):
