@@ -312,6 +312,23 @@ int rtxn_hashgrid_encode(const rtxn_hashgrid* g, int n_dir_freqs, const void* ta
 int rtxn_hashgrid_backward(const rtxn_hashgrid* g, const float* input, const void* dencT, long n_samples,
                            float* dtable, rtxn_stream_t stream);
 
+/* launchSampler folded into its consumers: the encoders and the hash-grid scatter take the packed SEGMENTS (start/end float3
+ * per segment, seg_view float2 per segment as rtxn_trace_grid writes them) and form sample (segment g, i) themselves exactly
+ * as rtxn_sample would -- sample_type RTXN_SAMPLING_REGULAR or RTXN_SAMPLING_MIDPOINT_WORLD (the deterministic modes) -- so the
+ * 20-byte samples (sampler/sampler.h:19-30, `d_sampled_points`) never exist in memory.  n_samples = 32 n_segments.
+ * t_vals (may be NULL): the sampler's t_vals, float[n_segments * 32], times t_scale (MIDPOINT_WORLD: world step x density
+ * scale; REGULAR: (i + 1)/32, t_scale ignored).  backward_segments: dtable_hashed_half NULL = all levels fp32
+ * (rtxn_hashgrid_backward), else the mixed form (rtxn_hashgrid_backward_mixed). */
+int rtxn_encode_frequency_segments(const rtxn_mlp* m, const float* start_points, const float* end_points, const float* seg_view,
+                                   long n_segments, int sample_type, float t_scale, void* encT, float* t_vals,
+                                   rtxn_stream_t stream);
+int rtxn_hashgrid_encode_segments(const rtxn_hashgrid* g, int n_dir_freqs, const void* table_fp16, const float* start_points,
+                                  const float* end_points, const float* seg_view, long n_segments, int sample_type,
+                                  float t_scale, void* encT, float* t_vals, rtxn_stream_t stream);
+int rtxn_hashgrid_backward_segments(const rtxn_hashgrid* g, const float* start_points, const float* end_points, long n_segments,
+                                    int sample_type, const void* dencT, float* dtable, void* dtable_hashed_half,
+                                    rtxn_stream_t stream);
+
 /* As rtxn_hashgrid_backward, with the HASHED levels' gradient accumulated in fp16 (n_features == 2: one
  * global_atomic_pk_add_f16 per corner instead of two fp32 atomics -- the scatter is bound by atomic instructions -- and what
  * tiny-cuda-nn does: its grid gradient is __half2).  dtable: fp32, whole-table layout, receives the densely stored levels;

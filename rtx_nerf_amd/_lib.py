@@ -124,6 +124,9 @@ SYMBOLS = {
     "rtxn_hashgrid_encode": (_I, [_P, _I, _P, _P, _P, _L, _P]),
     "rtxn_hashgrid_backward": (_I, [_P, _P, _P, _L, _P, _P]),
     "rtxn_hashgrid_backward_mixed": (_I, [_P, _P, _P, _L, _P, _P, _P]),
+    "rtxn_encode_frequency_segments": (_I, [_P, _P, _P, _P, _L, _I, _F, _P, _P, _P]),
+    "rtxn_hashgrid_encode_segments": (_I, [_P, _I, _P, _P, _P, _P, _L, _I, _F, _P, _P, _P]),
+    "rtxn_hashgrid_backward_segments": (_I, [_P, _P, _P, _L, _I, _P, _P, _P, _P]),
     "rtxn_mlp_train_workspace_bytes": (C.c_size_t, [_P, _L]),
     "rtxn_mlp_train_forward": (_I, [_P, _P, _L, _P, _P, _P, _P]),
     "rtxn_mlp_train_backward": (_I, [_P, _P, _P, _P, _L, _P, _P, _P, _P]),

@@ -349,6 +349,23 @@ class HashGrid:
                                               n, _stream()), "rtxn_hashgrid_encode")
         return encT
 
+    def encode_segments(self, table_fp16, start_points, end_points, seg_view, n_segments, sample_type, encT, t_vals=None, t_scale=1.0):
+        """launchSampler + encode in one pass over the packed segments (the float[S][5] samples are never written)."""
+        check(_lib.lib().rtxn_hashgrid_encode_segments(self._h, self.n_dir_freqs, _ptr(table_fp16, torch.float16, "table"),
+                                                       _ptr(start_points, torch.float32, "start_points"), _ptr(end_points, torch.float32, "end_points"),
+                                                       _ptr(seg_view, torch.float32, "seg_view"), n_segments, sample_type, t_scale,
+                                                       _ptr(encT, torch.float16, "encT"), _ptr(t_vals, torch.float32, "t_vals"), _stream()),
+              "rtxn_hashgrid_encode_segments")
+        return encT
+
+    def backward_segments(self, start_points, end_points, n_segments, sample_type, dencT, dtable, dtable_hashed_half=None):
+        check(_lib.lib().rtxn_hashgrid_backward_segments(self._h, _ptr(start_points, torch.float32, "start_points"),
+                                                         _ptr(end_points, torch.float32, "end_points"), n_segments, sample_type,
+                                                         _ptr(dencT, torch.float16, "dencT"), _ptr(dtable, torch.float32, "dtable"),
+                                                         _ptr(dtable_hashed_half, torch.float16, "dtable_hashed_half"), _stream()),
+              "rtxn_hashgrid_backward_segments")
+        return dtable
+
     def backward_mixed(self, inputs, dencT, dtable, dtable_hashed_half):
         """backward with the hashed levels' gradient accumulated in fp16 (packed atomics; n_features == 2)."""
         n = inputs.numel() // 5
@@ -373,6 +390,15 @@ def _net_encode_frequency(self, inputs, encT=None):
         encT = torch.empty((self.encoded_width(), padded_samples(n)), dtype=torch.float16, device=inputs.device)
     check(_lib.lib().rtxn_encode_frequency(self._h, _ptr(inputs, torch.float32, "inputs"), _ptr(encT, torch.float16),
                                            n, _stream()), "rtxn_encode_frequency")
+    return encT
+
+
+def _net_encode_frequency_segments(self, start_points, end_points, seg_view, n_segments, sample_type, encT, t_vals=None, t_scale=1.0):
+    """launchSampler + Composite-Frequency encoding in one pass over the packed segments."""
+    check(_lib.lib().rtxn_encode_frequency_segments(self._h, _ptr(start_points, torch.float32, "start_points"),
+                                                    _ptr(end_points, torch.float32, "end_points"), _ptr(seg_view, torch.float32, "seg_view"),
+                                                    n_segments, sample_type, t_scale, _ptr(encT, torch.float16, "encT"),
+                                                    _ptr(t_vals, torch.float32, "t_vals"), _stream()), "rtxn_encode_frequency_segments")
     return encT
 
 
@@ -428,6 +454,7 @@ Network.recompute_supported = _net_recompute_supported
 Network.train_forward_outputs = _net_train_forward_outputs
 Network.train_backward_recompute = _net_train_backward_recompute
 Network.encode_frequency = _net_encode_frequency
+Network.encode_frequency_segments = _net_encode_frequency_segments
 Network.train_workspace = _net_train_workspace
 Network.train_forward = _net_train_forward
 Network.train_backward = _net_train_backward

@@ -27,6 +27,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 struct rtxn_hashgrid {
@@ -57,13 +58,65 @@ __device__ __forceinline__ float sin_turns(float x, int f, int ph) {
   return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(ldexpf(x, f - 1)) + 0.25f * (float)ph);
 }
 
-__global__ __launch_bounds__(kThreads) void encode_freq_kernel(const float* __restrict__ in, _Float16* __restrict__ encT,
-                                                               long S, long Sp, int PD, int PF, int DD, int DF, int E) {
+// Where a kernel's samples come from: a materialised float[S][5] batch (the sampler's output, sampler/sampler.cu), or the
+// packed segments themselves -- sample (segment g, i) is then formed here exactly as sample_kernel forms it (REGULAR: t = i/32;
+// MIDPOINT_WORLD: t = (i + 0.5)/32; position = fma(t, end - start, start); (theta, phi) = the segment's), so the 20-byte
+// samples never exist in memory: launchSampler folded into its consumers.
+struct SampleSrc {
+  const float* in;        // [S][5], or NULL: segments
+  const float* start;     // [P][3]
+  const float* end;       // [P][3]
+  const float* seg_view;  // [P][2]
+  int midpoint;           // RTXN_SAMPLING_MIDPOINT_WORLD (1) / RTXN_SAMPLING_REGULAR (0)
+};
+__device__ __forceinline__ void sample_pos(const SampleSrc& src, long s, bool ok, float (&x)[3]) {
+  if (src.in) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) x[a] = ok ? src.in[5 * s + a] : 0.0f;
+  } else {
+    const long g = ok ? (s >> 5) * 3 : 0;
+    const float t = ((float)(int)(s & 31) + (src.midpoint ? 0.5f : 0.0f)) * (1.0f / 32);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float og = src.start[g + a];
+      x[a] = ok ? fmaf(t, src.end[g + a] - og, og) : 0.0f;
+    }
+  }
+}
+__device__ __forceinline__ void sample_dir(const SampleSrc& src, long s, bool ok, float (&v)[2]) {
+  if (src.in) {
+    v[0] = ok ? src.in[5 * s + 3] : 0.0f;
+    v[1] = ok ? src.in[5 * s + 4] : 0.0f;
+  } else {
+    const long g = ok ? (s >> 5) * 2 : 0;
+    v[0] = ok ? src.seg_view[g] : 0.0f;
+    v[1] = ok ? src.seg_view[g + 1] : 0.0f;
+  }
+}
+// the sampler's t_vals of sample s (segments only): REGULAR (i + 1)/32; MIDPOINT_WORLD |end - start|/32, times t_scale
+__device__ __forceinline__ float sample_tval(const SampleSrc& src, long s, float t_scale) {
+  if (!src.midpoint) return (float)((int)(s & 31) + 1) * (1.0f / 32);
+  const long g = (s >> 5) * 3;
+  const float dx = src.end[g] - src.start[g], dy = src.end[g + 1] - src.start[g + 1], dz = src.end[g + 2] - src.start[g + 2];
+  const float tv = sqrtf(fmaf(dz, dz, fmaf(dx, dx, dy * dy))) * (1.0f / 32);
+  return t_scale == 1.0f ? tv : tv * t_scale;
+}
+
+__global__ __launch_bounds__(kThreads) void encode_freq_kernel(SampleSrc src, _Float16* __restrict__ encT, float* __restrict__ t_vals,
+                                                               float t_scale, long S, long Sp, int PD, int PF, int DD, int DF, int E) {
   const long s = (long)blockIdx.x * kThreads + threadIdx.x;
   if (s >= Sp) return;
   const bool ok = s < S;
   float x[8];
-  for (int c = 0; c < PD + DD; ++c) x[c] = ok ? in[(PD + DD) * s + c] : 0.0f;
+  if (src.in) {
+    for (int c = 0; c < PD + DD; ++c) x[c] = ok ? src.in[(PD + DD) * s + c] : 0.0f;
+  } else {   // segments: 3 + 2 dimensions
+    float p3[3], v2[2];
+    sample_pos(src, s, ok, p3);
+    sample_dir(src, s, ok, v2);
+    x[0] = p3[0]; x[1] = p3[1]; x[2] = p3[2]; x[3] = v2[0]; x[4] = v2[1];
+    if (t_vals && ok) t_vals[s] = sample_tval(src, s, t_scale);
+  }
   int j = 0;
   for (int d = 0; d < PD; ++d)
     for (int f = 0; f < PF; ++f)
@@ -90,19 +143,20 @@ __device__ __forceinline__ unsigned hg_index(unsigned x, unsigned y, unsigned z,
 
 // grid.y = level (0..L-1: hash levels; L: direction frequencies + padding)
 __global__ __launch_bounds__(kThreads) void hashgrid_encode_kernel(HgLevels lv, int n_dir_freqs, const _Float16* __restrict__ table,
-                                                                   const float* __restrict__ in, _Float16* __restrict__ encT,
-                                                                   long S, long Sp, int E) {
+                                                                   SampleSrc src, _Float16* __restrict__ encT, float* __restrict__ t_vals,
+                                                                   float t_scale, long S, long Sp, int E) {
   const long s = (long)blockIdx.x * kThreads + threadIdx.x;
   if (s >= Sp) return;
   const bool ok = s < S;
   const int l = blockIdx.y;
   const int F = lv.n_features;
   if (l < lv.n_levels) {
-    float fr[3];
+    float fr[3], x3[3];
     unsigned g[3];
+    sample_pos(src, s, ok, x3);
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      const float x01 = fmaf(ok ? in[5 * s + a] : 0.0f, 0.5f, 0.5f);
+      const float x01 = fmaf(x3[a], 0.5f, 0.5f);
       const float p = fmaf(x01, lv.scale[l], 0.5f), fl = floorf(p);
       g[a] = (unsigned)(int)fl;
       fr[a] = p - fl;
@@ -126,8 +180,11 @@ __global__ __launch_bounds__(kThreads) void hashgrid_encode_kernel(HgLevels lv, 
     }
   } else {
     int j = lv.n_levels * F;
+    float v2[2];
+    sample_dir(src, s, ok, v2);
+    if (!src.in && t_vals && ok) t_vals[s] = sample_tval(src, s, t_scale);
     for (int d = 0; d < 2; ++d) {
-      const float x = ok ? in[5 * s + 3 + d] : 0.0f;
+      const float x = v2[d];
       for (int f = 0; f < n_dir_freqs; ++f)
         for (int ph = 0; ph < 2; ++ph, ++j) encT[(long)j * Sp + s] = ok ? (_Float16)sin_turns(x, f, ph) : (_Float16)0.0f;
     }
@@ -135,121 +192,98 @@ __global__ __launch_bounds__(kThreads) void hashgrid_encode_kernel(HgLevels lv, 
   }
 }
 
-// Scatter-add of dL/d(encoding) into the table gradient.  Fine (hashed) levels: one fp32
-// global atomic per (sample, corner, feature) -- addresses are spread, contention is low.
-// Coarse levels (whole level <= 64 KiB of fp32) are hit by every sample of every block, and
-// global float atomics on a few hot lines run an order of magnitude below their spread-out rate
-// (MI355X_MICROARCH.md, Global float atomics: contention), so those levels are first reduced in
-// an LDS copy of the level (ds_add_f32) per 8192-sample chunk and flushed once per block.
-constexpr int kHgLdsFloats = 32768;   // 128 KiB: one block per CU; covers the two coarsest levels of the config-3 grid
-constexpr int kHgChunk = 8192;
-
+// Scatter-add of dL/d(encoding) into the table gradient: one atomic per (sample, corner) and feature (fp32), or per
+// (sample, corner) for both features at once (PK, below).  What bounds it is the L2's atomic throughput on SCATTERED addresses
+// (MI355X_MICROARCH.md, Global float atomics: lanes in different rows run an order of magnitude below the streaming rate), so
+// the lever is the number of atomics that leave the wave.  Consecutive lanes are consecutive samples of a segment: on every
+// level but the finest, runs of lanes share a grid cell and with it all eight corner addresses (whole waves on the coarse
+// levels).  A segmented inclusive scan keyed on the cell leaves each run's sum in its last lane, which alone issues the
+// atomic; the finest levels, where no two lanes share a cell, skip the scans on a wave-uniform branch.
+// (Round 1 first reduced the coarsest levels in an LDS copy of the level, flushed once per block.  Measured inside the
+// config-3 step against sending those levels through the run aggregation as well: LDS copy 0.37-0.47 ms for the whole scatter,
+// none 0.28 ms -- the 64/128-KiB copy leaves one block per CU and its zero/flush passes cost more than the few atomics the
+// aggregation leaves.  The LDS path is gone.)
+//
 // PK (hashed levels, two features per entry): both features of a corner go out as ONE global_atomic_pk_add_f16 into an fp16
-// gradient table -- the scatter is bound by the number of atomic wave-instructions, not by bytes, and tiny-cuda-nn keeps this
-// gradient in fp16 as well (__half2 atomicAdd).  Entries of the hashed levels receive ~10 contributions each, so the fp16
-// accumulation costs ~1e-3 relative; the coarse levels, which receive thousands, stay fp32 (LDS / fp32 atomics).
-template <bool LDS, bool PK = false>
-__global__ __launch_bounds__(kThreads) void hashgrid_backward_kernel(HgLevels lv, int level0, const float* __restrict__ in,
+// gradient table -- half the atomics -- which is also what tiny-cuda-nn does (its grid gradient is __half2).  Entries of the
+// hashed levels receive ~10 contributions each, so the fp16 accumulation costs ~1e-3 relative; the densely stored coarse
+// levels, which receive thousands per entry, stay fp32.
+template <bool PK>
+__global__ __launch_bounds__(kThreads) void hashgrid_backward_kernel(HgLevels lv, int level0, SampleSrc src,
                                                                      const _Float16* __restrict__ dencT, long S, long Sp,
                                                                      float* __restrict__ dtable, _Float16* __restrict__ dtable_h,
                                                                      long hashed_lo) {
-  extern __shared__ float hist[];
   const int l = level0 + blockIdx.y;
   const int F = lv.n_features;
-  const int n_entries = (int)lv.size[l] * F;
   float* gdst = dtable + (size_t)lv.offset[l] * F;
   half2v* gdst_h = reinterpret_cast<half2v*>(dtable_h + ((size_t)lv.offset[l] * F - (size_t)hashed_lo));   // PK: F == 2
-  if (LDS) {
-    for (int i = threadIdx.x; i < n_entries; i += kThreads) hist[i] = 0.0f;
-    __syncthreads();
-  }
-  const long s_begin = LDS ? (long)blockIdx.x * kHgChunk : (long)blockIdx.x * kThreads;
-  const long s_end = LDS ? (s_begin + kHgChunk < S ? s_begin + kHgChunk : S) : s_begin + kThreads;   // !LDS: one pass, every lane stays
   const int lane = threadIdx.x & 63;
-  for (long s = s_begin + threadIdx.x; s < s_end; s += kThreads) {
-    const bool ok = s < S;
-    float fr[3];
-    unsigned g[3];
+  const long s = (long)blockIdx.x * kThreads + threadIdx.x;     // every lane stays: the aggregation shuffles across the wave
+  const bool ok = s < S;
+  float fr[3], x3[3];
+  unsigned g[3];
+  sample_pos(src, s, ok, x3);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float x01 = fmaf(x3[a], 0.5f, 0.5f);
+    const float p = fmaf(x01, lv.scale[l], 0.5f), fl = floorf(p);
+    g[a] = (unsigned)(int)fl;
+    fr[a] = p - fl;
+  }
+  float d[8];
+  for (int f = 0; f < F && f < 8; ++f) d[f] = ok ? (float)dencT[(long)(l * F + f) * Sp + s] : 0.0f;
+  int run_start = lane;
+  bool run_last = true;
+  const unsigned k0 = ok ? (g[0] | (g[1] << 16)) : 0xffffffffu, k1 = ok ? g[2] : (unsigned)lane;
+  const unsigned p0 = __shfl_up(k0, 1, 64), p1 = __shfl_up(k1, 1, 64);
+  const bool head = lane == 0 || p0 != k0 || p1 != k1;
+  const bool aggregate = __ballot(head) != ~0ull;   // wave-uniform: finest levels have no runs and skip the scans
+  if (aggregate) {
+    run_start = head ? lane : 0;
+#pragma unroll
+    for (int dlt = 1; dlt < 64; dlt <<= 1) {
+      const int t = __shfl_up(run_start, dlt, 64);
+      if (lane >= dlt && t > run_start) run_start = t;
+    }
+    const int next_head = __shfl_down((int)head, 1, 64);
+    run_last = lane == 63 || next_head != 0;
+  }
+#pragma unroll
+  for (int corner = 0; corner < 8; ++corner) {
+    float w = 1.0f;
+    unsigned p[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      const float x01 = fmaf(ok ? in[5 * s + a] : 0.0f, 0.5f, 0.5f);
-      const float p = fmaf(x01, lv.scale[l], 0.5f), fl = floorf(p);
-      g[a] = (unsigned)(int)fl;
-      fr[a] = p - fl;
+      const int hi = (corner >> a) & 1;
+      w *= hi ? fr[a] : 1.0f - fr[a];
+      p[a] = g[a] + (unsigned)hi;
     }
-    float d[8];
-    for (int f = 0; f < F && f < 8; ++f) d[f] = ok ? (float)dencT[(long)(l * F + f) * Sp + s] : 0.0f;
-    // !LDS (levels too large for an LDS copy): consecutive lanes are consecutive samples of a segment, so runs of lanes
-    // share a grid cell and with it all eight corner addresses -- up to 32 lanes on the coarser of these levels.  A
-    // segmented inclusive scan over each run (keyed on the cell) leaves the run's sum in its last lane, which alone issues
-    // the atomic: the L2 atomic units see one add per run instead of one per sample (they, not HBM, bound this kernel).
-    int run_start = lane;
-    bool run_last = true;
-    bool aggregate = false;
-    if (!LDS) {
-      const unsigned k0 = ok ? (g[0] | (g[1] << 16)) : 0xffffffffu, k1 = ok ? g[2] : (unsigned)lane;
-      const unsigned p0 = __shfl_up(k0, 1, 64), p1 = __shfl_up(k1, 1, 64);
-      const bool head = lane == 0 || p0 != k0 || p1 != k1;
-      aggregate = __ballot(head) != ~0ull;   // wave-uniform: finest levels have no runs and skip the scans
+    const unsigned idx = hg_index(p[0], p[1], p[2], lv.res[l], lv.size[l]);
+    if (PK) {
+      float v0 = w * d[0], v1 = w * d[1];
       if (aggregate) {
-        run_start = head ? lane : 0;
 #pragma unroll
         for (int dlt = 1; dlt < 64; dlt <<= 1) {
-          const int t = __shfl_up(run_start, dlt, 64);
-          if (lane >= dlt && t > run_start) run_start = t;
+          const float t0 = __shfl_up(v0, dlt, 64), t1 = __shfl_up(v1, dlt, 64);
+          if (lane - dlt >= run_start) { v0 += t0; v1 += t1; }
         }
-        const int next_head = __shfl_down((int)head, 1, 64);
-        run_last = lane == 63 || next_head != 0;
       }
-    }
-#pragma unroll
-    for (int corner = 0; corner < 8; ++corner) {
-      float w = 1.0f;
-      unsigned p[3];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        const int hi = (corner >> a) & 1;
-        w *= hi ? fr[a] : 1.0f - fr[a];
-        p[a] = g[a] + (unsigned)hi;
+      if (ok && run_last && (v0 != 0.0f || v1 != 0.0f)) {
+        const half2v hv = {(_Float16)v0, (_Float16)v1};
+        __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) half2v*)(gdst_h + idx), hv);
       }
-      const unsigned idx = hg_index(p[0], p[1], p[2], lv.res[l], lv.size[l]);
-      if (PK) {
-        float v0 = w * d[0], v1 = w * d[1];
+    } else {
+      for (int f = 0; f < F && f < 8; ++f) {
+        float v = w * d[f];
         if (aggregate) {
 #pragma unroll
           for (int dlt = 1; dlt < 64; dlt <<= 1) {
-            const float t0 = __shfl_up(v0, dlt, 64), t1 = __shfl_up(v1, dlt, 64);
-            if (lane - dlt >= run_start) { v0 += t0; v1 += t1; }
+            const float t = __shfl_up(v, dlt, 64);
+            if (lane - dlt >= run_start) v += t;
           }
         }
-        if (ok && run_last && (v0 != 0.0f || v1 != 0.0f)) {
-          const half2v hv = {(_Float16)v0, (_Float16)v1};
-          __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) half2v*)(gdst_h + idx), hv);
-        }
-        continue;
+        if (ok && run_last && v != 0.0f) atomicAdd(&gdst[(size_t)idx * F + f], v);
       }
-      for (int f = 0; f < F && f < 8; ++f) {
-        float v = w * d[f];
-        if (LDS) {
-          if (v != 0.0f) atomicAdd(&hist[idx * F + f], v);
-        } else {
-          if (aggregate) {
-#pragma unroll
-            for (int dlt = 1; dlt < 64; dlt <<= 1) {
-              const float t = __shfl_up(v, dlt, 64);
-              if (lane - dlt >= run_start) v += t;
-            }
-          }
-          if (ok && run_last && v != 0.0f) atomicAdd(&gdst[(size_t)idx * F + f], v);
-        }
-      }
-    }
-  }
-  if (LDS) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < n_entries; i += kThreads) {
-      const float v = hist[i];
-      if (v != 0.0f) atomicAdd(&gdst[i], v);
     }
   }
 }
@@ -1154,6 +1188,16 @@ extern "C" size_t rtxn_mlp_train_workspace_bytes(const rtxn_mlp* m, long n_sampl
   return (size_t)((2 * L * W + 16 + 8 * L) * Sp) * sizeof(_Float16);   // acts | dz | dzL | sign masks (16 B per sample and layer)
 }
 
+static int encode_frequency_impl(const rtxn_mlp* m, const SampleSrc& src, void* encT, float* t_vals, float t_scale, long n_samples,
+                                 rtxn_stream_t stream) {
+  const long Sp = padded(n_samples);
+  encode_freq_kernel<<<(unsigned)(Sp / kThreads), kThreads, 0, rtxn::as_stream(stream)>>>(
+      src, static_cast<_Float16*>(encT), t_vals, t_scale, n_samples, Sp, m->cfg.n_pos_dims, m->cfg.n_pos_freqs, m->cfg.n_dir_dims,
+      m->cfg.n_dir_freqs, m->enc_padded);
+  RTXN_LAUNCH_CHECK("encode_freq_kernel");
+  return RTXN_OK;
+}
+
 extern "C" int rtxn_encode_frequency(const rtxn_mlp* m, const float* input, void* encT, long n_samples,
                                      rtxn_stream_t stream) {
   RTXN_REQUIRE(m && m->cfg.encoding == RTXN_ENC_FREQUENCY, "rtxn_encode_frequency: model has no frequency encoding");
@@ -1161,12 +1205,31 @@ extern "C" int rtxn_encode_frequency(const rtxn_mlp* m, const float* input, void
   RTXN_DEVICE_OR_FAIL();
   if (n_samples == 0) return RTXN_OK;
   RTXN_REQUIRE(input && encT, "rtxn_encode_frequency: NULL buffer");
-  const long Sp = padded(n_samples);
-  encode_freq_kernel<<<(unsigned)(Sp / kThreads), kThreads, 0, rtxn::as_stream(stream)>>>(
-      input, static_cast<_Float16*>(encT), n_samples, Sp, m->cfg.n_pos_dims, m->cfg.n_pos_freqs, m->cfg.n_dir_dims,
-      m->cfg.n_dir_freqs, m->enc_padded);
-  RTXN_LAUNCH_CHECK("encode_freq_kernel");
+  const SampleSrc src{input, nullptr, nullptr, nullptr, 0};
+  return encode_frequency_impl(m, src, encT, nullptr, 1.0f, n_samples, stream);
+}
+
+static int check_segments(const char* who, const float* start_points, const float* end_points, const float* seg_view,
+                          long n_segments, int sample_type) {
+  RTXN_REQUIRE(n_segments >= 0 && n_segments <= kMaxTrainSamples / 32, "%s: n_segments = %ld", who, n_segments);
+  RTXN_REQUIRE(sample_type == RTXN_SAMPLING_REGULAR || sample_type == RTXN_SAMPLING_MIDPOINT_WORLD,
+               "%s: sample_type %d (the deterministic modes only: REGULAR, MIDPOINT_WORLD)", who, sample_type);
+  RTXN_REQUIRE(n_segments == 0 || (start_points && end_points && seg_view), "%s: NULL segment buffer", who);
   return RTXN_OK;
+}
+
+extern "C" int rtxn_encode_frequency_segments(const rtxn_mlp* m, const float* start_points, const float* end_points,
+                                              const float* seg_view, long n_segments, int sample_type, float t_scale,
+                                              void* encT, float* t_vals, rtxn_stream_t stream) {
+  RTXN_REQUIRE(m && m->cfg.encoding == RTXN_ENC_FREQUENCY, "rtxn_encode_frequency_segments: model has no frequency encoding");
+  RTXN_REQUIRE(m->cfg.n_pos_dims == 3 && m->cfg.n_dir_dims == 2, "rtxn_encode_frequency_segments: needs 3 + 2 input dimensions");
+  int rc = check_segments("rtxn_encode_frequency_segments", start_points, end_points, seg_view, n_segments, sample_type);
+  if (rc != RTXN_OK) return rc;
+  RTXN_DEVICE_OR_FAIL();
+  if (n_segments == 0) return RTXN_OK;
+  RTXN_REQUIRE(encT, "rtxn_encode_frequency_segments: NULL buffer");
+  const SampleSrc src{nullptr, start_points, end_points, seg_view, sample_type == RTXN_SAMPLING_MIDPOINT_WORLD};
+  return encode_frequency_impl(m, src, encT, t_vals, t_scale, n_segments * 32, stream);
 }
 
 extern "C" int rtxn_mlp_train_forward(const rtxn_mlp* m, const void* encT, long n_samples, void* workspace,
@@ -1436,6 +1499,17 @@ extern "C" int rtxn_hashgrid_encoded_width(const rtxn_hashgrid* g, int n_dir_fre
   return (g->cfg.n_levels * g->cfg.n_features + 4 * n_dir_freqs + 15) / 16 * 16;
 }
 
+static int hashgrid_encode_impl(const rtxn_hashgrid* g, int n_dir_freqs, const void* table_fp16, const SampleSrc& src, void* encT,
+                                float* t_vals, float t_scale, long n_samples, rtxn_stream_t stream) {
+  const long Sp = padded(n_samples);
+  const int E = rtxn_hashgrid_encoded_width(g, n_dir_freqs);
+  hashgrid_encode_kernel<<<dim3((unsigned)(Sp / kThreads), (unsigned)(g->cfg.n_levels + 1)), kThreads, 0, rtxn::as_stream(stream)>>>(
+      levels_of(g), n_dir_freqs, static_cast<const _Float16*>(table_fp16), src, static_cast<_Float16*>(encT), t_vals, t_scale,
+      n_samples, Sp, E);
+  RTXN_LAUNCH_CHECK("hashgrid_encode_kernel");
+  return RTXN_OK;
+}
+
 extern "C" int rtxn_hashgrid_encode(const rtxn_hashgrid* g, int n_dir_freqs, const void* table_fp16, const float* input,
                                     void* encT, long n_samples, rtxn_stream_t stream) {
   RTXN_REQUIRE(g && n_dir_freqs >= 0 && n_dir_freqs <= 16, "rtxn_hashgrid_encode: bad argument");
@@ -1443,52 +1517,49 @@ extern "C" int rtxn_hashgrid_encode(const rtxn_hashgrid* g, int n_dir_freqs, con
   RTXN_DEVICE_OR_FAIL();
   if (n_samples == 0) return RTXN_OK;
   RTXN_REQUIRE(table_fp16 && input && encT, "rtxn_hashgrid_encode: NULL buffer");
-  const long Sp = padded(n_samples);
-  const int E = rtxn_hashgrid_encoded_width(g, n_dir_freqs);
-  hashgrid_encode_kernel<<<dim3((unsigned)(Sp / kThreads), (unsigned)(g->cfg.n_levels + 1)), kThreads, 0, rtxn::as_stream(stream)>>>(
-      levels_of(g), n_dir_freqs, static_cast<const _Float16*>(table_fp16), input, static_cast<_Float16*>(encT), n_samples, Sp, E);
-  RTXN_LAUNCH_CHECK("hashgrid_encode_kernel");
-  return RTXN_OK;
+  const SampleSrc src{input, nullptr, nullptr, nullptr, 0};
+  return hashgrid_encode_impl(g, n_dir_freqs, table_fp16, src, encT, nullptr, 1.0f, n_samples, stream);
+}
+
+extern "C" int rtxn_hashgrid_encode_segments(const rtxn_hashgrid* g, int n_dir_freqs, const void* table_fp16,
+                                             const float* start_points, const float* end_points, const float* seg_view,
+                                             long n_segments, int sample_type, float t_scale, void* encT, float* t_vals,
+                                             rtxn_stream_t stream) {
+  RTXN_REQUIRE(g && n_dir_freqs >= 0 && n_dir_freqs <= 16, "rtxn_hashgrid_encode_segments: bad argument");
+  int rc = check_segments("rtxn_hashgrid_encode_segments", start_points, end_points, seg_view, n_segments, sample_type);
+  if (rc != RTXN_OK) return rc;
+  RTXN_DEVICE_OR_FAIL();
+  if (n_segments == 0) return RTXN_OK;
+  RTXN_REQUIRE(table_fp16 && encT, "rtxn_hashgrid_encode_segments: NULL buffer");
+  const SampleSrc src{nullptr, start_points, end_points, seg_view, sample_type == RTXN_SAMPLING_MIDPOINT_WORLD};
+  return hashgrid_encode_impl(g, n_dir_freqs, table_fp16, src, encT, t_vals, t_scale, n_segments * 32, stream);
 }
 
 // dtable_hashed_half == NULL: every level into the fp32 table.  Otherwise (n_features == 2): the hashed levels go to the fp16
 // buffer, which holds the parameters from the first hashed level on.
-static int hashgrid_backward_impl(const rtxn_hashgrid* g, const float* input, const void* dencT, long n_samples,
-                                  float* dtable, void* dtable_hashed_half, rtxn_stream_t stream, const char* who) {
+static int hashgrid_backward_impl(const rtxn_hashgrid* g, const SampleSrc& input, const void* dencT, long n_samples,
+                                  float* dtable, void* dtable_hashed_half, rtxn_stream_t stream) {
   const long Sp = padded(n_samples);
   const int NL = g->cfg.n_levels, F = g->cfg.n_features;
-  int n_small = 0;
-  while (n_small < NL && (long)g->size[n_small] * F <= kHgLdsFloats) ++n_small;
   int first_hashed = NL;
   for (int l = NL - 1; l >= 0; --l)
     if ((unsigned long long)g->res[l] * g->res[l] * g->res[l] > g->size[l]) first_hashed = l;
   const long hashed_lo = first_hashed < NL ? (long)g->offset[first_hashed] * F : g->n_params;
   if (!dtable_hashed_half) first_hashed = NL;          // everything fp32
-  if (n_small > first_hashed) n_small = first_hashed;  // mixed form: a hashed level goes to the fp16 table even when it would fit in LDS
   hipStream_t st = rtxn::as_stream(stream);
   const HgLevels lv = levels_of(g);
   const _Float16* de = static_cast<const _Float16*>(dencT);
-  _Float16* dh = static_cast<_Float16*>(dtable_hashed_half);
-  if (n_small > 0) {
-    size_t lds = 0;
-    for (int l = 0; l < n_small; ++l) lds = std::max(lds, (size_t)g->size[l] * F * sizeof(float));
-    RTXN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hashgrid_backward_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hashgrid_backward_kernel<true, false><<<dim3((unsigned)((n_samples + kHgChunk - 1) / kHgChunk), (unsigned)n_small), kThreads, lds, st>>>(
-        lv, 0, input, de, n_samples, Sp, dtable, nullptr, 0);
-    RTXN_LAUNCH_CHECK("hashgrid_backward_kernel<lds>");
-  }
   const unsigned sblocks = (unsigned)((n_samples + kThreads - 1) / kThreads);
-  if (first_hashed > n_small) {
-    hashgrid_backward_kernel<false, false><<<dim3(sblocks, (unsigned)(first_hashed - n_small)), kThreads, 0, st>>>(
-        lv, n_small, input, de, n_samples, Sp, dtable, nullptr, 0);
+  if (first_hashed > 0) {
+    hashgrid_backward_kernel<false><<<dim3(sblocks, (unsigned)first_hashed), kThreads, 0, st>>>(
+        lv, 0, input, de, n_samples, Sp, dtable, nullptr, 0);
     RTXN_LAUNCH_CHECK("hashgrid_backward_kernel");
   }
   if (first_hashed < NL) {
-    hashgrid_backward_kernel<false, true><<<dim3(sblocks, (unsigned)(NL - first_hashed)), kThreads, 0, st>>>(
-        lv, first_hashed, input, de, n_samples, Sp, dtable, dh, hashed_lo);
+    hashgrid_backward_kernel<true><<<dim3(sblocks, (unsigned)(NL - first_hashed)), kThreads, 0, st>>>(
+        lv, first_hashed, input, de, n_samples, Sp, dtable, static_cast<_Float16*>(dtable_hashed_half), hashed_lo);
     RTXN_LAUNCH_CHECK("hashgrid_backward_kernel<pk_f16>");
   }
-  (void)who;
   return RTXN_OK;
 }
 
@@ -1499,7 +1570,7 @@ extern "C" int rtxn_hashgrid_backward(const rtxn_hashgrid* g, const float* input
   RTXN_DEVICE_OR_FAIL();
   if (n_samples == 0) return RTXN_OK;
   RTXN_REQUIRE(input && dencT && dtable, "rtxn_hashgrid_backward: NULL buffer");
-  return hashgrid_backward_impl(g, input, dencT, n_samples, dtable, nullptr, stream, "rtxn_hashgrid_backward");
+  return hashgrid_backward_impl(g, SampleSrc{input, nullptr, nullptr, nullptr, 0}, dencT, n_samples, dtable, nullptr, stream);
 }
 
 extern "C" int rtxn_hashgrid_backward_mixed(const rtxn_hashgrid* g, const float* input, const void* dencT, long n_samples,
@@ -1511,7 +1582,21 @@ extern "C" int rtxn_hashgrid_backward_mixed(const rtxn_hashgrid* g, const float*
   if (n_samples == 0) return RTXN_OK;
   RTXN_REQUIRE(input && dencT && dtable && dtable_hashed_half, "rtxn_hashgrid_backward_mixed: NULL buffer");
   RTXN_REQUIRE(((uintptr_t)dtable_hashed_half & 3) == 0, "rtxn_hashgrid_backward_mixed: fp16 table must be 4-byte aligned");
-  return hashgrid_backward_impl(g, input, dencT, n_samples, dtable, dtable_hashed_half, stream, "rtxn_hashgrid_backward_mixed");
+  return hashgrid_backward_impl(g, SampleSrc{input, nullptr, nullptr, nullptr, 0}, dencT, n_samples, dtable, dtable_hashed_half, stream);
+}
+
+extern "C" int rtxn_hashgrid_backward_segments(const rtxn_hashgrid* g, const float* start_points, const float* end_points,
+                                               long n_segments, int sample_type, const void* dencT, float* dtable,
+                                               void* dtable_hashed_half, rtxn_stream_t stream) {
+  RTXN_REQUIRE(g, "rtxn_hashgrid_backward_segments: NULL grid");
+  int rc = check_segments("rtxn_hashgrid_backward_segments", start_points, end_points, start_points, n_segments, sample_type);
+  if (rc != RTXN_OK) return rc;
+  RTXN_REQUIRE(!dtable_hashed_half || g->cfg.n_features == 2, "rtxn_hashgrid_backward_segments: packed fp16 atomics need n_features == 2 (got %d)", g->cfg.n_features);
+  RTXN_DEVICE_OR_FAIL();
+  if (n_segments == 0) return RTXN_OK;
+  RTXN_REQUIRE(dencT && dtable, "rtxn_hashgrid_backward_segments: NULL buffer");
+  const SampleSrc src{nullptr, start_points, end_points, nullptr, sample_type == RTXN_SAMPLING_MIDPOINT_WORLD};
+  return hashgrid_backward_impl(g, src, dencT, n_segments * 32, dtable, dtable_hashed_half, stream);
 }
 
 extern "C" int rtxn_l2_loss(const float* pred, const float* target, long n, float loss_scale, float* values,

@@ -102,6 +102,10 @@ class Trainer:
         # three-kernel path (saved activations, dgrad chain, weight-gradient GEMM) for A/B runs.
         import os
         self.recompute = self.net.recompute_supported() and os.environ.get("RTXN_TRAIN_RECOMPUTE", "1") != "0"
+        # launchSampler folded into the encoders / the hash scatter (they form the samples from the packed segments): the
+        # float[S][5] samples and the separate sampler launch exist only for teacher rendering (render_rays(radiance_fn)) and
+        # for tests (materialize_samples()).  RTXN_TRAIN_FOLD_SAMPLER=0: the reference's stage order, sampler first.
+        self.fold_sampler = os.environ.get("RTXN_TRAIN_FOLD_SAMPLER", "1") != "0"
         # ---- per-step buffers at capacity ---------------------------------------------------------
         B = batch_rays
         self.max_segments = int(max_segments) if max_segments else 64 * B
@@ -118,6 +122,7 @@ class Trainer:
         self.scan_ws = torch.empty((api._lib.lib().rtxn_scan_workspace_bytes(B) + 3) // 4, dtype=torch.int32, device=d)
         self.start = torch.empty((M, 3), device=d)
         self.end = torch.empty((M, 3), device=d)
+        self.seg_view = torch.empty((M, 2), device=d)      # (theta, phi) of each segment's ray, written by the traversal
         self.samples = torch.empty((M * K, 5), device=d)
         self.t_vals = torch.empty(M * K, device=d)
         Sp = api.padded_samples(M * K)
@@ -141,7 +146,7 @@ class Trainer:
         with _Stage(self, "scan"):
             api.scan_hits(self.num_hits[:n], self.indices[:n], self.total, self.scan_ws)
         with _Stage(self, "trace_write"):
-            api.trace_grid(None, indices=self.indices, start_points=self.start, end_points=self.end,
+            api.trace_grid(None, indices=self.indices, start_points=self.start, end_points=self.end, seg_view=self.seg_view,
                            num_stored=self.num_stored, segment_capacity=self.max_segments, **kw)
         P = int(self.total.item())            # the reference synchronises here too (thrust::reduce, main.cu:632)
         if P > self.max_segments:
@@ -156,17 +161,34 @@ class Trainer:
             P = self.max_segments
         return P
 
+    def _stype(self):
+        return api.SAMPLING_MIDPOINT_WORLD if self.mode == "nerf" else api.SAMPLING_REGULAR
+
     def _sample(self, n, P):
-        stype = api.SAMPLING_MIDPOINT_WORLD if self.mode == "nerf" else api.SAMPLING_REGULAR
+        """The standalone sampler (sampler/sampler.h:19-30): float[S][5] samples + t_vals."""
         with _Stage(self, "sampler"):
             api.launchSampler(self.start, self.end, self.view_dirs, self.t_vals, self.samples, n, self.R, self.num_stored,
-                              self.indices, stype)
+                              self.indices, self._stype())
             if self.mode == "nerf" and self.density_scale != 1.0:
                 self.t_vals[:P * api.NUM_SAMPLES_PER_SEGMENT].mul_(self.density_scale)
 
-    def _forward(self, S):
+    def materialize_samples(self, n):
+        """Tests / inspection: run the standalone sampler over the current batch's segments (fills self.samples; t_vals are
+        rewritten with the same values the folded path produced)."""
+        self._sample(n, min(int(self.total.item()), self.max_segments))
+
+    def _forward(self, S, from_samples=False):
+        P = S // api.NUM_SAMPLES_PER_SEGMENT
+        t_scale = self.density_scale if self.mode == "nerf" else 1.0
         with _Stage(self, "encode"):
-            if self.encoding == "hash":
+            if self.fold_sampler and not from_samples:      # sampler + encoder in one pass over the segments; writes t_vals too
+                if self.encoding == "hash":
+                    self.hg.encode_segments(self.table, self.start, self.end, self.seg_view, P, self._stype(), self.encT,
+                                            self.t_vals, t_scale)
+                else:
+                    self.net.encode_frequency_segments(self.start, self.end, self.seg_view, P, self._stype(), self.encT,
+                                                       self.t_vals, t_scale)
+            elif self.encoding == "hash":
                 self.hg.encode(self.table, self.samples[:S], self.encT)
             else:
                 self.net.encode_frequency(self.samples[:S], self.encT)
@@ -181,7 +203,8 @@ class Trainer:
         n = rays_o.shape[0]
         P = self._segments(rays_o, rays_d, n)
         S = P * api.NUM_SAMPLES_PER_SEGMENT
-        self._sample(n, P)
+        if radiance_fn is not None or not self.fold_sampler:
+            self._sample(n, P)
         if S:
             if radiance_fn is None:
                 self._forward(S)
@@ -215,7 +238,8 @@ class Trainer:
             if finish and self.encoding == "hash":
                 self._finish_table_grad()
             return 0
-        self._sample(n, P)
+        if not self.fold_sampler:
+            self._sample(n, P)
         self._forward(S)
         with _Stage(self, "composite_fwd"):
             api.launch_volrender_cuda(None, self.radiance, self.num_stored, self.indices, self.t_vals, n, K,
@@ -232,7 +256,10 @@ class Trainer:
                 self.net.train_backward(self.encT, self.out, self.dout, S, self.ws, self.dparams, self.dencT)
         if self.encoding == "hash":
             with _Stage(self, "hash_bwd"):
-                if self.hash_fp16:
+                if self.fold_sampler:
+                    self.hg.backward_segments(self.start, self.end, P, self._stype(), self.dencT, self.dtable,
+                                              self.dtable_h if self.hash_fp16 else None)
+                elif self.hash_fp16:
                     self.hg.backward_mixed(self.samples[:S], self.dencT, self.dtable, self.dtable_h)
                 else:
                     self.hg.backward(self.samples[:S], self.dencT, self.dtable)

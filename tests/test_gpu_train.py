@@ -258,3 +258,58 @@ def test_recompute_path_is_refused_where_it_does_not_fit(gpu):
                                          torch.zeros((256, 16), dtype=torch.float16, device="cuda"),
                                          torch.zeros((256, 4), dtype=torch.float16, device="cuda"), 256,
                                          torch.zeros(net.n_params(), device="cuda"))
+
+
+@pytest.mark.parametrize("stype", [0, 3])
+def test_sampler_folded_into_encoders_and_scatter(gpu, oracle, stype):
+    """rtxn_*_segments (launchSampler folded into its consumers) == rtxn_sample followed by the sample-input entry points:
+    encodings and t_vals bit for bit, the scatter up to atomics order."""
+    torch = gpu
+    from rtx_nerf_amd import api
+    rng = np.random.default_rng(stype)
+    B, P = 300, 0
+    nh = rng.integers(0, 9, B).astype(np.int32)
+    P = int(nh.sum())
+    idx = np.concatenate([[0], np.cumsum(nh)[:-1]]).astype(np.int32)
+    sp = rng.uniform(-1, 1, (P, 3)).astype(np.float32)
+    ep = (sp + rng.uniform(-0.05, 0.05, (P, 3))).astype(np.float32)
+    vd = np.stack([rng.uniform(0, 3.1, B), rng.uniform(-3.1, 3.1, B)], 1).astype(np.float32)
+    sv = vd[np.repeat(np.arange(B), nh)]
+    S = P * 32
+    sp_d, ep_d, vd_d, sv_d = (_dev(torch, a) for a in (sp, ep, vd, sv))
+    samples = torch.zeros((S, 5), device="cuda")
+    t_ref = torch.zeros(S, device="cuda")
+    api.launchSampler(sp_d, ep_d, vd_d, t_ref, samples, B, 8, _dev(torch, nh), _dev(torch, idx), stype)
+    scale = 37.5
+    if stype == 3:
+        t_ref.mul_(scale)
+    Sp = api.padded_samples(S)
+    # hash grid
+    hg = api.HashGrid(8, 2, 14, 8, 1.6, n_dir_freqs=4)
+    table = _dev(torch, rng.uniform(-1, 1, hg.n_params()).astype(np.float16))
+    E = hg.encoded_width()
+    enc_ref = hg.encode(table, samples)
+    enc = torch.full((E, Sp), 3.0, dtype=torch.float16, device="cuda")
+    t_got = torch.full((S,), -1.0, device="cuda")
+    hg.encode_segments(table, sp_d, ep_d, sv_d, P, stype, enc, t_got, scale)
+    assert torch.equal(enc, enc_ref) and torch.equal(t_got, t_ref)
+    denc = _dev(torch, np.pad((rng.standard_normal((E, S)) * 0.1).astype(np.float16), ((0, 0), (0, Sp - S))))
+    for half in (False, True):
+        lo = hg.hashed_offset()
+        a32, b32 = torch.zeros(hg.n_params(), device="cuda"), torch.zeros(hg.n_params(), device="cuda")
+        a16 = torch.zeros(hg.n_params() - lo, dtype=torch.float16, device="cuda") if half else None
+        b16 = torch.zeros(hg.n_params() - lo, dtype=torch.float16, device="cuda") if half else None
+        hg.backward_segments(sp_d, ep_d, P, stype, denc, a32, a16)
+        if half:
+            hg.backward_mixed(samples, denc, b32, b16)
+            assert float((a16.float() - b16.float()).abs().max()) <= 4e-3 * float(b16.float().abs().max())
+        else:
+            hg.backward(samples, denc, b32)
+        assert float((a32 - b32).abs().max()) <= 1e-5 * float(b32.abs().max()) and float(b32.abs().max()) > 0
+    # frequency encoding
+    net = api.Network(n_neurons=64, n_hidden_layers=2)
+    f_ref = net.encode_frequency(samples)
+    f_got = torch.full((112, Sp), 3.0, dtype=torch.float16, device="cuda")
+    t_got.fill_(-1.0)
+    net.encode_frequency_segments(sp_d, ep_d, sv_d, P, stype, f_got, t_got, scale)
+    assert torch.equal(f_got, f_ref) and torch.equal(t_got, t_ref)

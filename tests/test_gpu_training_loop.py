@@ -46,6 +46,9 @@ def test_config3_training_step_matches_oracle_chain(gpu, oracle):
     loss = float(tr.step(o, d, tgt).item())
     P = int(tr.total.item())
     S = P * 32
+    t_folded = tr.t_vals[:S].clone()      # written by the encoder (sampler folded in)
+    tr.materialize_samples(B)             # the standalone sampler over the same segments, for the comparison below
+    assert torch.equal(tr.t_vals[:S], t_folded)
 
     # ---- the same step from oracle pieces -------------------------------------------------------
     O = oracle
@@ -117,6 +120,9 @@ def test_compat_training_step_matches_oracle_chain(gpu, oracle):
     P = int(tr.total.item())
     S = P * 32
     assert S > 20_000 and tr.step_count == 1
+    t_folded = tr.t_vals[:S].clone()
+    tr.materialize_samples(B)
+    assert torch.equal(tr.t_vals[:S], t_folded)
 
     O = oracle
     pk = O.trace_packed(rays_o=o.cpu().numpy(), rays_d=d.cpu().numpy(), R=R, occ=words, mode=1)
