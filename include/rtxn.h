@@ -188,6 +188,14 @@ int rtxn_volrender_bwd(const float* loss_values, const void* loss_gradients,
                        const int* indices, int batch_size, int num_samples_per_hit,
                        void* radiance_gradients, int mode, rtxn_stream_t stream);
 
+/* launch_volrender_cuda + loss->evaluate (L2) + launch_volrender_backward_cuda of a training batch (main.cu:737-767) in one
+ * launch, RTXN_VR_NERF arithmetic: pixels float[B*3], loss_gradients_half half[B*3] (may be NULL), *loss_sum (device float,
+ * may be NULL) = sum of (pixel - target)^2 / (3B), radiance_gradients half[P*K*4].  Same values as the three entry points
+ * called one after the other up to fp32 rounding of one dot product. */
+int rtxn_volrender_l2_train(const float* network_outputs, const float* ray_hit, const int* num_hits, const int* indices,
+                            int batch_size, int num_samples_per_hit, const float* target, float loss_scale, float* pixels,
+                            void* loss_gradients_half, float* loss_sum, void* radiance_gradients, rtxn_stream_t stream);
+
 /* ---- MLP (tiny-cuda-nn surface used by main.cu) ------------------------------- */
 /* Replaces tcnn::create_from_config(5, 4, config) (main.cu:35-69,325),
  * network->n_params / set_params / initialize_params (main.cu:327-349),
@@ -235,6 +243,9 @@ int rtxn_mlp_initialize_params(const rtxn_mlp* m, uint64_t seed, float* host_par
 /* Point the model at device fp16 params (tcnn layout); re-packs them into the
  * MFMA fragment order the kernels read.  Call again after every update. */
 int rtxn_mlp_set_params(rtxn_mlp* m, const void* params_fp16, rtxn_stream_t stream);
+/* The same for a training loop's per-step update: re-packs what the rtxn_mlp_train_* entry points read and leaves the fused
+ * inference kernels' copy as it was -- call rtxn_mlp_set_params before rendering with the rtxn_mlp_forward* family again. */
+int rtxn_mlp_set_params_training(rtxn_mlp* m, const void* params_fp16, rtxn_stream_t stream);
 /* network->forward: input float[N*5] (column-major 5xN = the sampler's AoS),
  * output half[N*16] (column-major 16xN). */
 int rtxn_mlp_forward(const rtxn_mlp* m, const float* input, void* output_half, long n, rtxn_stream_t stream);
@@ -369,6 +380,10 @@ int rtxn_l2_loss(const float* pred, const float* target, long n, float loss_scal
 /* optimizer->step (tcnn "Adam", main.cu:40-46,787): fp32 master weights + fp16 copy, fp32 gradients. */
 int rtxn_adam_step(long n, float* master, void* params_fp16, const float* grads, float* m, float* v, int step,
                    float lr, float beta1, float beta2, float eps, float loss_scale, rtxn_stream_t stream);
+
+/* rtxn_adam_step with the gradient in fp16 (the hashed levels' table gradient, rtxn_hashgrid_backward_mixed). */
+int rtxn_adam_step_half_grads(long n, float* master, void* params_fp16, const void* grads_fp16, float* m, float* v, int step,
+                              float lr, float beta1, float beta2, float eps, float loss_scale, rtxn_stream_t stream);
 
 /* fp32 <-> fp16 copies of a gradient block on the device (no counterpart in the reference, which is single-GPU): the
  * data-parallel exchange sends the hashed levels' gradient in fp16 -- tiny-cuda-nn holds that gradient in fp16 throughout. */

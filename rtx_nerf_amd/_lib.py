@@ -95,6 +95,7 @@ SYMBOLS = {
     "rtxn_sample": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _P]),
     "rtxn_volrender_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _I, _P]),
     "rtxn_volrender_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P]),
+    "rtxn_volrender_l2_train": (_I, [_P, _P, _P, _P, _I, _I, _P, _F, _P, _P, _P, _P, _P]),
     "rtxn_mlp_create": (_I, [C.POINTER(MlpConfig), C.POINTER(_P)]),
     "rtxn_mlp_destroy": (_I, [_P]),
     "rtxn_mlp_n_params": (_L, [_P]),
@@ -104,6 +105,7 @@ SYMBOLS = {
     "rtxn_mlp_encoded_width": (_I, [_P]),
     "rtxn_mlp_initialize_params": (_I, [_P, C.c_uint64, _P]),
     "rtxn_mlp_set_params": (_I, [_P, _P, _P]),
+    "rtxn_mlp_set_params_training": (_I, [_P, _P, _P]),
     "rtxn_mlp_forward": (_I, [_P, _P, _P, _L, _P]),
     "rtxn_mlp_forward_radiance": (_I, [_P, _P, _P, _L, _P]),
     "rtxn_mlp_forward_segments": (_I, [_P, _P, _P, _P, _P, _L, _P, _P, _P]),
@@ -135,6 +137,7 @@ SYMBOLS = {
     "rtxn_mlp_train_backward_recompute": (_I, [_P, _P, _P, _P, _L, _P, _P, _P]),
     "rtxn_l2_loss": (_I, [_P, _P, _L, _F, _P, _P, _P, _P]),
     "rtxn_adam_step": (_I, [_L, _P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _P]),
+    "rtxn_adam_step_half_grads": (_I, [_L, _P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _P]),
     "rtxn_load_images_json": (_I, [C.c_char_p, C.c_char_p, _I, C.POINTER(ImageDataset)]),
     "rtxn_free_image_dataset": (None, [C.POINTER(ImageDataset)]),
     "rtxn_load_llff": (_I, [C.c_char_p, _I, _I, C.POINTER(ImageDataset), C.POINTER(C.POINTER(C.c_float))]),

@@ -176,6 +176,17 @@ def launch_volrender_backward_cuda(loss_values, loss_gradients, sampled_points_r
           "rtxn_volrender_bwd")
 
 
+def volrender_l2_train(network_outputs, ray_hit, num_hits, indices, batch_size, num_samples_per_hit, target, loss_scale, pixels,
+                       loss_gradients, loss_sum, radiance_gradients):
+    """launch_volrender_cuda + L2 loss->evaluate + launch_volrender_backward_cuda (main.cu:737-767) in one launch (VR_NERF)."""
+    check(_lib.lib().rtxn_volrender_l2_train(_ptr(network_outputs, torch.float32, "network_outputs"), _ptr(ray_hit, torch.float32, "ray_hit"),
+                                             _ptr(num_hits, torch.int32, "num_hits"), _ptr(indices, torch.int32, "indices"), batch_size,
+                                             num_samples_per_hit, _ptr(target, torch.float32, "target"), loss_scale,
+                                             _ptr(pixels, torch.float32, "pixels"), _ptr(loss_gradients, torch.float16, "loss_gradients"),
+                                             _ptr(loss_sum, torch.float32, "loss_sum"), _ptr(radiance_gradients, torch.float16, "radiance_gradients"),
+                                             _stream()), "rtxn_volrender_l2_train")
+
+
 # --------------------------------------------------------------------------- MLP
 class Network:
     """tcnn::create_from_config(n_input_dims=5, n_output_dims=4, config) (main.cu:35-69,325)."""
@@ -230,6 +241,15 @@ class Network:
         self.params = params_fp16
         check(_lib.lib().rtxn_mlp_set_params(self._h, _ptr(params_fp16, torch.float16, "params"), _stream()),
               "rtxn_mlp_set_params")
+
+    def set_params_training(self, params_fp16):
+        """Per-step update inside a training loop: re-packs the training kernels' weights only (set_params() again before
+        rendering with the fused inference kernels)."""
+        if params_fp16.numel() != self.n_params():
+            raise _lib.RtxnError(f"params has {params_fp16.numel()} elements, model needs {self.n_params()}")
+        self.params = params_fp16
+        check(_lib.lib().rtxn_mlp_set_params_training(self._h, _ptr(params_fp16, torch.float16, "params"), _stream()),
+              "rtxn_mlp_set_params_training")
 
     def forward(self, input_batch, output=None):
         """network->forward(stream, input(5xN), &output(16xN)) (main.cu:715-721)."""
@@ -474,6 +494,14 @@ def adam_step(master, params_fp16, grads, m, v, step, lr=1e-3, beta1=0.9, beta2=
                                     _ptr(params_fp16, torch.float16, "params"), _ptr(grads, torch.float32, "grads"),
                                     _ptr(m, torch.float32, "m"), _ptr(v, torch.float32, "v"), step, lr, beta1, beta2, eps,
                                     loss_scale, _stream()), "rtxn_adam_step")
+
+
+def adam_step_half_grads(master, params_fp16, grads_fp16, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, loss_scale=1.0):
+    """adam_step with an fp16 gradient."""
+    check(_lib.lib().rtxn_adam_step_half_grads(master.numel(), _ptr(master, torch.float32, "master"),
+                                               _ptr(params_fp16, torch.float16, "params"), _ptr(grads_fp16, torch.float16, "grads"),
+                                               _ptr(m, torch.float32, "m"), _ptr(v, torch.float32, "v"), step, lr, beta1, beta2, eps,
+                                               loss_scale, _stream()), "rtxn_adam_step_half_grads")
 
 
 def convert_f32_to_f16(src, dst):

@@ -1524,15 +1524,26 @@ extern "C" int rtxn_mlp_initialize_params(const rtxn_mlp* m, uint64_t seed, floa
   return RTXN_OK;
 }
 
+static int set_params_impl(rtxn_mlp* m, const void* params_fp16, rtxn_stream_t stream, bool inference);
+
 extern "C" int rtxn_mlp_set_params(rtxn_mlp* m, const void* params_fp16, rtxn_stream_t stream) {
   RTXN_REQUIRE(m && params_fp16, "rtxn_mlp_set_params: NULL argument");
+  return set_params_impl(m, params_fp16, stream, true);
+}
+
+extern "C" int rtxn_mlp_set_params_training(rtxn_mlp* m, const void* params_fp16, rtxn_stream_t stream) {
+  RTXN_REQUIRE(m && params_fp16, "rtxn_mlp_set_params_training: NULL argument");
+  return set_params_impl(m, params_fp16, stream, false);
+}
+
+static int set_params_impl(rtxn_mlp* m, const void* params_fp16, rtxn_stream_t stream, bool inference) {
   RTXN_DEVICE_OR_FAIL();
   if (m->packed_bytes && !m->packed) RTXN_HIP(hipMalloc(&m->packed, m->packed_bytes));
   if (!m->packed_train) RTXN_HIP(hipMalloc(&m->packed_train, m->packed_train_bytes));
   if (!m->packed_t) RTXN_HIP(hipMalloc(&m->packed_t, m->packed_t_bytes));
   void* dst[3] = {m->packed, m->packed_train, m->packed_t};
   const size_t bytes[3] = {m->packed_bytes, m->packed_train_bytes, m->packed_t_bytes};
-  for (int mode = 0; mode < 3; ++mode) {
+  for (int mode = inference ? 0 : 1; mode < 3; ++mode) {
     if (!bytes[mode]) continue;
     const long total = (long)(bytes[mode] / 2);
     const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
@@ -1541,7 +1552,7 @@ extern "C" int rtxn_mlp_set_params(rtxn_mlp* m, const void* params_fp16, rtxn_st
                                                              m->enc_padded, m->k0, m->cfg.n_hidden_layers, mode);
     RTXN_LAUNCH_CHECK("pack_kernel");
   }
-  if (m->packed16_bytes) {
+  if (m->packed16_bytes && inference) {
     if (!m->packed16) RTXN_HIP(hipMalloc(&m->packed16, m->packed16_bytes));
     const long total = (long)(m->packed16_bytes / 2);
     const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);

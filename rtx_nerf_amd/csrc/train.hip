@@ -1156,6 +1156,23 @@ __global__ __launch_bounds__(kThreads) void f16_to_f32_kernel(const _Float16* __
   }
 }
 
+// Adam reading an fp16 gradient (the hashed levels' table gradient lives in fp16): same update as adam_kernel
+__global__ __launch_bounds__(kThreads) void adam_half_grads_kernel(long n, float* __restrict__ master, __half* __restrict__ params,
+                                                                   const __half* __restrict__ grads, float* __restrict__ m,
+                                                                   float* __restrict__ v, float lr_eff, float beta1, float beta2,
+                                                                   float eps, float inv_loss_scale) {
+  for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
+    const float g = __half2float(grads[i]) * inv_loss_scale;
+    const float mi = beta1 * m[i] + (1.0f - beta1) * g;
+    const float vi = beta2 * v[i] + (1.0f - beta2) * g * g;
+    m[i] = mi;
+    v[i] = vi;
+    const float w = master[i] - lr_eff * mi / (sqrtf(vi) + eps);
+    master[i] = w;
+    params[i] = __float2half(w);
+  }
+}
+
 int check_train(const rtxn_mlp* m, const char* who) {
   if (!m) { rtxn::set_error("%s: NULL model", who); return RTXN_ERR_INVALID; }
   if (m->cfg.n_neurons != 64 && m->cfg.n_neurons != 128) {
@@ -1625,5 +1642,22 @@ extern "C" int rtxn_adam_step(long n, float* master, void* params_fp16, const fl
   adam_kernel<<<blocks, kThreads, 0, rtxn::as_stream(stream)>>>(n, master, static_cast<__half*>(params_fp16), grads, m, v, lr_eff,
                                                                beta1, beta2, eps, 1.0f / loss_scale);
   RTXN_LAUNCH_CHECK("adam_kernel");
+  return RTXN_OK;
+}
+
+extern "C" int rtxn_adam_step_half_grads(long n, float* master, void* params_fp16, const void* grads_fp16, float* m, float* v,
+                                         int step, float lr, float beta1, float beta2, float eps, float loss_scale,
+                                         rtxn_stream_t stream) {
+  RTXN_REQUIRE(n >= 0 && step >= 1, "rtxn_adam_step_half_grads: n = %ld, step = %d", n, step);
+  RTXN_REQUIRE(loss_scale != 0.0f, "rtxn_adam_step_half_grads: loss_scale = 0");
+  RTXN_DEVICE_OR_FAIL();
+  if (n == 0) return RTXN_OK;
+  RTXN_REQUIRE(master && params_fp16 && grads_fp16 && m && v, "rtxn_adam_step_half_grads: NULL buffer");
+  const float lr_eff = lr * sqrtf(1.0f - powf(beta2, (float)step)) / (1.0f - powf(beta1, (float)step));
+  const unsigned blocks = (unsigned)((n + kThreads - 1) / kThreads < 2048 ? (n + kThreads - 1) / kThreads : 2048);
+  adam_half_grads_kernel<<<blocks, kThreads, 0, rtxn::as_stream(stream)>>>(n, master, static_cast<__half*>(params_fp16),
+                                                                          static_cast<const __half*>(grads_fp16), m, v, lr_eff, beta1,
+                                                                          beta2, eps, 1.0f / loss_scale);
+  RTXN_LAUNCH_CHECK("adam_half_grads_kernel");
   return RTXN_OK;
 }

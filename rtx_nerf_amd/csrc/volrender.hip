@@ -319,6 +319,203 @@ __global__ __launch_bounds__(256) void volrender_bwd_nerf_kernel(const __half* _
   }
 }
 
+// launch_volrender_cuda + loss->evaluate (L2) + launch_volrender_backward_cuda of one training batch in ONE launch
+// (RTXN_VR_NERF).  A ray's loss gradient depends on its own pixel only, and the first sweep of the exact backward --
+// S = sum_k w_k (g . c_k) -- is the forward's pixel dotted with g, so the forward sweep serves both: sweep 1 composites the
+// pixel, the wave forms d = pixel - target, the L2 value and g = half(loss_scale 2 d / n) (the fp16 rounding
+// network->backward sees, main.cu:759), sweep 2 writes the per-sample gradients.  Three launches and one pass over the
+// radiance fewer than the separate entry points; same arithmetic per sample (S differs by fp32 rounding: g . pixel
+// instead of the per-sample sum).
+__global__ __launch_bounds__(256) void volrender_l2_fused_kernel(const float4* __restrict__ radiance, const float* __restrict__ step_len,
+                                                                 const int* __restrict__ num_hits, const int* __restrict__ indices,
+                                                                 int batch_size, int K, const float* __restrict__ target,
+                                                                 float loss_scale, float* __restrict__ pixels,
+                                                                 __half* __restrict__ loss_gradients, float* __restrict__ loss_sum,
+                                                                 half4* __restrict__ grads) {
+  const int lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= batch_size) return;
+  const long base = (long)indices[ray] * K;
+  const long n = (long)num_hits[ray] * K;
+  const float inv_n = 1.0f / (float)(3L * batch_size);
+  // sweep 1: the pixel
+  float T_carry = 0.0f, ar = 0.0f, ag = 0.0f, ab = 0.0f;
+  for (long s0 = 0; s0 < n; s0 += 64) {
+    const bool act = s0 + lane < n;
+    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+    float d = 0.0f;
+    if (act) {
+      c = radiance[base + s0 + lane];
+      d = step_len[base + s0 + lane];
+    }
+    const float x = d * c.w;
+    const float incl = wave_incl_scan_f(x, lane);
+    const float w = act ? expf(-(T_carry + incl - x)) * (1.0f - expf(-x)) : 0.0f;
+    ar = fmaf(w, c.x, ar);
+    ag = fmaf(w, c.y, ag);
+    ab = fmaf(w, c.z, ab);
+    T_carry += __shfl(incl, 63, 64);
+  }
+  ar = wave_sum(ar);
+  ag = wave_sum(ag);
+  ab = wave_sum(ab);
+  // L2 (tcnn "L2": values = d^2 / n, gradients = loss_scale * 2 d / n, rounded to fp16)
+  const float d0 = ar - target[3 * (long)ray], d1 = ag - target[3 * (long)ray + 1], d2 = ab - target[3 * (long)ray + 2];
+  const __half h0 = __float2half(loss_scale * 2.0f * d0 * inv_n), h1 = __float2half(loss_scale * 2.0f * d1 * inv_n),
+               h2 = __float2half(loss_scale * 2.0f * d2 * inv_n);
+  const float g0 = __half2float(h0), g1 = __half2float(h1), g2 = __half2float(h2);
+  if (lane == 0) {
+    pixels[3 * (long)ray] = ar;
+    pixels[3 * (long)ray + 1] = ag;
+    pixels[3 * (long)ray + 2] = ab;
+    if (loss_gradients) {
+      loss_gradients[3 * (long)ray] = h0;
+      loss_gradients[3 * (long)ray + 1] = h1;
+      loss_gradients[3 * (long)ray + 2] = h2;
+    }
+    if (loss_sum) atomicAdd(loss_sum, (d0 * d0 + d1 * d1 + d2 * d2) * inv_n);
+  }
+  const float S = g0 * ar + g1 * ag + g2 * ab;     // = sum_k w_k (g . c_k)
+  // sweep 2: per-sample gradients (volrender_bwd_nerf_kernel's second sweep)
+  T_carry = 0.0f;
+  float P_carry = 0.0f;
+  for (long s0 = 0; s0 < n; s0 += 64) {
+    const bool act = s0 + lane < n;
+    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+    float d = 0.0f;
+    if (act) {
+      c = radiance[base + s0 + lane];
+      d = step_len[base + s0 + lane];
+    }
+    const float x = d * c.w;
+    const float incl = wave_incl_scan_f(x, lane);
+    const float Ti = expf(-(T_carry + incl - x));
+    const float ex = expf(-x);
+    const float a = 1.0f - ex;
+    const float gc = g0 * c.x + g1 * c.y + g2 * c.z;
+    const float wgc = Ti * a * gc;
+    const float pincl = P_carry + wave_incl_scan_f(wgc, lane);
+    if (act) {
+      const float suffix = S - pincl;
+      half4 o;
+      o.x = __float2half(g0 * Ti * a);
+      o.y = __float2half(g1 * Ti * a);
+      o.z = __float2half(g2 * Ti * a);
+      o.w = __float2half(d * (Ti * ex * gc - suffix));
+      grads[base + s0 + lane] = o;
+    }
+    T_carry += __shfl(incl, 63, 64);
+    P_carry = __shfl(pincl, 63, 64);
+  }
+}
+
+// The same with two samples per lane (128 per step) and the next step's loads in flight under the scans.  A training batch
+// is a few thousand rays, far fewer waves than the chip holds, so this launch takes as long as its LONGEST ray's chain of
+// dependent steps (load -> scan -> exp, twice over: two sweeps): halving the steps and hiding the load is what shortens it.
+// Needs an even K.
+__global__ __launch_bounds__(256) void volrender_l2_fused_pair_kernel(const float4* __restrict__ radiance, const float* __restrict__ step_len,
+                                                                      const int* __restrict__ num_hits, const int* __restrict__ indices,
+                                                                      int batch_size, int K, const float* __restrict__ target,
+                                                                      float loss_scale, float* __restrict__ pixels,
+                                                                      __half* __restrict__ loss_gradients, float* __restrict__ loss_sum,
+                                                                      half4* __restrict__ grads) {
+  const int lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= batch_size) return;
+  const long base = (long)indices[ray] * K;
+  const long n = (long)num_hits[ray] * K;          // even
+  const float inv_n = 1.0f / (float)(3L * batch_size);
+  struct Pair { float4 c0, c1; float d0, d1; };
+  auto load = [&](long s0, Pair& p) {
+    const long i0 = s0 + 2 * lane;
+    p.c0 = p.c1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    p.d0 = p.d1 = 0.0f;
+    if (i0 < n) {
+      p.c0 = radiance[base + i0];
+      p.c1 = radiance[base + i0 + 1];
+      const float2 dd = *reinterpret_cast<const float2*>(step_len + base + i0);
+      p.d0 = dd.x;
+      p.d1 = dd.y;
+    }
+  };
+  // sweep 1: the pixel
+  float T_carry = 0.0f, ar = 0.0f, ag = 0.0f, ab = 0.0f;
+  Pair cur, nxt;
+  if (n > 0) load(0, cur);
+  for (long s0 = 0; s0 < n; s0 += 128) {
+    if (s0 + 128 < n) load(s0 + 128, nxt);
+    const float x0 = cur.d0 * cur.c0.w, x1 = cur.d1 * cur.c1.w;     // inactive lanes hold zeros: x = 0, w = 0
+    const float pr = x0 + x1;
+    const float incl = wave_incl_scan_f(pr, lane);
+    const float T0 = T_carry + (incl - pr);
+    const float w0 = expf(-T0) * (1.0f - expf(-x0)), w1 = expf(-(T0 + x0)) * (1.0f - expf(-x1));
+    ar = fmaf(w1, cur.c1.x, fmaf(w0, cur.c0.x, ar));
+    ag = fmaf(w1, cur.c1.y, fmaf(w0, cur.c0.y, ag));
+    ab = fmaf(w1, cur.c1.z, fmaf(w0, cur.c0.z, ab));
+    T_carry += __shfl(incl, 63, 64);
+    cur = nxt;
+  }
+  ar = wave_sum(ar);
+  ag = wave_sum(ag);
+  ab = wave_sum(ab);
+  const float e0 = ar - target[3 * (long)ray], e1 = ag - target[3 * (long)ray + 1], e2 = ab - target[3 * (long)ray + 2];
+  const __half h0 = __float2half(loss_scale * 2.0f * e0 * inv_n), h1 = __float2half(loss_scale * 2.0f * e1 * inv_n),
+               h2 = __float2half(loss_scale * 2.0f * e2 * inv_n);
+  const float g0 = __half2float(h0), g1 = __half2float(h1), g2 = __half2float(h2);
+  if (lane == 0) {
+    pixels[3 * (long)ray] = ar;
+    pixels[3 * (long)ray + 1] = ag;
+    pixels[3 * (long)ray + 2] = ab;
+    if (loss_gradients) {
+      loss_gradients[3 * (long)ray] = h0;
+      loss_gradients[3 * (long)ray + 1] = h1;
+      loss_gradients[3 * (long)ray + 2] = h2;
+    }
+    if (loss_sum) atomicAdd(loss_sum, (e0 * e0 + e1 * e1 + e2 * e2) * inv_n);
+  }
+  const float S = g0 * ar + g1 * ag + g2 * ab;
+  // sweep 2: per-sample gradients (the radiance is re-read: cache hits)
+  T_carry = 0.0f;
+  float P_carry = 0.0f;
+  if (n > 0) load(0, cur);
+  for (long s0 = 0; s0 < n; s0 += 128) {
+    if (s0 + 128 < n) load(s0 + 128, nxt);
+    const long i0 = s0 + 2 * lane;
+    const float x0 = cur.d0 * cur.c0.w, x1 = cur.d1 * cur.c1.w;
+    const float pr = x0 + x1;
+    const float incl = wave_incl_scan_f(pr, lane);
+    const float T0 = T_carry + (incl - pr);
+    const float Ti0 = expf(-T0), Ti1 = expf(-(T0 + x0));
+    const float ex0 = expf(-x0), ex1 = expf(-x1);
+    const float a0 = 1.0f - ex0, a1 = 1.0f - ex1;
+    const float gc0 = g0 * cur.c0.x + g1 * cur.c0.y + g2 * cur.c0.z, gc1 = g0 * cur.c1.x + g1 * cur.c1.y + g2 * cur.c1.z;
+    const float wgc0 = Ti0 * a0 * gc0, wgc1 = Ti1 * a1 * gc1;
+    const float pw = wgc0 + wgc1;
+    const float pincl1 = P_carry + wave_incl_scan_f(pw, lane);     // inclusive prefix at the pair's second sample
+    const float pincl0 = pincl1 - wgc1;
+    if (i0 < n) {
+      half4 o0, o1;
+      o0.x = __float2half(g0 * Ti0 * a0);
+      o0.y = __float2half(g1 * Ti0 * a0);
+      o0.z = __float2half(g2 * Ti0 * a0);
+      o0.w = __float2half(cur.d0 * (Ti0 * ex0 * gc0 - (S - pincl0)));
+      o1.x = __float2half(g0 * Ti1 * a1);
+      o1.y = __float2half(g1 * Ti1 * a1);
+      o1.z = __float2half(g2 * Ti1 * a1);
+      o1.w = __float2half(cur.d1 * (Ti1 * ex1 * gc1 - (S - pincl1)));
+      uint4 packed;
+      packed.x = *reinterpret_cast<const unsigned*>(&o0.x);
+      packed.y = *reinterpret_cast<const unsigned*>(&o0.z);
+      packed.z = *reinterpret_cast<const unsigned*>(&o1.x);
+      packed.w = *reinterpret_cast<const unsigned*>(&o1.z);
+      *reinterpret_cast<uint4*>(grads + base + i0) = packed;      // two half4: one 16-byte store
+    }
+    T_carry += __shfl(incl, 63, 64);
+    P_carry = __shfl(pincl1, 63, 64);
+    cur = nxt;
+  }
+}
+
 // Second half of the fused compositor: per ray, pixel = sum_seg exp(-T_before(seg)) * C_seg over the
 // (C_r, C_g, C_b, X) records rtxn_mlp_forward_segments_composite wrote (16 B/segment instead of 640 B).
 __global__ __launch_bounds__(256) void composite_segments_kernel(const float4* __restrict__ seg, const int* __restrict__ num_hits,
@@ -437,5 +634,34 @@ extern "C" int rtxn_volrender_bwd(const float* loss_values, const void* loss_gra
     volrender_bwd_nerf_kernel<<<grid, block, 0, s>>>(lg, rad, t_hit, num_hits, indices, batch_size,
                                                      num_samples_per_hit, out);
   RTXN_LAUNCH_CHECK("volrender_bwd_kernel");
+  return RTXN_OK;
+}
+
+extern "C" int rtxn_volrender_l2_train(const float* network_outputs, const float* ray_hit, const int* num_hits, const int* indices,
+                                       int batch_size, int num_samples_per_hit, const float* target, float loss_scale,
+                                       float* pixels, void* loss_gradients_half, float* loss_sum, void* radiance_gradients,
+                                       rtxn_stream_t stream) {
+  RTXN_REQUIRE(batch_size >= 0, "rtxn_volrender_l2_train: batch_size = %d < 0", batch_size);
+  RTXN_REQUIRE(num_samples_per_hit > 0, "rtxn_volrender_l2_train: num_samples_per_hit = %d", num_samples_per_hit);
+  RTXN_DEVICE_OR_FAIL();
+  hipStream_t s = rtxn::as_stream(stream);
+  if (loss_sum) RTXN_HIP(hipMemsetAsync(loss_sum, 0, sizeof(float), s));
+  if (batch_size == 0) return RTXN_OK;
+  RTXN_REQUIRE(network_outputs && ray_hit && num_hits && indices && target && pixels && radiance_gradients,
+               "rtxn_volrender_l2_train: NULL buffer");
+  RTXN_REQUIRE(((uintptr_t)network_outputs & 15) == 0 && ((uintptr_t)radiance_gradients & 7) == 0,
+               "rtxn_volrender_l2_train: radiance must be 16-byte and gradients 8-byte aligned");
+  const bool pairs = num_samples_per_hit % 2 == 0 && ((uintptr_t)ray_hit & 7) == 0 && ((uintptr_t)radiance_gradients & 15) == 0;
+  if (pairs)
+    volrender_l2_fused_pair_kernel<<<(batch_size + 3) / 4, 256, 0, s>>>(reinterpret_cast<const float4*>(network_outputs), ray_hit, num_hits,
+                                                                        indices, batch_size, num_samples_per_hit, target, loss_scale, pixels,
+                                                                        static_cast<__half*>(loss_gradients_half), loss_sum,
+                                                                        static_cast<half4*>(radiance_gradients));
+  else
+    volrender_l2_fused_kernel<<<(batch_size + 3) / 4, 256, 0, s>>>(reinterpret_cast<const float4*>(network_outputs), ray_hit, num_hits,
+                                                                   indices, batch_size, num_samples_per_hit, target, loss_scale, pixels,
+                                                                   static_cast<__half*>(loss_gradients_half), loss_sum,
+                                                                   static_cast<half4*>(radiance_gradients));
+  RTXN_LAUNCH_CHECK("volrender_l2_fused_kernel");
   return RTXN_OK;
 }

@@ -106,6 +106,8 @@ class Trainer:
         # float[S][5] samples and the separate sampler launch exist only for teacher rendering (render_rays(radiance_fn)) and
         # for tests (materialize_samples()).  RTXN_TRAIN_FOLD_SAMPLER=0: the reference's stage order, sampler first.
         self.fold_sampler = os.environ.get("RTXN_TRAIN_FOLD_SAMPLER", "1") != "0"
+        # "nerf" mode: compositor forward + L2 + compositor backward as one launch (RTXN_TRAIN_FUSE_COMPOSITOR=0: three)
+        self.fuse_compositor = os.environ.get("RTXN_TRAIN_FUSE_COMPOSITOR", "1") != "0"
         # ---- per-step buffers at capacity ---------------------------------------------------------
         B = batch_rays
         self.max_segments = int(max_segments) if max_segments else 64 * B
@@ -215,11 +217,11 @@ class Trainer:
                                   api.NUM_SAMPLES_PER_SEGMENT, self.pixels[:n], mode=vr)
         return self.pixels[:n]
 
-    def gradients(self, rays_o, rays_d, targets, finish=True):
+    def gradients(self, rays_o, rays_d, targets):
         """Everything of a step up to (not including) the optimizer: traversal ... backward.  Leaves the loss-scaled
-        gradient SUMS of this batch in self.dparams (MLP, tcnn layout) and self.dtable (hash grid) and returns the number
-        of samples.  The loss is the mean over THIS batch's 3n pixel components (tcnn L2, main.cu:759).
-        finish=False (the data-parallel step): the hashed levels' gradient is left in self.dtable_h (fp16) for the exchange."""
+        gradient SUMS of this batch in self.dparams (MLP, tcnn layout) and self.dtable / self.dtable_h (hash grid: fp32 for the
+        densely stored levels, fp16 for the hashed ones; table_grad() assembles them) and returns the number of samples.  The
+        loss is the mean over THIS batch's 3n pixel components (tcnn L2, main.cu:759)."""
         n = rays_o.shape[0]
         K = api.NUM_SAMPLES_PER_SEGMENT
         vr = api.VR_NERF if self.mode == "nerf" else api.VR_COMPAT
@@ -235,20 +237,23 @@ class Trainer:
                     self.dtable.zero_()
         if S == 0:
             self.loss.zero_()
-            if finish and self.encoding == "hash":
-                self._finish_table_grad()
             return 0
         if not self.fold_sampler:
             self._sample(n, P)
         self._forward(S)
-        with _Stage(self, "composite_fwd"):
-            api.launch_volrender_cuda(None, self.radiance, self.num_stored, self.indices, self.t_vals, n, K,
-                                      self.pixels[:n], mode=vr)
-        with _Stage(self, "l2_loss"):
-            api.l2_loss(self.pixels[:n], targets, self.loss_scale, None, self.loss_grads[:n], self.loss)
-        with _Stage(self, "composite_bwd"):
-            api.launch_volrender_backward_cuda(None, self.loss_grads, self.radiance, self.t_vals, self.num_stored,
-                                               self.indices, n, K, self.dout, mode=vr)
+        if self.mode == "nerf" and self.fuse_compositor:
+            with _Stage(self, "composite_fwd+l2+bwd"):   # one launch: the backward's first sweep IS the forward
+                api.volrender_l2_train(self.radiance, self.t_vals, self.num_stored, self.indices, n, K, targets, self.loss_scale,
+                                       self.pixels[:n], self.loss_grads[:n], self.loss, self.dout)
+        else:
+            with _Stage(self, "composite_fwd"):
+                api.launch_volrender_cuda(None, self.radiance, self.num_stored, self.indices, self.t_vals, n, K,
+                                          self.pixels[:n], mode=vr)
+            with _Stage(self, "l2_loss"):
+                api.l2_loss(self.pixels[:n], targets, self.loss_scale, None, self.loss_grads[:n], self.loss)
+            with _Stage(self, "composite_bwd"):
+                api.launch_volrender_backward_cuda(None, self.loss_grads, self.radiance, self.t_vals, self.num_stored,
+                                                   self.indices, n, K, self.dout, mode=vr)
         with _Stage(self, "mlp_bwd+wgrad"):
             if self.recompute:
                 self.net.train_backward_recompute(self.encT, self.out, self.dout, S, self.dparams, self.dencT)
@@ -263,8 +268,6 @@ class Trainer:
                     self.hg.backward_mixed(self.samples[:S], self.dencT, self.dtable, self.dtable_h)
                 else:
                     self.hg.backward(self.samples[:S], self.dencT, self.dtable)
-                if finish:
-                    self._finish_table_grad()
         return S
 
     def apply_gradients(self, grad_divisor=1.0):
@@ -273,10 +276,27 @@ class Trainer:
         with _Stage(self, "adam"):
             api.adam_step(self.master, self.params, self.dparams, self.adam_m, self.adam_v, self.step_count, lr=self.lr,
                           loss_scale=self.loss_scale * grad_divisor)
-            self.net.set_params(self.params)
+            self.net.set_params_training(self.params)     # the Trainer only ever runs the training kernels
             if self.encoding == "hash":
-                api.adam_step(self.table_master, self.table, self.dtable, self.table_m, self.table_v, self.step_count,
-                              lr=self.lr * 10.0, eps=1e-15, loss_scale=self.loss_scale * grad_divisor)
+                kw = dict(lr=self.lr * 10.0, eps=1e-15, loss_scale=self.loss_scale * grad_divisor)
+                lo = self.hashed_lo
+                if self.hash_fp16:     # dense levels from the fp32 gradient, hashed levels straight from the fp16 one
+                    if lo > 0:
+                        api.adam_step(self.table_master[:lo], self.table[:lo], self.dtable[:lo], self.table_m[:lo], self.table_v[:lo],
+                                      self.step_count, **kw)
+                    api.adam_step_half_grads(self.table_master[lo:], self.table[lo:], self.dtable_h, self.table_m[lo:],
+                                             self.table_v[lo:], self.step_count, **kw)
+                else:
+                    api.adam_step(self.table_master, self.table, self.dtable, self.table_m, self.table_v, self.step_count, **kw)
+
+    def table_grad(self):
+        """The hash grid's gradient as ONE fp32 vector in table layout (a copy; tests and tools).  In the default mixed form
+        the hashed levels' part is held in fp16 (self.dtable_h) and only self.dtable[:hashed_lo] of the fp32 buffer is live."""
+        if not self.hash_fp16:
+            return self.dtable.clone()
+        out = self.dtable.clone()
+        out[self.hashed_lo:] = self.dtable_h.float()
+        return out
 
     def step(self, rays_o, rays_d, targets):
         """One optimisation step on a batch of rays; returns the (device) loss scalar.
@@ -286,7 +306,7 @@ class Trainer:
         takes part in the all-reduces and runs Adam in every step -- also a rank whose rays all miss the grid (its
         gradients are zero) -- so the ranks can neither deadlock nor drift apart in step count."""
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        S = self.gradients(rays_o, rays_d, targets, finish=world == 1)
+        S = self.gradients(rays_o, rays_d, targets)
         if S == 0 and world == 1:
             return self.loss                  # nothing to learn from: no Adam step, step_count unchanged
         if world > 1:
@@ -296,7 +316,7 @@ class Trainer:
                     pending.extend(self._allreduce_table_grad())
                 for w in pending:
                     w.wait()
-                if self.encoding == "hash":
+                if self.encoding == "hash" and not self.hash_fp16:
                     self._finish_table_grad()
         self.apply_gradients(float(world))
         return self.loss
@@ -323,7 +343,7 @@ class Trainer:
         return pending
 
     def _finish_table_grad(self):
-        """Widen the fp16 gradient of the hashed levels into dtable[hashed_lo:] (what Adam reads)."""
+        """fp32 scatter only: widen the exchanged fp16 staging copy back into dtable[hashed_lo:]."""
         if self.dtable_h is not None:
             api.convert_f16_to_f32(self.dtable_h, self.dtable[self.hashed_lo:])
 

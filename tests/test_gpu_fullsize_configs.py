@@ -94,12 +94,12 @@ def test_config3_two_shard_gradients_sum_to_the_batch_gradient(config3):
     o, d, tgt = config3["batch"]
     h = config3["B"] // 2
     tr.gradients(o, d, tgt)
-    full_p, full_t = tr.dparams.clone(), tr.dtable.clone()
+    full_p, full_t = tr.dparams.clone(), tr.table_grad()
     acc_p, acc_t = torch.zeros_like(full_p), torch.zeros_like(full_t)
     for sl in (slice(0, h), slice(h, 2 * h)):
         tr.gradients(o[sl].contiguous(), d[sl].contiguous(), tgt[sl].contiguous())
         acc_p += tr.dparams
-        acc_t += tr.dtable
+        acc_t += tr.table_grad()
     acc_p *= 0.5
     acc_t *= 0.5
     for full, acc in ((full_p, acc_p), (full_t, acc_t)):

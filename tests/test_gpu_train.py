@@ -313,3 +313,41 @@ def test_sampler_folded_into_encoders_and_scatter(gpu, oracle, stype):
     t_got.fill_(-1.0)
     net.encode_frequency_segments(sp_d, ep_d, sv_d, P, stype, f_got, t_got, scale)
     assert torch.equal(f_got, f_ref) and torch.equal(t_got, t_ref)
+
+
+def test_fused_compositor_l2_backward_matches_the_three_calls(gpu, oracle):
+    """rtxn_volrender_l2_train == launch_volrender_cuda(NERF) -> L2 loss->evaluate -> launch_volrender_backward_cuda(NERF),
+    and both == the oracle chain; ragged rays incl. rays without samples."""
+    torch = gpu
+    from rtx_nerf_amd import api
+    rng = np.random.default_rng(5)
+    B, K, ls = 777, 32, 128.0
+    nh = rng.integers(0, 12, B).astype(np.int32)
+    nh[::7] = 0
+    idx = np.concatenate([[0], np.cumsum(nh)[:-1]]).astype(np.int32)
+    P = int(nh.sum())
+    rad = np.concatenate([rng.uniform(0, 1, (P * K, 3)), rng.uniform(0, 1, (P * K, 1))], 1).astype(np.float32)
+    step = rng.uniform(0.0, 0.2, P * K).astype(np.float32)
+    tgt = rng.uniform(0, 1, (B, 3)).astype(np.float32)
+    d = {k: _dev(torch, v) for k, v in dict(rad=rad, step=step, nh=nh, idx=idx, tgt=tgt).items()}
+    pix, lg, loss = torch.zeros((B, 3), device="cuda"), torch.zeros((B, 3), dtype=torch.float16, device="cuda"), torch.full((1,), 9.0, device="cuda")
+    out = torch.zeros((P * K, 4), dtype=torch.float16, device="cuda")
+    api.volrender_l2_train(d["rad"], d["step"], d["nh"], d["idx"], B, K, d["tgt"], ls, pix, lg, loss, out)
+    pix2, lg2, loss2 = torch.zeros_like(pix), torch.zeros_like(lg), torch.zeros(1, device="cuda")
+    out2 = torch.zeros_like(out)
+    api.launch_volrender_cuda(None, d["rad"], d["nh"], d["idx"], d["step"], B, K, pix2, mode=api.VR_NERF)
+    api.l2_loss(pix2, d["tgt"], ls, None, lg2, loss2)
+    api.launch_volrender_backward_cuda(None, lg2, d["rad"], d["step"], d["nh"], d["idx"], B, K, out2, mode=api.VR_NERF)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(pix.cpu().numpy(), pix2.cpu().numpy(), rtol=0, atol=2e-6)
+    assert abs(float(loss.item()) - float(loss2.item())) < 1e-5 * float(loss2.item())
+    assert (lg.cpu().numpy().view(np.uint16) == lg2.cpu().numpy().view(np.uint16)).mean() > 0.999    # same fp16 loss gradients
+    a, b = out.cpu().numpy().astype(np.float32), out2.cpu().numpy().astype(np.float32)
+    np.testing.assert_allclose(a, b, rtol=2e-3, atol=1e-6)
+    # oracle chain
+    want_pix = oracle.volrender_fwd_nerf(rad, nh, idx, step, K=K)
+    np.testing.assert_allclose(pix.cpu().numpy(), want_pix, rtol=0, atol=2e-5)
+    o_loss, _, g16, _ = oracle.l2_loss(want_pix, tgt, ls)
+    assert abs(float(loss.item()) - o_loss) < 1e-4 * o_loss
+    want = oracle.volrender_bwd_nerf(lg.cpu().numpy(), rad, step, nh, idx, K=K)[:P * K]
+    np.testing.assert_allclose(a, want, rtol=1.5e-3, atol=2e-5)

@@ -84,7 +84,7 @@ def test_config3_training_step_matches_oracle_chain(gpu, oracle):
     got_dp = tr.dparams.cpu().numpy()
     assert np.linalg.norm(got_dp - dp) < 2e-2 * np.linalg.norm(dp) and np.abs(dp).max() > 0
     dt = O.hg_backward(ocfg, samples, tr.dencT.reshape(-1)[:tr.E * Sp].reshape(tr.E, Sp)[:, :S].t().contiguous().cpu().numpy())
-    got_dt = tr.dtable.cpu().numpy()
+    got_dt = tr.table_grad().cpu().numpy()
     # hashed levels are accumulated in fp16 (packed atomics): 11-bit contributions
     assert np.abs(got_dt - dt).max() < (3e-3 if tr.hash_fp16 else 1e-3) * max(1e-6, np.abs(dt).max())
     # Adam from the GPU's gradients reproduces the GPU's new parameters

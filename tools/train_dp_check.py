@@ -51,7 +51,7 @@ for it in range(a.steps):
         dm[odd] = -dm[odd]
     tr.step(o[mine].contiguous(), dm, tgt[mine].contiguous())
     if it == 0:   # gradients of the first step (summed over ranks -> mean), before Adam's normalisation amplifies noise
-        g0 = torch.cat([tr.dparams, tr.dtable if a.encoding == "hash" else tr.dparams[:0]]).cpu().numpy() / world
+        g0 = torch.cat([tr.dparams, tr.table_grad() if a.encoding == "hash" else tr.dparams[:0]]).cpu().numpy() / world
 torch.cuda.synchronize()
 assert tr.step_count == a.steps, (rank, tr.step_count)                  # every rank ran Adam in every step
 if world > 1:                                                           # ... and they all hold the same parameters
