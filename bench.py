@@ -134,9 +134,12 @@ def extra_train_config3(steps, warmup):
     S = samples / steps
     stages = tr.time_stages(*batch(), steps=5)
     # hash-grid kernels against the HBM roofline.  Algorithmic bytes: 16 levels x 8 corners x 2 features x 2 B
-    # = 512 B gathered per sample forward; backward the same 8-corner footprint per level as fp32 atomic adds = 1024 B.
+    # = 512 B gathered per sample forward; backward the same 8-corner footprint per level as atomic adds (fp16 pairs on the
+    # hashed levels, fp32 on the densely stored ones).
     L, F = hgd["n_levels"], hgd["n_features"]
-    enc_b, bwd_b = L * 8 * F * 2, L * 8 * F * 4
+    n_hashed = sum(1 for l in range(L) if tr.hg.level_offset(l) >= tr.hashed_lo) if tr.hash_fp16 else 0
+    enc_b = L * 8 * F * 2                                     # fp16 table entries gathered
+    bwd_b = n_hashed * 8 * F * 2 + (L - n_hashed) * 8 * F * 4  # hashed levels: packed fp16 atomics; dense levels: fp32
     kern = {}
     for name, bts in (("encode", enc_b), ("hash_bwd", bwd_b)):
         ms = stages.get(name)

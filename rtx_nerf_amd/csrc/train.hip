@@ -720,6 +720,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_fused64_kernel(FusedArgs 
         const half8 af = tr_operand(img + (v * 2) * kImgBytes, lane_tr, a_tile, ks);
         const half8 bf = tr_operand(img + (v * 2 + 1) * kImgBytes, lane_tr, b_tile, ks);
         q = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, q, 0, 0, 0);
+        if (ks == 3) __builtin_amdgcn_sched_barrier(0);   // one image's eight operand reads in flight at a time (all 32 hoisted: spills)
       }
   };
 
