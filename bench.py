@@ -153,7 +153,7 @@ def extra_train_config3(steps, warmup):
         "ms_per_step": round(1e3 * dt / steps, 4), "mrays_s": round(B * steps / dt / 1e6, 4), "steps": steps, "warmup": warmup,
         "samples_per_step": int(S), "loss_first": first, "loss_last": float(loss.item()), "dtype": "f16 MFMA / f32 accumulate",
         "stage_ms": {k: round(v, 4) for k, v in stages.items()},
-        "roofline": {"kernel": {"hash_bwd": "hashgrid_backward_kernel<lds|wave-aggregated>", "encode": "hashgrid_encode_kernel"}[dom],
+        "roofline": {"kernel": {"hash_bwd": "hashgrid_backward_kernel<run-aggregated, pk_f16 on hashed levels>", "encode": "hashgrid_encode_kernel"}[dom],
                      "bound": "hbm", "achieved": kern[dom]["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": kern[dom]["frac"], "traffic": None, "kernel_ms": kern[dom]["ms"],
                      "bytes_per_sample": kern[dom]["bytes_per_sample"], "samples_per_launch": int(S)},
