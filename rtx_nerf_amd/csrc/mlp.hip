@@ -130,19 +130,24 @@ __device__ __forceinline__ float4 seg_composite(float r, float g, float b, float
 //              (16 for the output layer: one k-step; W otherwise).
 // MODE 3 (inference on v_mfma_f32_16x16x32_f16, mlp_fwd16_kernel): fragments are 16 rows x 32 k, lane l = (r = l&15,
 //   g = l>>4) at byte 16*l, chunks [rowtile16][kstep32];
-//   layer 0  : element (r,g ; kk ; j) = W0[16rt + r][enc16_feature(8kk + j, g>>1, g&1)]  (0 where there is none), K = k0_16
+//   layer 0  : element (r,g ; kk ; j) = W0[16rt + r][enc16_feature(8kk + j, g)]  (0 where there is none), K = k0_16
 //   others   : element = Wl[16rt + r][perm_feature16(kk,g,j)]                             (output layer: one 16-row tile)
 struct Enc16Dims { int PD, PF, DD, DF, E, k0; };
-// Layer-0 input order of the 16x16x32 kernel.  Lane group g = 2q + h: h selects sin/cos, q the upper half of the
-// frequencies -- j-slot u of a k-step names one (dimension, frequency f0) and the four lane groups hold
-// sin/cos(2^(f0 + q*F/2) pi x): direction slots first (DD*DF/2), then position (PD*PF/2), then the 1.0 padding, then
-// nothing.  Returns the tcnn feature index (Composite: position block, then direction block, then padding) or -1.
-__host__ __device__ inline int enc16_feature(const Enc16Dims& d, int u, int q, int h) {
-  const int ND = d.DD * d.DF / 2, NP = d.PD * d.PF / 2, width = 2 * (d.PD * d.PF + d.DD * d.DF), NPAD = (d.E - width) / 4;
-  if (u < ND) { const int dd = u / (d.DF / 2), f = u % (d.DF / 2) + q * (d.DF / 2); return 2 * d.PD * d.PF + (dd * d.DF + f) * 2 + h; }
-  if (u < ND + NP) { const int v = u - ND, dim = v / (d.PF / 2), f = v % (d.PF / 2) + q * (d.PF / 2); return (dim * d.PF + f) * 2 + h; }
-  if (u < ND + NP + NPAD) return width + 4 * (u - ND - NP) + 2 * q + h;
-  return -1;
+// Layer-0 input order of the 16x16x32 kernel.  Lane group g (0..3) owns a BLOCK of consecutive frequencies of every
+// dimension, FB = ceil(F / 4) of them starting at FB g.  A B-fragment dword is one (dimension, k) pair of the block:
+// j-slot 2D holds sin, 2D+1 cos of 2^(FB g + k) pi x -- so a lane evaluates v_sin_f32 / v_cos_f32 once per dimension, at
+// k = 0, and gets the block's other octaves by angle doubling (octave_unit).  Dword order: direction dims (DD x FB_D),
+// position dims (PD x FB_P), padding dwords (features enc_width.. = 1.0), then nothing.  Frequencies beyond F (block 3 of a
+// 10-frequency dimension holds f = 9 only) are computed and meet zero weights.  Returns the tcnn feature index (Composite:
+// position block, then direction block, then padding) of j-slot u in lane group g, or -1.
+__host__ __device__ inline int enc16_feature(const Enc16Dims& d, int u, int g) {
+  const int FBD = (d.DF + 3) / 4, FBP = (d.PF + 3) / 4, ND = d.DD * FBD, NP = d.PD * FBP;
+  const int width = 2 * (d.PD * d.PF + d.DD * d.DF);
+  const int D = u >> 1, ph = u & 1;
+  if (D < ND) { const int dd = D / FBD, f = FBD * g + D % FBD; return f < d.DF ? 2 * d.PD * d.PF + (dd * d.DF + f) * 2 + ph : -1; }
+  if (D < ND + NP) { const int v = D - ND, dim = v / FBP, f = FBP * g + v % FBP; return f < d.PF ? (dim * d.PF + f) * 2 + ph : -1; }
+  const int feat = width + 4 * (2 * (D - ND - NP) + ph) + g;
+  return feat < d.E ? feat : -1;
 }
 
 //   output layer: FOUR variants of its single 16-row tile, [variant v][kstep]: variant 0 is the layer as it is (all 16
@@ -170,7 +175,7 @@ __global__ void pack16_kernel(const _Float16* __restrict__ params, _Float16* __r
     const int in_w = layer == 0 ? E : W, rows = layer == n_hidden ? 16 : W;
     int row = 16 * rt + r;
     if (layer == n_hidden) row = rt == 0 ? r : ((r >> 2) == rt ? (r & 3) : rows);   // variant v: rows 4v..4v+3 <- outputs 0..3
-    const int feat = layer == 0 ? enc16_feature(d, 8 * kk + j, g >> 1, g & 1) : rtxn::perm_feature16(kk, g, j);
+    const int feat = layer == 0 ? enc16_feature(d, 8 * kk + j, g) : rtxn::perm_feature16(kk, g, j);
     const long base = layer == 0 ? 0 : (long)W * E + (long)(layer - 1) * W * W;
     _Float16 v = (_Float16)0.0f;
     if (row < rows && feat >= 0 && feat < in_w) v = params[base + (long)row * in_w + feat];
@@ -670,182 +675,152 @@ __global__ __launch_bounds__(64 * RTXN_NW, CT == 2 ? 2 : 1) void mlp_fwd_kernel(
 // ---------------------------------------------------------------------------
 // Same block geometry, LDS plan, staging protocol and wave-group skew as mlp_fwd_kernel; what changes is the fragment
 // shape and with it who holds what: lane (c = l & 15, g = l >> 4) owns sample 16 ct + c of the wave's four 16-column tiles
-// and, of every 32 features, the eight perm_feature16 gives its lane group.  In layer 0 lane group g = 2q + h computes
-// sin (h = 0) / cos (h = 1) of the LOWER (q = 0) / UPPER (q = 1) half of each dimension's frequencies: the inputs are
-// pre-scaled once per tile by 2^(q F/2) (exact), after which j-slot u of a k-step is one compile-time (dimension, f0)
-// for all four groups and the per-slot instructions are those of the 32x32 kernel, bit-identical values included.
+// and, of every 32 features, the eight perm_feature16 gives its lane group.
+// Layer 0 / the encoder.  Lane group g evaluates a block of FB = ceil(F/4) consecutive frequencies of every input dimension
+// (enc16_feature): the inputs are pre-scaled once per tile by 2^(FB g) (exact), the block's lowest octave comes from ONE
+// v_sin_f32 + ONE v_cos_f32 (exact range reduction as before) and its other octaves from the double-angle identities
+// s' = 2 s c, c' = 1 - 2 s^2 -- three 4-cycle instructions per octave instead of two 8-cycle transcendentals with their
+// range reductions: 64 issue cycles per (dimension, column tile) for six features, where the direct form took 120.  The error
+// of an octave doubles the previous one's: two doublings on a ~1e-6 seed stay under 1e-5, a fortieth of an fp16 ulp of
+// these values (tests/test_gpu_parity.py reports the measured maximum per octave).
 template <int PD, int PF, int DD, int DF>
 struct EncSpec16 {
-  static_assert(PF % 2 == 0 && DF % 2 == 0, "the lane-group split halves each dimension's frequencies");
+  static constexpr int FBP = (PF + 3) / 4, FBD = (DF + 3) / 4;     // octaves per lane group and dimension
+  static_assert(FBP >= 1 && FBP <= 3 && FBD >= 1 && FBD <= 3, "octave_unit is written for 1-3 octaves per block");
   static constexpr int enc_width = 2 * (PD * PF + DD * DF);
   static constexpr int enc_padded = (enc_width + 15) / 16 * 16;
-  static constexpr int ND = DD * DF / 2, NP = PD * PF / 2, NPAD = (enc_padded - enc_width) / 4;
-  static constexpr int n_jslots = ND + NP + NPAD;
-  static constexpr int k0 = (n_jslots + 7) / 8 * 32;   // first-layer K as staged (32 per k-step)
+  static constexpr int ND = DD * FBD, NP = PD * FBP;               // dwords: direction, position
+  static constexpr int NPADW = (enc_padded - enc_width + 7) / 8;   // padding dwords (8 features each over the four groups)
+  static constexpr int n_dwords = ND + NP + NPADW;
+  static constexpr int k0 = (n_dwords + 3) / 4 * 32;               // first-layer K as staged (4 dwords = 32 k per k-step)
+  static_assert(ND <= 8, "direction dwords are placed before the pipeline starts: k-steps 0 and 1 only");
 };
 
-// value of j-slot U for this lane (plain code: padding slots and the odd real slot next to one)
-template <class ES, int PD, int PF, int DD, int DF, int U>
-__device__ __forceinline__ _Float16 encode_slot16(const float (&xq)[5], float phase) {
-  if constexpr (U < ES::ND) {
-    constexpr int dd = U / (DF / 2), f0 = U % (DF / 2);
-    return (_Float16)__builtin_amdgcn_sinf(__builtin_amdgcn_fractf(xq[PD + dd] * (0.5f * (float)(1u << f0))) + phase);
-  } else if constexpr (U < ES::ND + ES::NP) {
-    constexpr int v = U - ES::ND, dim = v / (PF / 2), f0 = v % (PF / 2);
-    return (_Float16)__builtin_amdgcn_sinf(__builtin_amdgcn_fractf(xq[dim] * (0.5f * (float)(1u << f0))) + phase);
-  } else if constexpr (U < ES::n_jslots) {
-    return (_Float16)1.0f;
+// One dimension of one sample: NK dwords {sin, cos} of octaves 0..NK-1 of the lane group's block.  xg = x 2^(FB g).
+template <int NK>
+__device__ __forceinline__ void octave_unit(float xg, int (&d)[3]) {
+  float t, u, sn, cs;
+  if constexpr (NK == 3) {
+    asm volatile(
+        "v_mul_f32 %3, 0.5, %7\n\t"
+        "v_fract_f32 %3, %3\n\t"
+        "v_sin_f32 %5, %3\n\t"
+        "v_cos_f32 %6, %3\n\t"
+        "s_nop 0\n\t"
+        "v_cvt_pk_f16_f32 %0, %5, %6\n\t"
+        "v_add_f32 %3, %5, %5\n\t"          // 2 s0
+        "v_mul_f32 %4, %3, %6\n\t"          // s1 = 2 s0 c0
+        "v_fma_f32 %6, -%3, %5, 1.0\n\t"    // c1 = 1 - 2 s0^2
+        "v_cvt_pk_f16_f32 %1, %4, %6\n\t"
+        "v_add_f32 %3, %4, %4\n\t"          // 2 s1
+        "v_mul_f32 %5, %3, %6\n\t"          // s2 = 2 s1 c1
+        "v_fma_f32 %6, -%3, %4, 1.0\n\t"    // c2 = 1 - 2 s1^2
+        "v_cvt_pk_f16_f32 %2, %5, %6"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(t), "=&v"(u), "=&v"(sn), "=&v"(cs)
+        : "v"(xg));
+  } else if constexpr (NK == 2) {
+    asm volatile(
+        "v_mul_f32 %2, 0.5, %6\n\t"
+        "v_fract_f32 %2, %2\n\t"
+        "v_sin_f32 %4, %2\n\t"
+        "v_cos_f32 %5, %2\n\t"
+        "s_nop 0\n\t"
+        "v_cvt_pk_f16_f32 %0, %4, %5\n\t"
+        "v_add_f32 %2, %4, %4\n\t"
+        "v_mul_f32 %3, %2, %5\n\t"
+        "v_fma_f32 %5, -%2, %4, 1.0\n\t"
+        "v_cvt_pk_f16_f32 %1, %3, %5"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(t), "=&v"(u), "=&v"(sn), "=&v"(cs)
+        : "v"(xg));
+    d[2] = 0;
+  } else {
+    asm volatile(
+        "v_mul_f32 %1, 0.5, %4\n\t"
+        "v_fract_f32 %1, %1\n\t"
+        "v_sin_f32 %2, %1\n\t"
+        "v_cos_f32 %3, %1\n\t"
+        "s_nop 0\n\t"
+        "v_cvt_pk_f16_f32 %0, %2, %3"
+        : "=&v"(d[0]), "=&v"(t), "=&v"(sn), "=&v"(cs)
+        : "v"(xg));
+    d[1] = d[2] = 0;
   }
-  return (_Float16)0.0f;
 }
 
 template <int PD, int PF, int DD, int DF>
 struct DirShare16 {
-  static constexpr bool possible = DD == 2 && (DD * DF / 2) % 2 == 0 && DD * DF / 2 <= 16;
-  static constexpr int n_dwords = possible ? DD * DF / 4 : 1;
+  static constexpr bool possible = DD <= 16;
+  static constexpr int n_dwords = DD * EncSpec16<PD, PF, DD, DF>::FBD;
 };
 
 // Segment input: a segment is TWO adjacent 16-column tiles and its direction features are the same for all 32 samples.
-// Lane (c, g) computes direction j-slot c of its own lane group (q, h) once, neighbours pack with a DPP move, and
-// DD*DF/4 ds_bpermute broadcasts give every lane of the group the finished B-fragment dwords (cf. share_direction).
-// theta / phi come in already scaled by 2^(q DF/2).
+// Lane (c, g), c < DD, runs the octave unit of direction dimension c for its own lane group; DD * FB_D ds_bpermute broadcasts
+// hand every lane of the group the finished B-fragment dwords (dword dd * FB_D + k from lane (dd, g)).  The inputs come in
+// already scaled by 2^(FB_D g).
 template <int PD, int PF, int DD, int DF>
-__device__ __forceinline__ void share_direction16(float theta_q, float phi_q, float phase, int lane,
-                                                  int (&dirs)[DirShare16<PD, PF, DD, DF>::n_dwords]) {
+__device__ __forceinline__ void share_direction16(const float (&dir_g)[DD], int lane, int (&dirs)[DirShare16<PD, PF, DD, DF>::n_dwords]) {
+  constexpr int FBD = EncSpec16<PD, PF, DD, DF>::FBD;
   const int c = lane & 15;
-  const int u = c < DD * DF / 2 ? c : 0;
-  const float xs = u >= DF / 2 ? phi_q : theta_q;
-  const float rev = __builtin_amdgcn_fractf(xs * ldexpf(0.5f, u % (DF / 2))) + phase;
-  const float v = __builtin_amdgcn_sinf(rev);
-  const float w = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
-  float2v pr = {v, w};
-  const int packed = __builtin_bit_cast(int, __builtin_convertvector(pr, half2v));
+  float xs = dir_g[0];
 #pragma unroll
-  for (int j = 0; j < DirShare16<PD, PF, DD, DF>::n_dwords; ++j)
-    dirs[j] = __builtin_amdgcn_ds_bpermute(4 * ((lane & 48) + 2 * j), packed);
+  for (int dd = 1; dd < DD; ++dd) xs = c == dd ? dir_g[dd] : xs;     // by value (a select on an array element once went through scratch)
+  int d[3];
+  octave_unit<FBD>(xs, d);
+#pragma unroll
+  for (int dd = 0; dd < DD; ++dd)
+#pragma unroll
+    for (int k = 0; k < FBD; ++k) dirs[dd * FBD + k] = __builtin_amdgcn_ds_bpermute(4 * ((lane & 48) + dd), d[k]);
 }
 
-// dword E (0..3) of the B fragment of k-step KK for one column tile: j-slots 8 KK + 2 E, + 1
-template <class ES, int PD, int PF, int DD, int DF, bool SHARE, int KK, int E>
-__device__ __forceinline__ int encode_unit16(const float (&xq)[5], float phase, const int (&dirs)[DirShare16<PD, PF, DD, DF>::n_dwords]) {
-  constexpr int u0 = 8 * KK + 2 * E, u1 = u0 + 1;
-  if constexpr (SHARE && u1 < ES::ND) {
-    return dirs[u0 / 2];
-  } else if constexpr (u1 < ES::ND + ES::NP && (u0 >= ES::ND || u1 < ES::ND)) {   // two real slots of one kind
-    constexpr bool dir = u1 < ES::ND;
-    constexpr int v0 = dir ? u0 : u0 - ES::ND, v1 = v0 + 1, H = dir ? DF / 2 : PF / 2, base = dir ? PD : 0;
-    constexpr int d0 = base + v0 / H, d1 = base + v1 / H;
-    const float c0 = 0.5f * (float)(1u << (v0 % H)), c1 = 0.5f * (float)(1u << (v1 % H));
-    int r;
-    float t0, t1;
-    asm volatile(
-        "v_mul_f32 %1, %4, %3\n\t"
-        "v_mul_f32 %2, %6, %5\n\t"
-        "v_fract_f32 %1, %1\n\t"
-        "v_fract_f32 %2, %2\n\t"
-        "v_add_f32 %1, %1, %7\n\t"
-        "v_add_f32 %2, %2, %7\n\t"
-        "v_sin_f32 %1, %1\n\t"
-        "v_sin_f32 %2, %2\n\t"
-        "s_nop 0\n\t"
-        "v_cvt_pk_f16_f32 %0, %1, %2"
-        : "=v"(r), "=&v"(t0), "=&v"(t1)
-        : "v"(xq[d0]), "s"(c0), "v"(xq[d1]), "s"(c1), "v"(phase));
-    return r;
-  } else {
-    half2v v;
-    v[0] = encode_slot16<ES, PD, PF, DD, DF, u0>(xq, phase);
-    v[1] = encode_slot16<ES, PD, PF, DD, DF, u1>(xq, phase);
-    return __builtin_bit_cast(int, v);
-  }
-}
-// WHICH: 0 every unit; 1 only the shared direction dwords (plain register moves); 2 everything but those
-template <class ES, int PD, int PF, int DD, int DF, int CT, bool SHARE, int KK, int U0, int U1, int WHICH = 0>
-__device__ __forceinline__ void encode_units16(const float (&xq)[CT][5], float phase, half8 (&b)[CT],
-                                               const int (&dirs)[CT / 2][DirShare16<PD, PF, DD, DF>::n_dwords]) {
-  if constexpr (U0 < U1) {   // unit U: column tile U / 4, dword U % 4
-    constexpr int ct = U0 / 4, e = U0 % 4;
-    constexpr bool shared = SHARE && 8 * KK + 2 * e + 1 < ES::ND;
-    if constexpr (WHICH == 0 || (WHICH == 1) == shared) {
-      rtxn::int4v t = __builtin_bit_cast(rtxn::int4v, b[ct]);
-      t[e] = encode_unit16<ES, PD, PF, DD, DF, SHARE, KK, e>(xq[ct], phase, dirs[ct / 2]);
-      b[ct] = __builtin_bit_cast(half8, t);
-    }
-    encode_units16<ES, PD, PF, DD, DF, CT, SHARE, KK, U0 + 1, U1, WHICH>(xq, phase, b, dirs);
-  }
-}
-
-// The shared direction dwords (k-steps 0 and, for the reference model, 1) are in place before the first step: the pipeline
-// itself encodes position / padding slots only and carries no direction table (12 VGPRs fewer under the 128 accumulators).
-template <class ES, int PD, int PF, int DD, int DF, int RT, int KS0, int NB, int CT, bool SHARE, int I>
-struct Layer0Step16 {
-  using DirTab = int[CT / 2][DirShare16<PD, PF, DD, DF>::n_dwords];
-  static constexpr int D = RTXN_PIPE16, N = RT * KS0, WAVES = RTXN_NW;
-  static constexpr int CHUNKS = N < 32 / WAVES ? N : 32 / WAVES;
-  static constexpr int UE = (4 * CT + RT - 1) / RT;   // encode units per (kk, rt) sub-step
-  __device__ static __forceinline__ void run(unsigned addr, const float (&xq)[CT][5], float phase, half8 (&b)[2][CT],
-                                             half8 (&out)[NB][CT], half8 (&ring)[D], rtxn::floatx4 (&acc)[RT][CT],
-                                             const rtxn::StageJob& sj, int wave_u, int lane, const DirTab& dirs) {
-    constexpr int kk = I / RT, rt = I % RT, cur = kk & 1;
-    constexpr int outstanding = (N - 1 - I) < (D - 1) ? (N - 1 - I) : (D - 1);
-    rtxn::lds_wait<outstanding>();
-    const half8 a = ring[I % D];
-    if (kk == 0) {
+// The whole encoded input of a column tile as layer 0's B fragments: global dword D sits in k-step D / 4, dword D % 4.
+// Layer 0 then runs on the same row-tile-outer pipeline as the hidden layers, with the encoding done BEFORE it rather than in
+// slices behind its MFMAs.  Measured against the k-step-outer form that hid the encoder inside layer 0 (round 1's design,
+// carried over to this kernel first): the same kernel time within noise -- the other wave group keeps the matrix core busy
+// during the encode, and the chip is issue- and power-bound, not latency-bound -- at 189 instead of 231-251 VGPRs (32
+// accumulator registers live in layer 0 instead of 128).  That is what lets the traversal and compositor kernels of the
+// neighbouring frames co-reside with two of these waves per SIMD (render.py, render_async): MLP-to-MLP gaps 12-20 us.
+template <class ES, int PD, int PF, int DD, int DF, int KS0, int NB, int CT, bool SHARE>
+__device__ __forceinline__ void encode_layer0_input(const float (&xq)[CT][5], const int (&dirs)[CT / 2][DirShare16<PD, PF, DD, DF>::n_dwords],
+                                                    half8 (&bf)[NB][CT]) {
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
+  for (int ct = 0; ct < CT; ++ct) {
+    rtxn::int4v t[KS0];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[rt][ct][e] = 0.0f;
+    for (int kk = 0; kk < KS0; ++kk)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int D = 4 * kk + e;   // padding dwords {1.0, 1.0} (features beyond enc_padded meet zero weights); beyond n_dwords: 0
+        t[kk][e] = (D >= ES::ND + ES::NP && D < ES::n_dwords) ? 0x3c003c00 : 0;
+      }
+    if constexpr (SHARE) {
+#pragma unroll
+      for (int D = 0; D < ES::ND; ++D) t[D / 4][D % 4] = dirs[ct / 2][D];
+    } else {
+#pragma unroll
+      for (int dd = 0; dd < DD; ++dd) {
+        int d[3];
+        octave_unit<ES::FBD>(xq[ct][PD + dd], d);
+#pragma unroll
+        for (int k = 0; k < ES::FBD; ++k) t[(dd * ES::FBD + k) / 4][(dd * ES::FBD + k) % 4] = d[k];
+      }
     }
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[cur][ct], acc[rt][ct], 0, 0, 0);
-    if constexpr (kk + 1 < KS0) {
-      constexpr int u0 = rt * UE < 4 * CT ? rt * UE : 4 * CT, u1 = (rt + 1) * UE < 4 * CT ? (rt + 1) * UE : 4 * CT;
-      encode_units16<ES, PD, PF, DD, DF, CT, SHARE, kk + 1, u0, u1, (SHARE && kk + 1 < 2) ? 2 : 0>(xq, phase, b[cur ^ 1], dirs);
-    } else if constexpr (rt > 0) {
-      rtxn::convert_units16<NB, CT, rt - 1, 0, 2 * CT>(acc[rt - 1], out);   // last k-step: row tile rt-1 is complete
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (I + D < N) rtxn::lds_read_frag<(((I + D) % RT) * KS0 + (I + D) / RT) * 1024>(ring[I % D], addr);
-    if constexpr (I < CHUNKS) {
-      rtxn::stage_chunk<I, WAVES>(sj, wave_u, lane);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if constexpr (I + 1 < N)
-      Layer0Step16<ES, PD, PF, DD, DF, RT, KS0, NB, CT, SHARE, I + 1>::run(addr, xq, phase, b, out, ring, acc, sj, wave_u, lane, dirs);
-  }
-};
-
-template <class ES, int PD, int PF, int DD, int DF, int RT, int KS0, int NB, int CT, bool SHARE>
-__device__ __forceinline__ void pipe_layer0_16(const uint8_t* lds_buf, const rtxn::StageJob& sj, const float (&xq)[CT][5], float phase,
-                                               const int (&dirs)[CT / 2][DirShare16<PD, PF, DD, DF>::n_dwords],
-                                               half8 (&out)[NB][CT], rtxn::floatx4 (&pend)[CT], int wave_u, int lane) {
-  constexpr int D = RTXN_PIPE16, N = RT * KS0;
-  static_assert(N * 1024 <= 65535 + 1024, "fragment offsets must fit the 16-bit ds offset");
-  static_assert(RT % 2 == 0, "the pending row tile is the odd tile of its pair");
-  half8 ring[D];
-  const unsigned addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) uint8_t*)lds_buf + lane * 16;
-  rtxn::lds_read_frag<0>(ring[0], addr);
-  if constexpr (D > 1) rtxn::lds_read_frag<((1 % RT) * KS0 + 1 / RT) * 1024>(ring[1 % D], addr);
-  if constexpr (D > 2) rtxn::lds_read_frag<((2 % RT) * KS0 + 2 / RT) * 1024>(ring[2 % D], addr);
-  if constexpr (D > 3) rtxn::lds_read_frag<((3 % RT) * KS0 + 3 / RT) * 1024>(ring[3 % D], addr);
-  static_assert(!SHARE || ES::ND <= 16, "shared direction slots must lie in k-steps 0 and 1");
-  half8 b[2][CT];
-  encode_units16<ES, PD, PF, DD, DF, CT, SHARE, 0, 0, 4 * CT>(xq, phase, b[0], dirs);   // k-step 0: nothing to hide behind yet
-  if constexpr (SHARE && KS0 > 1) encode_units16<ES, PD, PF, DD, DF, CT, SHARE, 1, 0, 4 * CT, 1>(xq, phase, b[1], dirs);
-  // Segment input: the two column tiles of a segment get IDENTICAL k-step-0 fragments when that k-step holds direction
-  // slots only, and hipcc then merges their MFMAs (one result feeding both accumulator chains: an out-of-place MFMA for one
-  // tile, in-place for the other).  Legal for the compiler -- but that kernel came out wrong on the hardware, and not
-  // reproducibly so (first column tile of a wave's first segment; tools/scratch notes in DESIGN.md 3.4), while every build
-  // that keeps the four accumulator chains separate is exact and bit-deterministic.  The hand-placed asm slices of this
-  // pipeline rely on the chains being what the source says, so the fragments are made opaque to value numbering.
-  if constexpr (SHARE) {
+    for (int dim = 0; dim < PD; ++dim) {
+      int d[3];
+      octave_unit<ES::FBP>(xq[ct][dim], d);
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) asm volatile("" : "+v"(b[0][ct]));
-  }
-  rtxn::floatx4 acc[RT][CT];
-  Layer0Step16<ES, PD, PF, DD, DF, RT, KS0, NB, CT, SHARE, 0>::run(addr, xq, phase, b, out, ring, acc, sj, wave_u, lane, dirs);
+      for (int k = 0; k < ES::FBP; ++k) t[(ES::ND + ES::FBP * dim + k) / 4][(ES::ND + ES::FBP * dim + k) % 4] = d[k];
+    }
 #pragma unroll
-  for (int ct = 0; ct < CT; ++ct) pend[ct] = acc[RT - 1][ct];
+    for (int kk = 0; kk < KS0; ++kk) bf[kk][ct] = __builtin_bit_cast(half8, t[kk]);
+    // Segment input: the two column tiles of a segment get IDENTICAL k-step-0 fragments when that k-step holds direction
+    // dwords only, and hipcc then merges their MFMAs (one result feeding both accumulator chains: an out-of-place MFMA for one
+    // tile, in-place for the other).  Legal for the compiler -- but that kernel came out wrong on the hardware, and not
+    // reproducibly so (first column tile of a wave's first segment), while every build that keeps the four accumulator
+    // chains separate is exact and bit-deterministic.  The hand-placed asm slices of the pipeline rely on the chains being
+    // what the source says, so the fragment is made opaque to value numbering.
+    if constexpr (SHARE) asm volatile("" : "+v"(bf[0][ct]));
+  }
 }
 
 // OUT_MODE 0: half[n][16]; 1: float4 radiance (+ t_vals); 3: compact half4.  (The per-segment compositor epilogue,
@@ -889,7 +864,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd16_kernel(FwdArgs a) {
   stage<OUT_BYTES, THREADS>(a.packed + layer_off(n_layers - 1), smem + L0_BYTES, tid);
   int qs = 0;                               // hidden stages this wave has begun (ring slot = qs % 3)
 
-  const float pos_scale = q ? (float)(1u << (PF / 2)) : 1.0f, dir_scale = q ? (float)(1u << (DF / 2)) : 1.0f;
+  const float pos_scale = (float)(1u << (ES::FBP * g)), dir_scale = (float)(1u << (ES::FBD * g));   // 2^(FB g): see EncSpec16
   float xq[CT][5];                          // inputs of the lane's four samples, already scaled for its lane group
   auto sample_of = [&](int tile, int ct, bool& valid) -> long {
     if (IN_MODE == 1) {
@@ -936,7 +911,6 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd16_kernel(FwdArgs a) {
     rtxn::staged_barrier();
   }
   for (int tile = (int)blockIdx.x; tile < n_tiles; tile += tile_step) {
-    const float phase = 0.25f * (float)(g & 1);
     const bool more = tile + tile_step < n_tiles;       // this block has another tile after this one
     if (IN_MODE == 1 && OUT_MODE == 1 && a.t_vals) {
       // REGULAR t_vals (sampler.cu:65: post-increment) of the wave's 64 samples, one per lane: lane l is sample l of the two
@@ -951,9 +925,13 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd16_kernel(FwdArgs a) {
     int dirs[CT / 2][DirShare16<PD, PF, DD, DF>::n_dwords];
     if constexpr (SHARE) {
 #pragma unroll
-      for (int sg = 0; sg < CT / 2; ++sg) share_direction16<PD, PF, DD, DF>(xq[2 * sg][PD], xq[2 * sg][PD + 1], phase, lane, dirs[sg]);
+      for (int sg = 0; sg < CT / 2; ++sg) {
+        float dg[DD];
+#pragma unroll
+        for (int dd = 0; dd < DD; ++dd) dg[dd] = xq[2 * sg][PD + dd];
+        share_direction16<PD, PF, DD, DF>(dg, lane, dirs[sg]);
+      }
     }
-
     half8 bf[NB][CT], bg[NB][CT];
     rtxn::floatx4 acc2[2][CT];
     rtxn::StageJob sj;
@@ -1039,8 +1017,9 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd16_kernel(FwdArgs a) {
       }
     };
     {
+      encode_layer0_input<ES, PD, PF, DD, DF, KS0, NB, CT, SHARE>(xq, dirs, bf);   // VALU only: before the stage barrier, not behind it
       const uint8_t* w = begin_stage(0);
-      pipe_layer0_16<ES, PD, PF, DD, DF, RT, KS0, NB, CT, SHARE>(w, sj, xq, phase, dirs, bg, acc2[1], wave_u, lane);
+      rtxn::pipe_layer16<RT, KS0, NB, CT, false>(w, sj, bf, bg, acc2, wave_u, lane);
     }
     int l = 1;
     for (; l + 1 < n_layers - 1; l += 2) {
