@@ -68,5 +68,5 @@ dt = time.perf_counter() - t0
 print(json.dumps({
     "metric": "training rays/s (full optimisation step)", "value": round(a.batch * a.steps / dt / 1e6, 4), "unit": "Mrays/s",
     "ms_per_step": round(1e3 * dt / a.steps, 3), "samples_per_step": samples // a.steps, "final_loss": float(loss.item()),
-    "config": {"workload": f"{a.batch} rays/batch, {a.encoding} encoding + 4x64 MLP, {R}^3 grid ({100 * dense.mean():.1f}% cells), K=32, "
+    "config": {"workload": f"{a.batch} rays/batch, {a.encoding} encoding + {a.layers}x{a.neurons} MLP, {R}^3 grid ({100 * dense.mean():.1f}% cells), K=32, "
                            "L2 + Adam, teacher = analytic field", "n_gpus": 1}}))

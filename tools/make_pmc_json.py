@@ -21,7 +21,7 @@ def kernel_src_sha16():
     return h.hexdigest()[:16]
 
 
-def means(path, pat="mlp_fwd_kernel"):
+def means(path, pat="mlp_fwd16_kernel"):   # the dominant kernel of the bench frame (16x16x32 form)
     acc, dur, name = defaultdict(list), [], None
     with open(path, newline="") as f:
         for row in csv.DictReader(f):
