@@ -385,6 +385,67 @@ int rtxn_adam_step(long n, float* master, void* params_fp16, const float* grads,
 int rtxn_adam_step_half_grads(long n, float* master, void* params_fp16, const void* grads_fp16, float* m, float* v, int step,
                               float lr, float beta1, float beta2, float eps, float loss_scale, rtxn_stream_t stream);
 
+/* The two Adam entry points for a step that is replayed as a hipGraph: the bias-corrected rate lr*sqrt(1-beta2^t)/(1-beta1^t)
+ * depends on the step number, which must not be baked into the captured launch, so it is read from DEVICE memory
+ * (*effective_lr) -- the caller refreshes it before every replay (e.g. an H2D copy node from pinned memory holding
+ * rtxn_adam_effective_lr(lr, beta1, beta2, t), which is exactly the value rtxn_adam_step computes on the host).
+ * grads_fp16 != 0: `grads` is half[n] (as rtxn_adam_step_half_grads), else float[n]. */
+float rtxn_adam_effective_lr(float lr, float beta1, float beta2, int step);
+int rtxn_adam_step_captured(long n, float* master, void* params_fp16, const void* grads, int grads_fp16, float* m, float* v,
+                            const float* effective_lr, float beta1, float beta2, float eps, float loss_scale,
+                            rtxn_stream_t stream);
+
+/* ---- one training batch without a host round trip ------------------------------------------------------------------
+ * The body of the reference's training loop between the traversal and the optimizer (main.cu:703-781: launchSampler ->
+ * network->forward -> launch_volrender_cuda -> loss->evaluate -> launch_volrender_backward_cuda -> network->backward) as
+ * ONE call whose kernels take the batch's segment count from the device (`total_segments`, as rtxn_scan_hits leaves it;
+ * clamped to segment_capacity), where the reference -- and the per-stage entry points above -- need it on the host
+ * (main.cu:632 synchronises for it).  Nothing in the call synchronises or allocates, so traversal + this call + the
+ * optimizer can be captured into a hipGraph and replayed.  Same kernels and results as the per-stage sequence
+ *   rtxn_hashgrid_encode_segments | rtxn_encode_frequency_segments -> rtxn_mlp_train_forward[_outputs] ->
+ *   rtxn_volrender_l2_train (RTXN_VR_NERF) | rtxn_volrender_fwd + rtxn_l2_loss + rtxn_volrender_bwd (RTXN_VR_COMPAT) ->
+ *   rtxn_mlp_train_backward[_recompute] -> rtxn_hashgrid_backward_segments
+ * with one difference in layout only: the feature-major workspaces use the row stride of the CAPACITY,
+ * rtxn_padded_samples(32 * segment_capacity), every step.  All buffers are the caller's, sized for segment_capacity
+ * segments; the gradient outputs are ACCUMULATED into (zero them first). */
+typedef struct rtxn_train_batch {
+  const rtxn_mlp* mlp;
+  const rtxn_hashgrid* grid;        /* NULL: the model's own Composite-Frequency encoding */
+  int n_dir_freqs;                  /* hash grid only: Frequency(n) on the two direction dimensions */
+  const void* table_fp16;           /* hash grid only: half[rtxn_hashgrid_n_params] */
+  /* the batch's packed segments (rtxn_trace_grid write pass) */
+  const float* start_points;        /* float[capacity][3] */
+  const float* end_points;          /* float[capacity][3] */
+  const float* seg_view;            /* float[capacity][2] */
+  const int* num_stored;            /* int[n_rays]: segments per ray actually stored */
+  const int* indices;               /* int[n_rays]: first segment of each ray */
+  const int* total_segments;        /* DEVICE int: segments of this batch (rtxn_scan_hits' total) */
+  long segment_capacity;
+  int n_rays;
+  int sample_type;                  /* RTXN_SAMPLING_REGULAR | RTXN_SAMPLING_MIDPOINT_WORLD */
+  float t_scale;                    /* MIDPOINT_WORLD: factor on the step lengths written to t_vals */
+  int vr_mode;                      /* RTXN_VR_COMPAT | RTXN_VR_NERF */
+  const float* targets;             /* float[n_rays][3] */
+  float loss_scale;
+  /* workspaces */
+  void* encT;                       /* half[E][Sp], Sp = rtxn_padded_samples(32 * capacity) */
+  void* dencT;                      /* half[E][Sp]; hash grid only */
+  void* workspace;                  /* rtxn_mlp_train_workspace_bytes(mlp, 32 * capacity), or NULL: recompute path
+                                       (rtxn_mlp_train_recompute_supported) */
+  void* output_half;                /* half[32 * capacity][16] */
+  float* radiance;                  /* float[32 * capacity][4] */
+  float* t_vals;                    /* float[32 * capacity] */
+  void* radiance_gradients;         /* half[32 * capacity][4] */
+  /* outputs */
+  float* pixels;                    /* float[n_rays][3] */
+  void* loss_gradients_half;        /* half[n_rays][3] */
+  float* loss_sum;                  /* device float (may be NULL): mean squared error of the batch */
+  float* dparams;                   /* float[rtxn_mlp_n_params], accumulated into */
+  float* dtable;                    /* hash grid: float[n_params], accumulated into */
+  void* dtable_hashed_half;         /* hash grid, optional: as rtxn_hashgrid_backward_segments */
+} rtxn_train_batch;
+int rtxn_train_gradients(const rtxn_train_batch* batch, rtxn_stream_t stream);
+
 /* fp32 <-> fp16 copies of a gradient block on the device (no counterpart in the reference, which is single-GPU): the
  * data-parallel exchange sends the hashed levels' gradient in fp16 -- tiny-cuda-nn holds that gradient in fp16 throughout. */
 int rtxn_convert_f32_to_f16(const float* src, void* dst_half, long n, rtxn_stream_t stream);

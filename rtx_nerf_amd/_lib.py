@@ -81,6 +81,19 @@ class MlpConfig(C.Structure):
         "n_neurons", "n_hidden_layers", "n_output_dims", "output_activation", "encoding", "n_encoded_features")]
 
 
+class TrainBatch(C.Structure):
+    """struct rtxn_train_batch (include/rtxn.h)."""
+    _fields_ = [("mlp", C.c_void_p), ("grid", C.c_void_p), ("n_dir_freqs", C.c_int), ("table_fp16", C.c_void_p),
+                ("start_points", C.c_void_p), ("end_points", C.c_void_p), ("seg_view", C.c_void_p),
+                ("num_stored", C.c_void_p), ("indices", C.c_void_p), ("total_segments", C.c_void_p),
+                ("segment_capacity", C.c_long), ("n_rays", C.c_int), ("sample_type", C.c_int), ("t_scale", C.c_float),
+                ("vr_mode", C.c_int), ("targets", C.c_void_p), ("loss_scale", C.c_float),
+                ("encT", C.c_void_p), ("dencT", C.c_void_p), ("workspace", C.c_void_p), ("output_half", C.c_void_p),
+                ("radiance", C.c_void_p), ("t_vals", C.c_void_p), ("radiance_gradients", C.c_void_p),
+                ("pixels", C.c_void_p), ("loss_gradients_half", C.c_void_p), ("loss_sum", C.c_void_p),
+                ("dparams", C.c_void_p), ("dtable", C.c_void_p), ("dtable_hashed_half", C.c_void_p)]
+
+
 # every symbol include/rtxn.h declares: name -> (restype, argtypes)
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_long, C.c_float
 SYMBOLS = {
@@ -138,6 +151,9 @@ SYMBOLS = {
     "rtxn_l2_loss": (_I, [_P, _P, _L, _F, _P, _P, _P, _P]),
     "rtxn_adam_step": (_I, [_L, _P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _P]),
     "rtxn_adam_step_half_grads": (_I, [_L, _P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _P]),
+    "rtxn_adam_effective_lr": (_F, [_F, _F, _F, _I]),
+    "rtxn_adam_step_captured": (_I, [_L, _P, _P, _P, _I, _P, _P, _P, _F, _F, _F, _F, _P]),
+    "rtxn_train_gradients": (_I, [C.POINTER(TrainBatch), _P]),
     "rtxn_load_images_json": (_I, [C.c_char_p, C.c_char_p, _I, C.POINTER(ImageDataset)]),
     "rtxn_free_image_dataset": (None, [C.POINTER(ImageDataset)]),
     "rtxn_load_llff": (_I, [C.c_char_p, _I, _I, C.POINTER(ImageDataset), C.POINTER(C.POINTER(C.c_float))]),

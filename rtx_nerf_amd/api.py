@@ -504,6 +504,57 @@ def adam_step_half_grads(master, params_fp16, grads_fp16, m, v, step, lr=1e-3, b
                                                loss_scale, _stream()), "rtxn_adam_step_half_grads")
 
 
+def adam_effective_lr(lr, beta1, beta2, step):
+    """The bias-corrected rate rtxn_adam_step uses at `step` (computed by the library, so the captured form is bit-identical)."""
+    return float(_lib.lib().rtxn_adam_effective_lr(lr, beta1, beta2, int(step)))
+
+
+def adam_step_captured(master, params_fp16, grads, m, v, effective_lr, beta1=0.9, beta2=0.999, eps=1e-8, loss_scale=1.0):
+    """adam_step / adam_step_half_grads (by the dtype of `grads`) with the bias-corrected rate read from the device float
+    `effective_lr`: the form a hipGraph can replay."""
+    half = grads.dtype == torch.float16
+    check(_lib.lib().rtxn_adam_step_captured(master.numel(), _ptr(master, torch.float32, "master"),
+                                             _ptr(params_fp16, torch.float16, "params"),
+                                             _ptr(grads, torch.float16 if half else torch.float32, "grads"), 1 if half else 0,
+                                             _ptr(m, torch.float32, "m"), _ptr(v, torch.float32, "v"),
+                                             _ptr(effective_lr, torch.float32, "effective_lr"), beta1, beta2, eps, loss_scale,
+                                             _stream()), "rtxn_adam_step_captured")
+
+
+def train_gradients(net, *, grid=None, n_dir_freqs=0, table=None, start_points, end_points, seg_view, num_stored, indices,
+                    total_segments, segment_capacity, n_rays, sample_type, t_scale=1.0, vr_mode, targets, loss_scale,
+                    encT, dencT=None, workspace=None, output_half, radiance, t_vals, radiance_gradients, pixels, loss_gradients,
+                    loss_sum=None, dparams, dtable=None, dtable_hashed_half=None):
+    """rtxn_train_gradients: sampler ... backward of one batch with the segment count taken on the device (main.cu:703-781)."""
+    b = _lib.TrainBatch()
+    b.mlp, b.grid = net._h, (grid._h if grid is not None else None)
+    b.n_dir_freqs = int(n_dir_freqs)
+    b.table_fp16 = _ptr(table, torch.float16, "table")
+    b.start_points, b.end_points = _ptr(start_points, torch.float32, "start_points"), _ptr(end_points, torch.float32, "end_points")
+    b.seg_view = _ptr(seg_view, torch.float32, "seg_view")
+    b.num_stored, b.indices = _ptr(num_stored, torch.int32, "num_stored"), _ptr(indices, torch.int32, "indices")
+    b.total_segments = _ptr(total_segments, torch.int32, "total_segments")
+    b.segment_capacity, b.n_rays, b.sample_type, b.t_scale, b.vr_mode = int(segment_capacity), int(n_rays), int(sample_type), float(t_scale), int(vr_mode)
+    b.targets, b.loss_scale = _ptr(targets, torch.float32, "targets"), float(loss_scale)
+    b.encT, b.dencT = _ptr(encT, torch.float16, "encT"), _ptr(dencT, torch.float16, "dencT")
+    b.workspace = _ptr(workspace, torch.float16, "workspace")
+    b.output_half, b.radiance = _ptr(output_half, torch.float16, "output_half"), _ptr(radiance, torch.float32, "radiance")
+    b.t_vals, b.radiance_gradients = _ptr(t_vals, torch.float32, "t_vals"), _ptr(radiance_gradients, torch.float16, "radiance_gradients")
+    b.pixels, b.loss_gradients_half = _ptr(pixels, torch.float32, "pixels"), _ptr(loss_gradients, torch.float16, "loss_gradients")
+    b.loss_sum = _ptr(loss_sum, torch.float32, "loss_sum")
+    b.dparams, b.dtable = _ptr(dparams, torch.float32, "dparams"), _ptr(dtable, torch.float32, "dtable")
+    b.dtable_hashed_half = _ptr(dtable_hashed_half, torch.float16, "dtable_hashed_half")
+    for nm, t, need in (("encT", encT, net.encoded_width() * padded_samples(32 * int(segment_capacity))),
+                        ("output_half", output_half, 32 * int(segment_capacity) * 16), ("radiance", radiance, 32 * int(segment_capacity) * 4),
+                        ("t_vals", t_vals, 32 * int(segment_capacity)), ("radiance_gradients", radiance_gradients, 32 * int(segment_capacity) * 4),
+                        ("start_points", start_points, 3 * int(segment_capacity)), ("end_points", end_points, 3 * int(segment_capacity)),
+                        ("seg_view", seg_view, 2 * int(segment_capacity)), ("pixels", pixels, 3 * int(n_rays)),
+                        ("targets", targets, 3 * int(n_rays)), ("num_stored", num_stored, int(n_rays)), ("indices", indices, int(n_rays))):
+        if t.numel() < need:
+            raise _lib.RtxnError(f"train_gradients: {nm} holds {t.numel()} elements, {need} needed for capacity {segment_capacity} / {n_rays} rays")
+    check(_lib.lib().rtxn_train_gradients(C.byref(b), _stream()), "rtxn_train_gradients")
+
+
 def convert_f32_to_f16(src, dst):
     check(_lib.lib().rtxn_convert_f32_to_f16(_ptr(src, torch.float32, "src"), _ptr(dst, torch.float16, "dst"), src.numel(), _stream()),
           "rtxn_convert_f32_to_f16")

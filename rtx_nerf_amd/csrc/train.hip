@@ -29,6 +29,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 struct rtxn_hashgrid {
   rtxn_hashgrid_config cfg;
@@ -49,6 +51,21 @@ constexpr int kThreads = 256;
 constexpr int kTile = 256;
 
 inline long padded(long S) { return (S + kTile - 1) / kTile * kTile; }
+
+// A training step without a host round trip (rtxn_train_gradients): the kernels take the batch's segment count from the
+// scan's device-side total, clamped to what the buffers hold; grids are sized for the capacity and the blocks past the live
+// samples leave at once.  total_segments == NULL: the host's count as passed (every per-stage entry point).  The row stride
+// S_pad of the feature-major tensors is then that of the CAPACITY, so it does not change from step to step.
+struct DevCount {
+  const int* total_segments;
+  int capacity;
+};
+__device__ __forceinline__ long live_samples(const DevCount& dc, long S_host) {
+  if (!dc.total_segments) return S_host;
+  const int t = *dc.total_segments;
+  return 32L * (t < dc.capacity ? (t < 0 ? 0 : t) : dc.capacity);
+}
+__device__ __forceinline__ long padded_dev(long S) { return (S + kTile - 1) / kTile * kTile; }
 // the fused training kernels address X[feature][S_pad] with one 32-bit per-lane byte offset (row_elem): (s + 4*S_pad)*2 < 2^32
 constexpr long kMaxTrainSamples = (1L << 32) / 10 - kTile;
 
@@ -103,9 +120,11 @@ __device__ __forceinline__ float sample_tval(const SampleSrc& src, long s, float
 }
 
 __global__ __launch_bounds__(kThreads) void encode_freq_kernel(SampleSrc src, _Float16* __restrict__ encT, float* __restrict__ t_vals,
-                                                               float t_scale, long S, long Sp, int PD, int PF, int DD, int DF, int E) {
+                                                               float t_scale, long S, long Sp, int PD, int PF, int DD, int DF, int E,
+                                                               DevCount dc) {
   const long s = (long)blockIdx.x * kThreads + threadIdx.x;
-  if (s >= Sp) return;
+  S = live_samples(dc, S);
+  if (s >= padded_dev(S)) return;
   const bool ok = s < S;
   float x[8];
   if (src.in) {
@@ -144,9 +163,10 @@ __device__ __forceinline__ unsigned hg_index(unsigned x, unsigned y, unsigned z,
 // grid.y = level (0..L-1: hash levels; L: direction frequencies + padding)
 __global__ __launch_bounds__(kThreads) void hashgrid_encode_kernel(HgLevels lv, int n_dir_freqs, const _Float16* __restrict__ table,
                                                                    SampleSrc src, _Float16* __restrict__ encT, float* __restrict__ t_vals,
-                                                                   float t_scale, long S, long Sp, int E) {
+                                                                   float t_scale, long S, long Sp, int E, DevCount dc) {
   const long s = (long)blockIdx.x * kThreads + threadIdx.x;
-  if (s >= Sp) return;
+  S = live_samples(dc, S);
+  if (s >= padded_dev(S)) return;
   const bool ok = s < S;
   const int l = blockIdx.y;
   const int F = lv.n_features;
@@ -212,7 +232,9 @@ template <bool PK>
 __global__ __launch_bounds__(kThreads) void hashgrid_backward_kernel(HgLevels lv, int level0, SampleSrc src,
                                                                      const _Float16* __restrict__ dencT, long S, long Sp,
                                                                      float* __restrict__ dtable, _Float16* __restrict__ dtable_h,
-                                                                     long hashed_lo) {
+                                                                     long hashed_lo, DevCount dc) {
+  S = live_samples(dc, S);
+  if ((long)blockIdx.x * kThreads >= S) return;                 // whole block past the live samples (block-uniform)
   const int l = level0 + blockIdx.y;
   const int F = lv.n_features;
   float* gdst = dtable + (size_t)lv.offset[l] * F;
@@ -293,6 +315,7 @@ struct TrainArgs {
   const uint8_t* packed;    // packed_train (fwd) or packed_t (bwd)
   int n_hidden, out_act, E;
   long S, Sp;
+  DevCount dc;              // S from the device (see DevCount); Sp stays the stride
   const _Float16* encT;     // [E][Sp]
   _Float16* acts;           // [L][W][Sp]
   unsigned long long* masks; // [L][Sp][2]: bit 8*kk + j of lane-half h's word = (post-ReLU activation != 0) of feature
@@ -324,6 +347,8 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_train_fwd_kernel(TrainArgs a)
   constexpr int RT = W / 32, KS = W / 16;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
+  a.S = live_samples(a.dc, a.S);
+  if ((long)blockIdx.x * kTile >= a.S) return;
   const long tile0 = (long)blockIdx.x * kTile + wave * 64;
   const int KS0 = a.E / 16;
   const int L = a.n_hidden;
@@ -475,6 +500,8 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_bwd_kernel(TrainArgs a) {
   constexpr int RT = W / 32, KS = W / 16;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
+  a.S = live_samples(a.dc, a.S);
+  if ((long)blockIdx.x * kTile >= a.S) return;
   const long tile0 = (long)blockIdx.x * kTile + wave * 64;
   const int L = a.n_hidden;
   long off = 0;
@@ -654,6 +681,7 @@ struct FusedArgs {
   const uint8_t* packed_t;     // transposed layers in backward order: out, L-1, ..., 1, 0
   int L, KS0, out_act, E;
   long S, Sp;
+  DevCount dc;                 // S and n_tiles from the device (see DevCount)
   int n_tiles;                 // 256-sample block tiles
   const _Float16* encT;        // [E][Sp]
   const _Float16* out_half;    // [S][16]
@@ -680,6 +708,11 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_fused64_kernel(FusedArgs 
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (a.dc.total_segments) {
+    a.S = live_samples(a.dc, a.S);
+    a.n_tiles = (int)(padded_dev(a.S) / kTile);
+  }
+  if ((int)blockIdx.x >= a.n_tiles) return;
   const int L = a.L, KS0 = a.KS0;
   const int rt_e = (a.E + 31) / 32;
   const int fwd_bytes = (KS0 * RT + (L - 1) * KS * RT) * 1024;
@@ -961,6 +994,7 @@ struct WgradArgs {
   WgradLayer layer[17];
   long Sp, chunk;
   int lds_path;   // layers with >= 2 tiles are left to wgrad_lds_kernel
+  DevCount dc;    // contraction length from the device (see DevCount); Sp stays the row stride
 };
 
 __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
@@ -972,9 +1006,10 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
   const long Sp = a.Sp;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int tm = blockIdx.x / L.tiles_n, tn = blockIdx.x % L.tiles_n;
+  const long Send = a.dc.total_segments ? padded_dev(live_samples(a.dc, 0)) : Sp;
   const long s_begin = ((long)blockIdx.y * 4 + wave) * a.chunk;
-  const long s_end = s_begin + a.chunk < Sp ? s_begin + a.chunk : Sp;
-  if (s_begin >= Sp) return;
+  const long s_end = s_begin + a.chunk < Send ? s_begin + a.chunk : Send;
+  if (s_begin >= Send) return;
   floatx16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -1038,9 +1073,10 @@ __global__ __launch_bounds__(kThreads) void wgrad_lds_kernel(WgradArgs a) {
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tm = wave >> 1, tn = wave & 1;
+  const long Send = a.dc.total_segments ? padded_dev(live_samples(a.dc, 0)) : Sp;
   const long s_begin = (long)blockIdx.x * a.chunk;
-  const long s_end = s_begin + a.chunk < Sp ? s_begin + a.chunk : Sp;
-  if (s_begin >= Sp) return;
+  const long s_end = s_begin + a.chunk < Send ? s_begin + a.chunk : Send;
+  if (s_begin >= Send) return;
   // this wave's 8 fragments of a stage: (kk, q) = ((wave*8 + i) / 8, (wave*8 + i) % 8) = (wave, i) for kWgK == 4
   const _Float16* src[8];
 #pragma unroll
@@ -1121,7 +1157,8 @@ __global__ __launch_bounds__(kThreads) void l2_loss_kernel(const float* __restri
 __global__ __launch_bounds__(kThreads) void adam_kernel(long n, float* __restrict__ master, __half* __restrict__ params,
                                                         const float* __restrict__ grads, float* __restrict__ m,
                                                         float* __restrict__ v, float lr_eff, float beta1, float beta2,
-                                                        float eps, float inv_loss_scale) {
+                                                        float eps, float inv_loss_scale, const float* __restrict__ lr_dev) {
+  if (lr_dev) lr_eff = *lr_dev;      // captured steps: the bias-corrected rate changes every replay, the graph does not
   for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
     const float g = grads[i] * inv_loss_scale;
     const float mi = beta1 * m[i] + (1.0f - beta1) * g;
@@ -1161,7 +1198,8 @@ __global__ __launch_bounds__(kThreads) void f16_to_f32_kernel(const _Float16* __
 __global__ __launch_bounds__(kThreads) void adam_half_grads_kernel(long n, float* __restrict__ master, __half* __restrict__ params,
                                                                    const __half* __restrict__ grads, float* __restrict__ m,
                                                                    float* __restrict__ v, float lr_eff, float beta1, float beta2,
-                                                                   float eps, float inv_loss_scale) {
+                                                                   float eps, float inv_loss_scale, const float* __restrict__ lr_dev) {
+  if (lr_dev) lr_eff = *lr_dev;
   for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
     const float g = __half2float(grads[i]) * inv_loss_scale;
     const float mi = beta1 * m[i] + (1.0f - beta1) * g;
@@ -1206,12 +1244,14 @@ extern "C" size_t rtxn_mlp_train_workspace_bytes(const rtxn_mlp* m, long n_sampl
   return (size_t)((2 * L * W + 16 + 8 * L) * Sp) * sizeof(_Float16);   // acts | dz | dzL | sign masks (16 B per sample and layer)
 }
 
+// In every *_impl below: dc.total_segments == NULL: n_samples is the batch's; otherwise n_samples is the CAPACITY (grids, row
+// stride) and the kernels take the live count from the device.
 static int encode_frequency_impl(const rtxn_mlp* m, const SampleSrc& src, void* encT, float* t_vals, float t_scale, long n_samples,
-                                 rtxn_stream_t stream) {
+                                 DevCount dc, rtxn_stream_t stream) {
   const long Sp = padded(n_samples);
   encode_freq_kernel<<<(unsigned)(Sp / kThreads), kThreads, 0, rtxn::as_stream(stream)>>>(
       src, static_cast<_Float16*>(encT), t_vals, t_scale, n_samples, Sp, m->cfg.n_pos_dims, m->cfg.n_pos_freqs, m->cfg.n_dir_dims,
-      m->cfg.n_dir_freqs, m->enc_padded);
+      m->cfg.n_dir_freqs, m->enc_padded, dc);
   RTXN_LAUNCH_CHECK("encode_freq_kernel");
   return RTXN_OK;
 }
@@ -1224,7 +1264,7 @@ extern "C" int rtxn_encode_frequency(const rtxn_mlp* m, const float* input, void
   if (n_samples == 0) return RTXN_OK;
   RTXN_REQUIRE(input && encT, "rtxn_encode_frequency: NULL buffer");
   const SampleSrc src{input, nullptr, nullptr, nullptr, 0};
-  return encode_frequency_impl(m, src, encT, nullptr, 1.0f, n_samples, stream);
+  return encode_frequency_impl(m, src, encT, nullptr, 1.0f, n_samples, DevCount{nullptr, 0}, stream);
 }
 
 static int check_segments(const char* who, const float* start_points, const float* end_points, const float* seg_view,
@@ -1247,17 +1287,34 @@ extern "C" int rtxn_encode_frequency_segments(const rtxn_mlp* m, const float* st
   if (n_segments == 0) return RTXN_OK;
   RTXN_REQUIRE(encT, "rtxn_encode_frequency_segments: NULL buffer");
   const SampleSrc src{nullptr, start_points, end_points, seg_view, sample_type == RTXN_SAMPLING_MIDPOINT_WORLD};
-  return encode_frequency_impl(m, src, encT, t_vals, t_scale, n_segments * 32, stream);
+  return encode_frequency_impl(m, src, encT, t_vals, t_scale, n_segments * 32, DevCount{nullptr, 0}, stream);
 }
 
-extern "C" int rtxn_mlp_train_forward(const rtxn_mlp* m, const void* encT, long n_samples, void* workspace,
-                                      void* output_half, float* radiance, rtxn_stream_t stream) {
-  int rc = check_train(m, "rtxn_mlp_train_forward");
-  if (rc != RTXN_OK) return rc;
-  RTXN_REQUIRE(n_samples >= 0 && n_samples <= kMaxTrainSamples, "rtxn_mlp_train_forward: n_samples = %ld out of [0, %ld]", n_samples, kMaxTrainSamples);
-  RTXN_DEVICE_OR_FAIL();
-  if (n_samples == 0) return RTXN_OK;
-  RTXN_REQUIRE(encT && workspace && output_half, "rtxn_mlp_train_forward: NULL buffer");
+// hipFuncSetAttribute once per (device, kernel): not repeated in front of every launch (and never inside a stream capture
+// after the first, un-captured, call)
+static hipError_t set_lds_once(const void* fn, int bytes) {
+  struct Seen { int dev; const void* fn; int bytes; };
+  static std::mutex mu;
+  static std::vector<Seen> seen;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(mu);
+  for (Seen& q : seen)
+    if (q.dev == dev && q.fn == fn) {
+      if (q.bytes >= bytes) return hipSuccess;
+      e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+      if (e == hipSuccess) q.bytes = bytes;
+      return e;
+    }
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) seen.push_back(Seen{dev, fn, bytes});
+  return e;
+}
+
+// workspace == NULL: outputs only (the forward half of the recompute path)
+static int train_forward_impl(const rtxn_mlp* m, const void* encT, long n_samples, void* workspace, void* output_half,
+                              float* radiance, DevCount dc, rtxn_stream_t stream) {
   const int W = m->cfg.n_neurons;
   const long Sp = padded(n_samples);
   TrainArgs a;
@@ -1268,34 +1325,43 @@ extern "C" int rtxn_mlp_train_forward(const rtxn_mlp* m, const void* encT, long 
   a.E = m->enc_padded;
   a.S = n_samples;
   a.Sp = Sp;
+  a.dc = dc;
   a.encT = static_cast<const _Float16*>(encT);
-  a.acts = static_cast<_Float16*>(workspace);
-  a.masks = reinterpret_cast<unsigned long long*>(static_cast<_Float16*>(workspace) + (2L * m->cfg.n_hidden_layers * W + 16) * Sp);
+  if (workspace) {
+    a.acts = static_cast<_Float16*>(workspace);
+    a.masks = reinterpret_cast<unsigned long long*>(static_cast<_Float16*>(workspace) + (2L * m->cfg.n_hidden_layers * W + 16) * Sp);
+  }
   a.out_half = static_cast<_Float16*>(output_half);
   a.radiance = reinterpret_cast<float4*>(radiance);
   const int RT = W / 32, KS = W / 16, KS0 = a.E / 16;
   const size_t lds = (size_t)(KS0 > KS ? KS0 : KS) * RT * 1024;
   hipStream_t s = rtxn::as_stream(stream);
-  if (W == 64) {
-    RTXN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_train_fwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(mlp_train_fwd_kernel<64>, dim3((unsigned)(Sp / kTile)), dim3(kThreads), lds, s, a);
-  } else {
-    RTXN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_train_fwd_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(mlp_train_fwd_kernel<128>, dim3((unsigned)(Sp / kTile)), dim3(kThreads), lds, s, a);
-  }
-  RTXN_LAUNCH_CHECK("mlp_train_fwd_kernel");
+  const dim3 grid((unsigned)(Sp / kTile)), block(kThreads);
+#define RTXN_FWD_LAUNCH(WW, SAVE)                                                                        \
+  do {                                                                                                   \
+    RTXN_HIP(set_lds_once(reinterpret_cast<const void*>(mlp_train_fwd_kernel<WW, SAVE>), (int)lds));      \
+    hipLaunchKernelGGL((mlp_train_fwd_kernel<WW, SAVE>), grid, block, lds, s, a);                         \
+  } while (0)
+  if (W == 64) { if (workspace) RTXN_FWD_LAUNCH(64, true); else RTXN_FWD_LAUNCH(64, false); }
+  else         { if (workspace) RTXN_FWD_LAUNCH(128, true); else RTXN_FWD_LAUNCH(128, false); }
+#undef RTXN_FWD_LAUNCH
+  RTXN_LAUNCH_CHECK(workspace ? "mlp_train_fwd_kernel" : "mlp_train_fwd_kernel<outputs only>");
   return RTXN_OK;
 }
 
-extern "C" int rtxn_mlp_train_backward(const rtxn_mlp* m, const void* encT, const void* output_half,
-                                       const void* dout_half4, long n_samples, void* workspace, float* dparams,
-                                       void* dencT, rtxn_stream_t stream) {
-  int rc = check_train(m, "rtxn_mlp_train_backward");
+extern "C" int rtxn_mlp_train_forward(const rtxn_mlp* m, const void* encT, long n_samples, void* workspace,
+                                      void* output_half, float* radiance, rtxn_stream_t stream) {
+  int rc = check_train(m, "rtxn_mlp_train_forward");
   if (rc != RTXN_OK) return rc;
-  RTXN_REQUIRE(n_samples >= 0 && n_samples <= kMaxTrainSamples, "rtxn_mlp_train_backward: n_samples = %ld out of [0, %ld]", n_samples, kMaxTrainSamples);
+  RTXN_REQUIRE(n_samples >= 0 && n_samples <= kMaxTrainSamples, "rtxn_mlp_train_forward: n_samples = %ld out of [0, %ld]", n_samples, kMaxTrainSamples);
   RTXN_DEVICE_OR_FAIL();
   if (n_samples == 0) return RTXN_OK;
-  RTXN_REQUIRE(encT && output_half && dout_half4 && workspace && dparams, "rtxn_mlp_train_backward: NULL buffer");
+  RTXN_REQUIRE(encT && workspace && output_half, "rtxn_mlp_train_forward: NULL buffer");
+  return train_forward_impl(m, encT, n_samples, workspace, output_half, radiance, DevCount{nullptr, 0}, stream);
+}
+
+static int train_backward_impl(const rtxn_mlp* m, const void* encT, const void* output_half, const void* dout_half4,
+                               long n_samples, void* workspace, float* dparams, void* dencT, DevCount dc, rtxn_stream_t stream) {
   const int W = m->cfg.n_neurons, L = m->cfg.n_hidden_layers, E = m->enc_padded;
   const long Sp = padded(n_samples);
   _Float16* ws = static_cast<_Float16*>(workspace);
@@ -1307,6 +1373,7 @@ extern "C" int rtxn_mlp_train_backward(const rtxn_mlp* m, const void* encT, cons
   a.E = E;
   a.S = n_samples;
   a.Sp = Sp;
+  a.dc = dc;
   a.encT = static_cast<const _Float16*>(encT);
   a.acts = ws;
   a.dz = ws + (long)L * W * Sp;
@@ -1319,10 +1386,10 @@ extern "C" int rtxn_mlp_train_backward(const rtxn_mlp* m, const void* encT, cons
   const size_t lds = (size_t)(RTE > RT ? RTE : RT) * KS * 1024;
   hipStream_t s = rtxn::as_stream(stream);
   if (W == 64) {
-    RTXN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    RTXN_HIP(set_lds_once(reinterpret_cast<const void*>(mlp_bwd_kernel<64>), (int)lds));
     hipLaunchKernelGGL(mlp_bwd_kernel<64>, dim3((unsigned)(Sp / kTile)), dim3(kThreads), lds, s, a);
   } else {
-    RTXN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    RTXN_HIP(set_lds_once(reinterpret_cast<const void*>(mlp_bwd_kernel<128>), (int)lds));
     hipLaunchKernelGGL(mlp_bwd_kernel<128>, dim3((unsigned)(Sp / kTile)), dim3(kThreads), lds, s, a);
   }
   RTXN_LAUNCH_CHECK("mlp_bwd_kernel");
@@ -1330,6 +1397,7 @@ extern "C" int rtxn_mlp_train_backward(const rtxn_mlp* m, const void* encT, cons
   RTXN_REQUIRE(L + 1 <= 17, "rtxn_mlp_train_backward: %d layers exceed the weight-gradient launch table", L + 1);
   WgradArgs wa;
   wa.Sp = Sp;
+  wa.dc = dc;
   wa.chunk = 1024;
   const unsigned kblocks = (unsigned)((Sp + 4 * wa.chunk - 1) / (4 * wa.chunk));
   long poff = 0;
@@ -1356,11 +1424,23 @@ extern "C" int rtxn_mlp_train_backward(const rtxn_mlp* m, const void* encT, cons
   if (wa.lds_path) {
     WgradArgs wl = wa;
     wl.chunk = 2048;
-    RTXN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kWgStage));
+    RTXN_HIP(set_lds_once(reinterpret_cast<const void*>(wgrad_lds_kernel), 2 * kWgStage));
     wgrad_lds_kernel<<<dim3((unsigned)((Sp + wl.chunk - 1) / wl.chunk), (unsigned)(L + 1)), kThreads, 2 * kWgStage, s>>>(wl);
     RTXN_LAUNCH_CHECK("wgrad_lds_kernel");
   }
   return RTXN_OK;
+}
+
+extern "C" int rtxn_mlp_train_backward(const rtxn_mlp* m, const void* encT, const void* output_half,
+                                       const void* dout_half4, long n_samples, void* workspace, float* dparams,
+                                       void* dencT, rtxn_stream_t stream) {
+  int rc = check_train(m, "rtxn_mlp_train_backward");
+  if (rc != RTXN_OK) return rc;
+  RTXN_REQUIRE(n_samples >= 0 && n_samples <= kMaxTrainSamples, "rtxn_mlp_train_backward: n_samples = %ld out of [0, %ld]", n_samples, kMaxTrainSamples);
+  RTXN_DEVICE_OR_FAIL();
+  if (n_samples == 0) return RTXN_OK;
+  RTXN_REQUIRE(encT && output_half && dout_half4 && workspace && dparams, "rtxn_mlp_train_backward: NULL buffer");
+  return train_backward_impl(m, encT, output_half, dout_half4, n_samples, workspace, dparams, dencT, DevCount{nullptr, 0}, stream);
 }
 
 // ---- recompute path (64-wide models): forward without saved activations + fused backward ----
@@ -1377,30 +1457,40 @@ extern "C" int rtxn_mlp_train_forward_outputs(const rtxn_mlp* m, const void* enc
   RTXN_DEVICE_OR_FAIL();
   if (n_samples == 0) return RTXN_OK;
   RTXN_REQUIRE(encT && output_half, "rtxn_mlp_train_forward_outputs: NULL buffer");
-  const int W = m->cfg.n_neurons;
-  const long Sp = padded(n_samples);
-  TrainArgs a;
+  return train_forward_impl(m, encT, n_samples, nullptr, output_half, radiance, DevCount{nullptr, 0}, stream);
+}
+
+static int train_backward_recompute_impl(const rtxn_mlp* m, const void* encT, const void* output_half, const void* dout_half4,
+                                         long n_samples, float* dparams, void* dencT, DevCount dc, rtxn_stream_t stream) {
+  const int L = m->cfg.n_hidden_layers, E = m->enc_padded;
+  FusedArgs a;
   memset(&a, 0, sizeof(a));
-  a.packed = static_cast<const uint8_t*>(m->packed_train);
-  a.n_hidden = m->cfg.n_hidden_layers;
+  a.packed_fwd = static_cast<const uint8_t*>(m->packed_train);
+  a.packed_t = static_cast<const uint8_t*>(m->packed_t);
+  a.L = L;
+  a.KS0 = E / 16;
   a.out_act = m->cfg.output_activation;
-  a.E = m->enc_padded;
+  a.E = E;
   a.S = n_samples;
-  a.Sp = Sp;
+  a.Sp = padded(n_samples);
+  a.dc = dc;
+  a.n_tiles = (int)(a.Sp / kTile);
   a.encT = static_cast<const _Float16*>(encT);
-  a.out_half = static_cast<_Float16*>(output_half);
-  a.radiance = reinterpret_cast<float4*>(radiance);
-  const int RT = W / 32, KS = W / 16, KS0 = a.E / 16;
-  const size_t lds = (size_t)(KS0 > KS ? KS0 : KS) * RT * 1024;
-  hipStream_t s = rtxn::as_stream(stream);
-  if (W == 64) {
-    RTXN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_train_fwd_kernel<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((mlp_train_fwd_kernel<64, false>), dim3((unsigned)(Sp / kTile)), dim3(kThreads), lds, s, a);
-  } else {
-    RTXN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_train_fwd_kernel<128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((mlp_train_fwd_kernel<128, false>), dim3((unsigned)(Sp / kTile)), dim3(kThreads), lds, s, a);
-  }
-  RTXN_LAUNCH_CHECK("mlp_train_fwd_kernel<outputs only>");
+  a.out_half = static_cast<const _Float16*>(output_half);
+  a.dout = static_cast<const _Float16*>(dout_half4);
+  a.dencT = static_cast<_Float16*>(dencT);
+  a.dparams = dparams;
+  const int RT = 2, KS = 4;
+  const size_t lds = (size_t)(a.KS0 * RT + (L - 1) * KS * RT) * 1024 + (size_t)(RT + (L - 1) * RT * KS + ((E + 31) / 32) * KS) * 1024 +
+                     8 * (size_t)kImgBytes;
+  int dev = 0, n_cu = 0;
+  RTXN_HIP(hipGetDevice(&dev));
+  RTXN_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  if (n_cu <= 0) n_cu = 256;
+  const int grid = a.n_tiles < n_cu ? a.n_tiles : n_cu;   // persistent: one block per CU (LDS- and register-bound)
+  RTXN_HIP(set_lds_once(reinterpret_cast<const void*>(mlp_bwd_fused64_kernel), (int)lds));
+  hipLaunchKernelGGL(mlp_bwd_fused64_kernel, dim3((unsigned)grid), dim3(kThreads), lds, rtxn::as_stream(stream), a);
+  RTXN_LAUNCH_CHECK("mlp_bwd_fused64_kernel");
   return RTXN_OK;
 }
 
@@ -1419,35 +1509,7 @@ extern "C" int rtxn_mlp_train_backward_recompute(const rtxn_mlp* m, const void* 
   RTXN_DEVICE_OR_FAIL();
   if (n_samples == 0) return RTXN_OK;
   RTXN_REQUIRE(encT && output_half && dout_half4 && dparams, "rtxn_mlp_train_backward_recompute: NULL buffer");
-  const int L = m->cfg.n_hidden_layers, E = m->enc_padded;
-  FusedArgs a;
-  memset(&a, 0, sizeof(a));
-  a.packed_fwd = static_cast<const uint8_t*>(m->packed_train);
-  a.packed_t = static_cast<const uint8_t*>(m->packed_t);
-  a.L = L;
-  a.KS0 = E / 16;
-  a.out_act = m->cfg.output_activation;
-  a.E = E;
-  a.S = n_samples;
-  a.Sp = padded(n_samples);
-  a.n_tiles = (int)(a.Sp / kTile);
-  a.encT = static_cast<const _Float16*>(encT);
-  a.out_half = static_cast<const _Float16*>(output_half);
-  a.dout = static_cast<const _Float16*>(dout_half4);
-  a.dencT = static_cast<_Float16*>(dencT);
-  a.dparams = dparams;
-  const int RT = 2, KS = 4;
-  const size_t lds = (size_t)(a.KS0 * RT + (L - 1) * KS * RT) * 1024 + (size_t)(RT + (L - 1) * RT * KS + ((E + 31) / 32) * KS) * 1024 +
-                     8 * (size_t)kImgBytes;
-  int dev = 0, n_cu = 0;
-  RTXN_HIP(hipGetDevice(&dev));
-  RTXN_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-  if (n_cu <= 0) n_cu = 256;
-  const int grid = a.n_tiles < n_cu ? a.n_tiles : n_cu;   // persistent: one block per CU (LDS- and register-bound)
-  RTXN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_fused64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(mlp_bwd_fused64_kernel, dim3((unsigned)grid), dim3(kThreads), lds, rtxn::as_stream(stream), a);
-  RTXN_LAUNCH_CHECK("mlp_bwd_fused64_kernel");
-  return RTXN_OK;
+  return train_backward_recompute_impl(m, encT, output_half, dout_half4, n_samples, dparams, dencT, DevCount{nullptr, 0}, stream);
 }
 
 extern "C" int rtxn_hashgrid_create(const rtxn_hashgrid_config* cfg, rtxn_hashgrid** out) {
@@ -1518,12 +1580,12 @@ extern "C" int rtxn_hashgrid_encoded_width(const rtxn_hashgrid* g, int n_dir_fre
 }
 
 static int hashgrid_encode_impl(const rtxn_hashgrid* g, int n_dir_freqs, const void* table_fp16, const SampleSrc& src, void* encT,
-                                float* t_vals, float t_scale, long n_samples, rtxn_stream_t stream) {
+                                float* t_vals, float t_scale, long n_samples, DevCount dc, rtxn_stream_t stream) {
   const long Sp = padded(n_samples);
   const int E = rtxn_hashgrid_encoded_width(g, n_dir_freqs);
   hashgrid_encode_kernel<<<dim3((unsigned)(Sp / kThreads), (unsigned)(g->cfg.n_levels + 1)), kThreads, 0, rtxn::as_stream(stream)>>>(
       levels_of(g), n_dir_freqs, static_cast<const _Float16*>(table_fp16), src, static_cast<_Float16*>(encT), t_vals, t_scale,
-      n_samples, Sp, E);
+      n_samples, Sp, E, dc);
   RTXN_LAUNCH_CHECK("hashgrid_encode_kernel");
   return RTXN_OK;
 }
@@ -1536,7 +1598,7 @@ extern "C" int rtxn_hashgrid_encode(const rtxn_hashgrid* g, int n_dir_freqs, con
   if (n_samples == 0) return RTXN_OK;
   RTXN_REQUIRE(table_fp16 && input && encT, "rtxn_hashgrid_encode: NULL buffer");
   const SampleSrc src{input, nullptr, nullptr, nullptr, 0};
-  return hashgrid_encode_impl(g, n_dir_freqs, table_fp16, src, encT, nullptr, 1.0f, n_samples, stream);
+  return hashgrid_encode_impl(g, n_dir_freqs, table_fp16, src, encT, nullptr, 1.0f, n_samples, DevCount{nullptr, 0}, stream);
 }
 
 extern "C" int rtxn_hashgrid_encode_segments(const rtxn_hashgrid* g, int n_dir_freqs, const void* table_fp16,
@@ -1550,13 +1612,13 @@ extern "C" int rtxn_hashgrid_encode_segments(const rtxn_hashgrid* g, int n_dir_f
   if (n_segments == 0) return RTXN_OK;
   RTXN_REQUIRE(table_fp16 && encT, "rtxn_hashgrid_encode_segments: NULL buffer");
   const SampleSrc src{nullptr, start_points, end_points, seg_view, sample_type == RTXN_SAMPLING_MIDPOINT_WORLD};
-  return hashgrid_encode_impl(g, n_dir_freqs, table_fp16, src, encT, t_vals, t_scale, n_segments * 32, stream);
+  return hashgrid_encode_impl(g, n_dir_freqs, table_fp16, src, encT, t_vals, t_scale, n_segments * 32, DevCount{nullptr, 0}, stream);
 }
 
 // dtable_hashed_half == NULL: every level into the fp32 table.  Otherwise (n_features == 2): the hashed levels go to the fp16
 // buffer, which holds the parameters from the first hashed level on.
 static int hashgrid_backward_impl(const rtxn_hashgrid* g, const SampleSrc& input, const void* dencT, long n_samples,
-                                  float* dtable, void* dtable_hashed_half, rtxn_stream_t stream) {
+                                  float* dtable, void* dtable_hashed_half, DevCount dc, rtxn_stream_t stream) {
   const long Sp = padded(n_samples);
   const int NL = g->cfg.n_levels, F = g->cfg.n_features;
   int first_hashed = NL;
@@ -1570,12 +1632,12 @@ static int hashgrid_backward_impl(const rtxn_hashgrid* g, const SampleSrc& input
   const unsigned sblocks = (unsigned)((n_samples + kThreads - 1) / kThreads);
   if (first_hashed > 0) {
     hashgrid_backward_kernel<false><<<dim3(sblocks, (unsigned)first_hashed), kThreads, 0, st>>>(
-        lv, 0, input, de, n_samples, Sp, dtable, nullptr, 0);
+        lv, 0, input, de, n_samples, Sp, dtable, nullptr, 0, dc);
     RTXN_LAUNCH_CHECK("hashgrid_backward_kernel");
   }
   if (first_hashed < NL) {
     hashgrid_backward_kernel<true><<<dim3(sblocks, (unsigned)(NL - first_hashed)), kThreads, 0, st>>>(
-        lv, first_hashed, input, de, n_samples, Sp, dtable, static_cast<_Float16*>(dtable_hashed_half), hashed_lo);
+        lv, first_hashed, input, de, n_samples, Sp, dtable, static_cast<_Float16*>(dtable_hashed_half), hashed_lo, dc);
     RTXN_LAUNCH_CHECK("hashgrid_backward_kernel<pk_f16>");
   }
   return RTXN_OK;
@@ -1588,7 +1650,7 @@ extern "C" int rtxn_hashgrid_backward(const rtxn_hashgrid* g, const float* input
   RTXN_DEVICE_OR_FAIL();
   if (n_samples == 0) return RTXN_OK;
   RTXN_REQUIRE(input && dencT && dtable, "rtxn_hashgrid_backward: NULL buffer");
-  return hashgrid_backward_impl(g, SampleSrc{input, nullptr, nullptr, nullptr, 0}, dencT, n_samples, dtable, nullptr, stream);
+  return hashgrid_backward_impl(g, SampleSrc{input, nullptr, nullptr, nullptr, 0}, dencT, n_samples, dtable, nullptr, DevCount{nullptr, 0}, stream);
 }
 
 extern "C" int rtxn_hashgrid_backward_mixed(const rtxn_hashgrid* g, const float* input, const void* dencT, long n_samples,
@@ -1600,7 +1662,7 @@ extern "C" int rtxn_hashgrid_backward_mixed(const rtxn_hashgrid* g, const float*
   if (n_samples == 0) return RTXN_OK;
   RTXN_REQUIRE(input && dencT && dtable && dtable_hashed_half, "rtxn_hashgrid_backward_mixed: NULL buffer");
   RTXN_REQUIRE(((uintptr_t)dtable_hashed_half & 3) == 0, "rtxn_hashgrid_backward_mixed: fp16 table must be 4-byte aligned");
-  return hashgrid_backward_impl(g, SampleSrc{input, nullptr, nullptr, nullptr, 0}, dencT, n_samples, dtable, dtable_hashed_half, stream);
+  return hashgrid_backward_impl(g, SampleSrc{input, nullptr, nullptr, nullptr, 0}, dencT, n_samples, dtable, dtable_hashed_half, DevCount{nullptr, 0}, stream);
 }
 
 extern "C" int rtxn_hashgrid_backward_segments(const rtxn_hashgrid* g, const float* start_points, const float* end_points,
@@ -1614,7 +1676,7 @@ extern "C" int rtxn_hashgrid_backward_segments(const rtxn_hashgrid* g, const flo
   if (n_segments == 0) return RTXN_OK;
   RTXN_REQUIRE(dencT && dtable, "rtxn_hashgrid_backward_segments: NULL buffer");
   const SampleSrc src{nullptr, start_points, end_points, nullptr, sample_type == RTXN_SAMPLING_MIDPOINT_WORLD};
-  return hashgrid_backward_impl(g, src, dencT, n_segments * 32, dtable, dtable_hashed_half, stream);
+  return hashgrid_backward_impl(g, src, dencT, n_segments * 32, dtable, dtable_hashed_half, DevCount{nullptr, 0}, stream);
 }
 
 extern "C" int rtxn_l2_loss(const float* pred, const float* target, long n, float loss_scale, float* values,
@@ -1631,34 +1693,117 @@ extern "C" int rtxn_l2_loss(const float* pred, const float* target, long n, floa
   return RTXN_OK;
 }
 
+static float adam_lr_eff(float lr, float beta1, float beta2, int step) {
+  return lr * sqrtf(1.0f - powf(beta2, (float)step)) / (1.0f - powf(beta1, (float)step));
+}
+static int adam_impl(const char* who, long n, float* master, void* params_fp16, const void* grads, int grads_fp16, float* m, float* v,
+                     float lr_eff, const float* lr_dev, float beta1, float beta2, float eps, float loss_scale, rtxn_stream_t stream) {
+  RTXN_REQUIRE(loss_scale != 0.0f, "%s: loss_scale = 0", who);
+  RTXN_DEVICE_OR_FAIL();
+  if (n == 0) return RTXN_OK;
+  RTXN_REQUIRE(master && params_fp16 && grads && m && v, "%s: NULL buffer", who);
+  const unsigned blocks = (unsigned)((n + kThreads - 1) / kThreads < 2048 ? (n + kThreads - 1) / kThreads : 2048);
+  if (grads_fp16)
+    adam_half_grads_kernel<<<blocks, kThreads, 0, rtxn::as_stream(stream)>>>(n, master, static_cast<__half*>(params_fp16),
+                                                                            static_cast<const __half*>(grads), m, v, lr_eff, beta1,
+                                                                            beta2, eps, 1.0f / loss_scale, lr_dev);
+  else
+    adam_kernel<<<blocks, kThreads, 0, rtxn::as_stream(stream)>>>(n, master, static_cast<__half*>(params_fp16),
+                                                                 static_cast<const float*>(grads), m, v, lr_eff, beta1, beta2, eps,
+                                                                 1.0f / loss_scale, lr_dev);
+  RTXN_LAUNCH_CHECK(grads_fp16 ? "adam_half_grads_kernel" : "adam_kernel");
+  return RTXN_OK;
+}
+
 extern "C" int rtxn_adam_step(long n, float* master, void* params_fp16, const float* grads, float* m, float* v, int step,
                               float lr, float beta1, float beta2, float eps, float loss_scale, rtxn_stream_t stream) {
   RTXN_REQUIRE(n >= 0 && step >= 1, "rtxn_adam_step: n = %ld, step = %d", n, step);
-  RTXN_REQUIRE(loss_scale != 0.0f, "rtxn_adam_step: loss_scale = 0");
-  RTXN_DEVICE_OR_FAIL();
-  if (n == 0) return RTXN_OK;
-  RTXN_REQUIRE(master && params_fp16 && grads && m && v, "rtxn_adam_step: NULL buffer");
-  const float lr_eff = lr * sqrtf(1.0f - powf(beta2, (float)step)) / (1.0f - powf(beta1, (float)step));
-  const unsigned blocks = (unsigned)((n + kThreads - 1) / kThreads < 2048 ? (n + kThreads - 1) / kThreads : 2048);
-  adam_kernel<<<blocks, kThreads, 0, rtxn::as_stream(stream)>>>(n, master, static_cast<__half*>(params_fp16), grads, m, v, lr_eff,
-                                                               beta1, beta2, eps, 1.0f / loss_scale);
-  RTXN_LAUNCH_CHECK("adam_kernel");
-  return RTXN_OK;
+  return adam_impl("rtxn_adam_step", n, master, params_fp16, grads, 0, m, v, adam_lr_eff(lr, beta1, beta2, step), nullptr, beta1, beta2,
+                   eps, loss_scale, stream);
 }
 
 extern "C" int rtxn_adam_step_half_grads(long n, float* master, void* params_fp16, const void* grads_fp16, float* m, float* v,
                                          int step, float lr, float beta1, float beta2, float eps, float loss_scale,
                                          rtxn_stream_t stream) {
   RTXN_REQUIRE(n >= 0 && step >= 1, "rtxn_adam_step_half_grads: n = %ld, step = %d", n, step);
-  RTXN_REQUIRE(loss_scale != 0.0f, "rtxn_adam_step_half_grads: loss_scale = 0");
+  return adam_impl("rtxn_adam_step_half_grads", n, master, params_fp16, grads_fp16, 1, m, v, adam_lr_eff(lr, beta1, beta2, step), nullptr,
+                   beta1, beta2, eps, loss_scale, stream);
+}
+
+extern "C" float rtxn_adam_effective_lr(float lr, float beta1, float beta2, int step) {
+  return step >= 1 ? adam_lr_eff(lr, beta1, beta2, step) : 0.0f;
+}
+
+extern "C" int rtxn_adam_step_captured(long n, float* master, void* params_fp16, const void* grads, int grads_fp16, float* m,
+                                       float* v, const float* effective_lr, float beta1, float beta2, float eps, float loss_scale,
+                                       rtxn_stream_t stream) {
+  RTXN_REQUIRE(n >= 0 && effective_lr, "rtxn_adam_step_captured: n = %ld, effective_lr = %p", n, (const void*)effective_lr);
+  return adam_impl("rtxn_adam_step_captured", n, master, params_fp16, grads, grads_fp16, m, v, 0.0f, effective_lr, beta1, beta2, eps,
+                   loss_scale, stream);
+}
+
+// ------------------------------------------------------------------------- a whole batch, segment count on the device
+extern "C" int rtxn_train_gradients(const rtxn_train_batch* b, rtxn_stream_t stream) {
+  RTXN_REQUIRE(b && b->mlp, "rtxn_train_gradients: NULL batch or model");
+  const rtxn_mlp* m = b->mlp;
+  int rc = check_train(m, "rtxn_train_gradients");
+  if (rc != RTXN_OK) return rc;
+  RTXN_REQUIRE(b->n_rays > 0, "rtxn_train_gradients: n_rays = %d", b->n_rays);
+  RTXN_REQUIRE(b->segment_capacity > 0 && b->segment_capacity <= kMaxTrainSamples / 32 && b->segment_capacity <= 0x7fffffffL,
+               "rtxn_train_gradients: segment_capacity = %ld", b->segment_capacity);
+  rc = check_segments("rtxn_train_gradients", b->start_points, b->end_points, b->seg_view, b->segment_capacity, b->sample_type);
+  if (rc != RTXN_OK) return rc;
+  RTXN_REQUIRE(b->total_segments && b->num_stored && b->indices, "rtxn_train_gradients: NULL total_segments / num_stored / indices");
+  RTXN_REQUIRE(b->vr_mode == RTXN_VR_COMPAT || b->vr_mode == RTXN_VR_NERF, "rtxn_train_gradients: vr_mode %d", b->vr_mode);
+  RTXN_REQUIRE(b->encT && b->output_half && b->radiance && b->t_vals && b->radiance_gradients && b->pixels && b->loss_gradients_half &&
+               b->targets && b->dparams, "rtxn_train_gradients: NULL buffer");
+  const bool hash = b->grid != nullptr;
+  if (hash) {
+    RTXN_REQUIRE(b->table_fp16 && b->dencT && b->dtable, "rtxn_train_gradients: hash grid without table / dencT / dtable");
+    RTXN_REQUIRE(!b->dtable_hashed_half || b->grid->cfg.n_features == 2, "rtxn_train_gradients: packed fp16 atomics need n_features == 2");
+    RTXN_REQUIRE(rtxn_hashgrid_encoded_width(b->grid, b->n_dir_freqs) == m->enc_padded,
+                 "rtxn_train_gradients: the grid encodes %d features, the model takes %d", rtxn_hashgrid_encoded_width(b->grid, b->n_dir_freqs), m->enc_padded);
+  } else {
+    RTXN_REQUIRE(m->cfg.encoding == RTXN_ENC_FREQUENCY && m->cfg.n_pos_dims == 3 && m->cfg.n_dir_dims == 2,
+                 "rtxn_train_gradients: without a grid the model must carry the 3 + 2 frequency encoding");
+  }
+  const bool recompute = b->workspace == nullptr;
+  if (recompute)
+    RTXN_REQUIRE(rtxn_mlp_train_recompute_supported(m), "rtxn_train_gradients: workspace == NULL selects the recompute path, which this model "
+                 "(%d wide, %d layers, %d features) does not have", m->cfg.n_neurons, m->cfg.n_hidden_layers, m->enc_padded);
   RTXN_DEVICE_OR_FAIL();
-  if (n == 0) return RTXN_OK;
-  RTXN_REQUIRE(master && params_fp16 && grads_fp16 && m && v, "rtxn_adam_step_half_grads: NULL buffer");
-  const float lr_eff = lr * sqrtf(1.0f - powf(beta2, (float)step)) / (1.0f - powf(beta1, (float)step));
-  const unsigned blocks = (unsigned)((n + kThreads - 1) / kThreads < 2048 ? (n + kThreads - 1) / kThreads : 2048);
-  adam_half_grads_kernel<<<blocks, kThreads, 0, rtxn::as_stream(stream)>>>(n, master, static_cast<__half*>(params_fp16),
-                                                                          static_cast<const __half*>(grads_fp16), m, v, lr_eff, beta1,
-                                                                          beta2, eps, 1.0f / loss_scale);
-  RTXN_LAUNCH_CHECK("adam_half_grads_kernel");
-  return RTXN_OK;
+  const DevCount dc{b->total_segments, (int)b->segment_capacity};
+  const long cap_samples = b->segment_capacity * 32;
+  const SampleSrc src{nullptr, b->start_points, b->end_points, b->seg_view, b->sample_type == RTXN_SAMPLING_MIDPOINT_WORLD};
+  // launchSampler + encoding (main.cu:703,721)
+  rc = hash ? hashgrid_encode_impl(b->grid, b->n_dir_freqs, b->table_fp16, src, b->encT, b->t_vals, b->t_scale, cap_samples, dc, stream)
+            : encode_frequency_impl(m, src, b->encT, b->t_vals, b->t_scale, cap_samples, dc, stream);
+  if (rc != RTXN_OK) return rc;
+  // network->forward (main.cu:721)
+  rc = train_forward_impl(m, b->encT, cap_samples, b->workspace, b->output_half, b->radiance, dc, stream);
+  if (rc != RTXN_OK) return rc;
+  // launch_volrender_cuda, loss->evaluate, launch_volrender_backward_cuda (main.cu:737-767): per ray, no sample count needed
+  if (b->vr_mode == RTXN_VR_NERF) {
+    rc = rtxn_volrender_l2_train(b->radiance, b->t_vals, b->num_stored, b->indices, b->n_rays, 32, b->targets, b->loss_scale, b->pixels,
+                                 b->loss_gradients_half, b->loss_sum, b->radiance_gradients, stream);
+    if (rc != RTXN_OK) return rc;
+  } else {
+    rc = rtxn_volrender_fwd(nullptr, b->radiance, b->num_stored, b->indices, b->t_vals, b->n_rays, 32, b->pixels, b->vr_mode, stream);
+    if (rc != RTXN_OK) return rc;
+    rc = rtxn_l2_loss(b->pixels, b->targets, 3L * b->n_rays, b->loss_scale, nullptr, b->loss_gradients_half, b->loss_sum, stream);
+    if (rc != RTXN_OK) return rc;
+    rc = rtxn_volrender_bwd(nullptr, b->loss_gradients_half, b->radiance, b->t_vals, b->num_stored, b->indices, b->n_rays, 32,
+                            b->radiance_gradients, b->vr_mode, stream);
+    if (rc != RTXN_OK) return rc;
+  }
+  // network->backward (main.cu:781)
+  rc = recompute ? train_backward_recompute_impl(m, b->encT, b->output_half, b->radiance_gradients, cap_samples, b->dparams, b->dencT, dc, stream)
+                 : train_backward_impl(m, b->encT, b->output_half, b->radiance_gradients, cap_samples, b->workspace, b->dparams,
+                                       hash ? b->dencT : nullptr, dc, stream);
+  if (rc != RTXN_OK) return rc;
+  if (hash) {
+    const SampleSrc bsrc{nullptr, b->start_points, b->end_points, nullptr, b->sample_type == RTXN_SAMPLING_MIDPOINT_WORLD};
+    rc = hashgrid_backward_impl(b->grid, bsrc, b->dencT, cap_samples, b->dtable, b->dtable_hashed_half, dc, stream);
+  }
+  return rc;
 }

@@ -23,13 +23,24 @@
 
 namespace {
 
-__device__ __forceinline__ float wave_incl_scan_f(float v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    float t = __shfl_up(v, d, 64);
-    if (lane >= d) v += t;
-  }
+// Inclusive prefix sum over the 64 lanes in six DPP adds (row_shr 1/2/4/8 inside each row of 16, then row_bcast:15 into rows
+// 1 and 3 and row_bcast:31 into rows 2 and 3): no LDS crossbar round trips -- the __shfl_up form (six dependent
+// ds_bpermute_b32) was most of a compositor step's latency (tools/probe/dpp_scan_probe.hip checks the lane pattern).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_term(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+}
+__device__ __forceinline__ float wave_incl_scan_f(float v, int /*lane*/) {
+  v += dpp_term<0x111, 0xf>(v);
+  v += dpp_term<0x112, 0xf>(v);
+  v += dpp_term<0x114, 0xf>(v);
+  v += dpp_term<0x118, 0xf>(v);
+  v += dpp_term<0x142, 0xa>(v);
+  v += dpp_term<0x143, 0xc>(v);
   return v;
+}
+__device__ __forceinline__ float lane63(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -409,110 +420,154 @@ __global__ __launch_bounds__(256) void volrender_l2_fused_kernel(const float4* _
   }
 }
 
-// The same with two samples per lane (128 per step) and the next step's loads in flight under the scans.  A training batch
-// is a few thousand rays, far fewer waves than the chip holds, so this launch takes as long as its LONGEST ray's chain of
-// dependent steps (load -> scan -> exp, twice over: two sweeps): halving the steps and hiding the load is what shortens it.
-// Needs an even K.
-__global__ __launch_bounds__(256) void volrender_l2_fused_pair_kernel(const float4* __restrict__ radiance, const float* __restrict__ step_len,
-                                                                      const int* __restrict__ num_hits, const int* __restrict__ indices,
-                                                                      int batch_size, int K, const float* __restrict__ target,
-                                                                      float loss_scale, float* __restrict__ pixels,
-                                                                      __half* __restrict__ loss_gradients, float* __restrict__ loss_sum,
-                                                                      half4* __restrict__ grads) {
-  const int lane = threadIdx.x & 63;
-  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (ray >= batch_size) return;
-  const long base = (long)indices[ray] * K;
-  const long n = (long)num_hits[ray] * K;          // even
-  const float inv_n = 1.0f / (float)(3L * batch_size);
-  struct Pair { float4 c0, c1; float d0, d1; };
-  auto load = [&](long s0, Pair& p) {
-    const long i0 = s0 + 2 * lane;
-    p.c0 = p.c1 = make_float4(0.f, 0.f, 0.f, 0.f);
-    p.d0 = p.d1 = 0.0f;
-    if (i0 < n) {
-      p.c0 = radiance[base + i0];
-      p.c1 = radiance[base + i0 + 1];
-      const float2 dd = *reinterpret_cast<const float2*>(step_len + base + i0);
-      p.d0 = dd.x;
-      p.d1 = dd.y;
+// The training compositor as it runs by default: U blocks of 128 samples (two adjacent samples per lane) per step, their scans
+// independent and interleaved, the block offsets chained through scalar registers.  A training batch has few, long rays (the
+// configs[2] batch: 12 % of the 4096 rays hit anything, those cross 44 occupied cells on average and up to 128 = 4096
+// samples), so the launch lasts as long as the LONGEST ray's chain of dependent steps: 512 samples per step make that 8
+// steps per sweep instead of 32.  The loss is reduced per block and added ONCE per block at the very end: a same-address
+// atomic per ray sat in front of the second sweep's loads in every wave's in-order memory counter (+45 us of 91).
+template <int U>
+__global__ __launch_bounds__(256) void volrender_l2_fused_multi_kernel(const float4* __restrict__ radiance, const float* __restrict__ step_len,
+                                                                       const int* __restrict__ num_hits, const int* __restrict__ indices,
+                                                                       int batch_size, int K, const float* __restrict__ target,
+                                                                       float loss_scale, float* __restrict__ pixels,
+                                                                       __half* __restrict__ loss_gradients, float* __restrict__ loss_sum,
+                                                                       half4* __restrict__ grads) {
+  __shared__ float red[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ray = blockIdx.x * 4 + wave;
+  float loss_part = 0.0f;
+  if (ray < batch_size) {
+    const long base = (long)indices[ray] * K;
+    const long n = (long)num_hits[ray] * K;          // even
+    const float inv_n = 1.0f / (float)(3L * batch_size);
+    constexpr long STEP = 128L * U;
+    struct Pair { float4 c0, c1; float d0, d1; };
+    auto load = [&](long s0, Pair (&p)[U]) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long i0 = s0 + 128 * u + 2 * lane;
+        p[u].c0 = p[u].c1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        p[u].d0 = p[u].d1 = 0.0f;
+        if (i0 < n) {
+          p[u].c0 = radiance[base + i0];
+          p[u].c1 = radiance[base + i0 + 1];
+          const float2 dd = *reinterpret_cast<const float2*>(step_len + base + i0);
+          p[u].d0 = dd.x;
+          p[u].d1 = dd.y;
+        }
+      }
+    };
+    // sweep 1: the pixel
+    float T_carry = 0.0f, ar = 0.0f, ag = 0.0f, ab = 0.0f;
+    Pair cur[U], nxt[U];
+    if (n > 0) load(0, cur);
+    for (long s0 = 0; s0 < n; s0 += STEP) {
+      if (s0 + STEP < n) load(s0 + STEP, nxt);
+      float x0[U], x1[U], pr[U], incl[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        x0[u] = cur[u].d0 * cur[u].c0.w;                 // inactive lanes hold zeros: x = 0, w = 0
+        x1[u] = cur[u].d1 * cur[u].c1.w;
+        pr[u] = x0[u] + x1[u];
+        incl[u] = wave_incl_scan_f(pr[u], lane);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float T0 = T_carry + (incl[u] - pr[u]);
+        const float w0 = expf(-T0) * (1.0f - expf(-x0[u])), w1 = expf(-(T0 + x0[u])) * (1.0f - expf(-x1[u]));
+        ar = fmaf(w1, cur[u].c1.x, fmaf(w0, cur[u].c0.x, ar));
+        ag = fmaf(w1, cur[u].c1.y, fmaf(w0, cur[u].c0.y, ag));
+        ab = fmaf(w1, cur[u].c1.z, fmaf(w0, cur[u].c0.z, ab));
+        T_carry += lane63(incl[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) cur[u] = nxt[u];
     }
-  };
-  // sweep 1: the pixel
-  float T_carry = 0.0f, ar = 0.0f, ag = 0.0f, ab = 0.0f;
-  Pair cur, nxt;
-  if (n > 0) load(0, cur);
-  for (long s0 = 0; s0 < n; s0 += 128) {
-    if (s0 + 128 < n) load(s0 + 128, nxt);
-    const float x0 = cur.d0 * cur.c0.w, x1 = cur.d1 * cur.c1.w;     // inactive lanes hold zeros: x = 0, w = 0
-    const float pr = x0 + x1;
-    const float incl = wave_incl_scan_f(pr, lane);
-    const float T0 = T_carry + (incl - pr);
-    const float w0 = expf(-T0) * (1.0f - expf(-x0)), w1 = expf(-(T0 + x0)) * (1.0f - expf(-x1));
-    ar = fmaf(w1, cur.c1.x, fmaf(w0, cur.c0.x, ar));
-    ag = fmaf(w1, cur.c1.y, fmaf(w0, cur.c0.y, ag));
-    ab = fmaf(w1, cur.c1.z, fmaf(w0, cur.c0.z, ab));
-    T_carry += __shfl(incl, 63, 64);
-    cur = nxt;
+    ar = wave_sum(ar);
+    ag = wave_sum(ag);
+    ab = wave_sum(ab);
+    const float e0 = ar - target[3 * (long)ray], e1 = ag - target[3 * (long)ray + 1], e2 = ab - target[3 * (long)ray + 2];
+    const __half h0 = __float2half(loss_scale * 2.0f * e0 * inv_n), h1 = __float2half(loss_scale * 2.0f * e1 * inv_n),
+                 h2 = __float2half(loss_scale * 2.0f * e2 * inv_n);
+    const float g0 = __half2float(h0), g1 = __half2float(h1), g2 = __half2float(h2);
+    if (lane == 0) {
+      pixels[3 * (long)ray] = ar;
+      pixels[3 * (long)ray + 1] = ag;
+      pixels[3 * (long)ray + 2] = ab;
+      if (loss_gradients) {
+        loss_gradients[3 * (long)ray] = h0;
+        loss_gradients[3 * (long)ray + 1] = h1;
+        loss_gradients[3 * (long)ray + 2] = h2;
+      }
+    }
+    loss_part = (e0 * e0 + e1 * e1 + e2 * e2) * inv_n;
+    const float S = g0 * ar + g1 * ag + g2 * ab;
+    // sweep 2: per-sample gradients (the radiance is re-read: cache hits)
+    T_carry = 0.0f;
+    float P_carry = 0.0f;
+    if (n > 0) load(0, cur);
+    for (long s0 = 0; s0 < n; s0 += STEP) {
+      if (s0 + STEP < n) load(s0 + STEP, nxt);
+      float x0[U], x1[U], pr[U], incl[U], T0[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        x0[u] = cur[u].d0 * cur[u].c0.w;
+        x1[u] = cur[u].d1 * cur[u].c1.w;
+        pr[u] = x0[u] + x1[u];
+        incl[u] = wave_incl_scan_f(pr[u], lane);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        T0[u] = T_carry + (incl[u] - pr[u]);
+        T_carry += lane63(incl[u]);
+      }
+      float Ti0[U], Ti1[U], ex0[U], ex1[U], gc0[U], gc1[U], wgc1[U], pin[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        Ti0[u] = expf(-T0[u]);
+        Ti1[u] = expf(-(T0[u] + x0[u]));
+        ex0[u] = expf(-x0[u]);
+        ex1[u] = expf(-x1[u]);
+        gc0[u] = g0 * cur[u].c0.x + g1 * cur[u].c0.y + g2 * cur[u].c0.z;
+        gc1[u] = g0 * cur[u].c1.x + g1 * cur[u].c1.y + g2 * cur[u].c1.z;
+        const float wgc0 = Ti0[u] * (1.0f - ex0[u]) * gc0[u];
+        wgc1[u] = Ti1[u] * (1.0f - ex1[u]) * gc1[u];
+        pin[u] = wave_incl_scan_f(wgc0 + wgc1[u], lane);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long i0 = s0 + 128 * u + 2 * lane;
+        const float pincl1 = P_carry + pin[u];          // inclusive prefix at the pair's second sample
+        const float pincl0 = pincl1 - wgc1[u];
+        P_carry += lane63(pin[u]);
+        if (i0 < n) {
+          const float a0 = 1.0f - ex0[u], a1 = 1.0f - ex1[u];
+          half4 o0, o1;
+          o0.x = __float2half(g0 * Ti0[u] * a0);
+          o0.y = __float2half(g1 * Ti0[u] * a0);
+          o0.z = __float2half(g2 * Ti0[u] * a0);
+          o0.w = __float2half(cur[u].d0 * (Ti0[u] * ex0[u] * gc0[u] - (S - pincl0)));
+          o1.x = __float2half(g0 * Ti1[u] * a1);
+          o1.y = __float2half(g1 * Ti1[u] * a1);
+          o1.z = __float2half(g2 * Ti1[u] * a1);
+          o1.w = __float2half(cur[u].d1 * (Ti1[u] * ex1[u] * gc1[u] - (S - pincl1)));
+          uint4 packed;
+          packed.x = *reinterpret_cast<const unsigned*>(&o0.x);
+          packed.y = *reinterpret_cast<const unsigned*>(&o0.z);
+          packed.z = *reinterpret_cast<const unsigned*>(&o1.x);
+          packed.w = *reinterpret_cast<const unsigned*>(&o1.z);
+          *reinterpret_cast<uint4*>(grads + base + i0) = packed;      // two half4: one 16-byte store
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+    }
   }
-  ar = wave_sum(ar);
-  ag = wave_sum(ag);
-  ab = wave_sum(ab);
-  const float e0 = ar - target[3 * (long)ray], e1 = ag - target[3 * (long)ray + 1], e2 = ab - target[3 * (long)ray + 2];
-  const __half h0 = __float2half(loss_scale * 2.0f * e0 * inv_n), h1 = __float2half(loss_scale * 2.0f * e1 * inv_n),
-               h2 = __float2half(loss_scale * 2.0f * e2 * inv_n);
-  const float g0 = __half2float(h0), g1 = __half2float(h1), g2 = __half2float(h2);
-  if (lane == 0) {
-    pixels[3 * (long)ray] = ar;
-    pixels[3 * (long)ray + 1] = ag;
-    pixels[3 * (long)ray + 2] = ab;
-    if (loss_gradients) {
-      loss_gradients[3 * (long)ray] = h0;
-      loss_gradients[3 * (long)ray + 1] = h1;
-      loss_gradients[3 * (long)ray + 2] = h2;
-    }
-    if (loss_sum) atomicAdd(loss_sum, (e0 * e0 + e1 * e1 + e2 * e2) * inv_n);
-  }
-  const float S = g0 * ar + g1 * ag + g2 * ab;
-  // sweep 2: per-sample gradients (the radiance is re-read: cache hits)
-  T_carry = 0.0f;
-  float P_carry = 0.0f;
-  if (n > 0) load(0, cur);
-  for (long s0 = 0; s0 < n; s0 += 128) {
-    if (s0 + 128 < n) load(s0 + 128, nxt);
-    const long i0 = s0 + 2 * lane;
-    const float x0 = cur.d0 * cur.c0.w, x1 = cur.d1 * cur.c1.w;
-    const float pr = x0 + x1;
-    const float incl = wave_incl_scan_f(pr, lane);
-    const float T0 = T_carry + (incl - pr);
-    const float Ti0 = expf(-T0), Ti1 = expf(-(T0 + x0));
-    const float ex0 = expf(-x0), ex1 = expf(-x1);
-    const float a0 = 1.0f - ex0, a1 = 1.0f - ex1;
-    const float gc0 = g0 * cur.c0.x + g1 * cur.c0.y + g2 * cur.c0.z, gc1 = g0 * cur.c1.x + g1 * cur.c1.y + g2 * cur.c1.z;
-    const float wgc0 = Ti0 * a0 * gc0, wgc1 = Ti1 * a1 * gc1;
-    const float pw = wgc0 + wgc1;
-    const float pincl1 = P_carry + wave_incl_scan_f(pw, lane);     // inclusive prefix at the pair's second sample
-    const float pincl0 = pincl1 - wgc1;
-    if (i0 < n) {
-      half4 o0, o1;
-      o0.x = __float2half(g0 * Ti0 * a0);
-      o0.y = __float2half(g1 * Ti0 * a0);
-      o0.z = __float2half(g2 * Ti0 * a0);
-      o0.w = __float2half(cur.d0 * (Ti0 * ex0 * gc0 - (S - pincl0)));
-      o1.x = __float2half(g0 * Ti1 * a1);
-      o1.y = __float2half(g1 * Ti1 * a1);
-      o1.z = __float2half(g2 * Ti1 * a1);
-      o1.w = __float2half(cur.d1 * (Ti1 * ex1 * gc1 - (S - pincl1)));
-      uint4 packed;
-      packed.x = *reinterpret_cast<const unsigned*>(&o0.x);
-      packed.y = *reinterpret_cast<const unsigned*>(&o0.z);
-      packed.z = *reinterpret_cast<const unsigned*>(&o1.x);
-      packed.w = *reinterpret_cast<const unsigned*>(&o1.z);
-      *reinterpret_cast<uint4*>(grads + base + i0) = packed;      // two half4: one 16-byte store
-    }
-    T_carry += __shfl(incl, 63, 64);
-    P_carry = __shfl(pincl1, 63, 64);
-    cur = nxt;
+  if (loss_sum) {
+    if (lane == 0) red[wave] = loss_part;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss_sum, (red[0] + red[1]) + (red[2] + red[3]));
   }
 }
 
@@ -653,7 +708,7 @@ extern "C" int rtxn_volrender_l2_train(const float* network_outputs, const float
                "rtxn_volrender_l2_train: radiance must be 16-byte and gradients 8-byte aligned");
   const bool pairs = num_samples_per_hit % 2 == 0 && ((uintptr_t)ray_hit & 7) == 0 && ((uintptr_t)radiance_gradients & 15) == 0;
   if (pairs)
-    volrender_l2_fused_pair_kernel<<<(batch_size + 3) / 4, 256, 0, s>>>(reinterpret_cast<const float4*>(network_outputs), ray_hit, num_hits,
+    volrender_l2_fused_multi_kernel<4><<<(batch_size + 3) / 4, 256, 0, s>>>(reinterpret_cast<const float4*>(network_outputs), ray_hit, num_hits,
                                                                         indices, batch_size, num_samples_per_hit, target, loss_scale, pixels,
                                                                         static_cast<__half*>(loss_gradients_half), loss_sum,
                                                                         static_cast<half4*>(radiance_gradients));

@@ -415,6 +415,172 @@ class Trainer:
         self.net.set_params(self.params)
         return header
 
+    # ------------------------------------------------------------------------------------------ captured step (hipGraph)
+    _LR_TABLE = 1 << 16     # beyond ~2^16 steps the bias correction is exactly 1.0f for beta2 <= 0.999
+
+    def capture_step(self, n_rays, launch_segments=None):
+        """Capture the whole optimisation step for batches of exactly `n_rays` rays as a hipGraph: traversal (count, scan,
+        write) -> rtxn_train_gradients (sampler ... backward with the segment count read ON THE DEVICE) -> Adam -> weight
+        re-pack, with no host round trip anywhere (the reference synchronises for the segment count, main.cu:632, and so
+        does step()).  Afterwards fill graph_rays_o / graph_rays_d / graph_targets (static device buffers) and call
+        step_captured().
+
+        launch_segments: the segment count the captured launches are SIZED for (grids and the row stride of the
+        feature-major workspaces); default: the trainer's max_segments.  A batch that needs more is cut off on the device
+        exactly as in step() and counted in truncated_steps; blocks past the live samples exit at once, so an estimate
+        ~1.5x the typical count costs nothing measurable while a 20x one costs a few empty-block dispatches per kernel.
+
+        Data parallel: gradients and optimizer are captured as two graphs with the all-reduces between them."""
+        if not self.fold_sampler:
+            raise RuntimeError("capture_step needs the folded sampler (RTXN_TRAIN_FOLD_SAMPLER=0 is set)")
+        n = int(n_rays)
+        if n < 1 or n > self.B:
+            raise ValueError(f"capture_step: n_rays = {n} outside [1, batch_rays = {self.B}]")
+        cap = int(launch_segments) if launch_segments else self.max_segments
+        cap = max(1, min(cap, self.max_segments))
+        d = self.dev
+        self.graph_rays_o = torch.zeros((n, 3), device=d)
+        self.graph_rays_d = torch.zeros((n, 3), device=d)
+        self.graph_rays_d[:, 2] = 1.0
+        self.graph_targets = torch.zeros((n, 3), device=d)
+        self._g_n, self._g_cap = n, cap
+        self._g_total_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        # bias-corrected rates per step number, computed by the library's own host function (bit-identical to step());
+        # the graph looks its entry up with a device-side step counter
+        T = self._LR_TABLE
+        tab = np.zeros((T, 2), np.float32)
+        for t in range(1, T):
+            tab[t, 0] = api.adam_effective_lr(self.lr, 0.9, 0.999, t)
+            tab[t, 1] = api.adam_effective_lr(self.lr * 10.0, 0.9, 0.999, t)
+            if t > 64 and tab[t, 0] == tab[t - 1, 0] and tab[t, 1] == tab[t - 1, 1] and tab[t - 1, 0] == tab[t - 2, 0]:
+                tab[t:] = tab[t]          # converged: the rest of the table is this value
+                break
+        self._g_lr_table = torch.from_numpy(tab).to(d)
+        self._g_step = torch.full((1,), self.step_count, dtype=torch.int64, device=d)
+        self._g_idx = torch.zeros(1, dtype=torch.int64, device=d)
+        self._g_lr = torch.zeros((1, 2), device=d)
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self._g_world = world
+
+        def grads():
+            self._captured_gradients(n, cap)
+
+        def apply():
+            self._captured_apply(float(world))
+
+        # one eager pass on a side stream (kernel attributes, lazy module state), then capture
+        side = torch.cuda.Stream(device=d)
+        side.wait_stream(torch.cuda.current_stream())
+        state = (self.master.clone(), self.params.clone(), self.adam_m.clone(), self.adam_v.clone())
+        tstate = (self.table_master.clone(), self.table.clone(), self.table_m.clone(), self.table_v.clone()) if self.encoding == "hash" else None
+        with torch.cuda.stream(side):
+            grads()
+            apply()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        # undo the warm-up step: same parameters and step number as before capture_step()
+        for dst, src in zip((self.master, self.params, self.adam_m, self.adam_v), state):
+            dst.copy_(src)
+        if tstate is not None:
+            for dst, src in zip((self.table_master, self.table, self.table_m, self.table_v), tstate):
+                dst.copy_(src)
+        self.net.set_params_training(self.params)
+        self._g_step.fill_(self.step_count)
+        torch.cuda.synchronize()
+        self._g_total_host[0] = 0          # the warm-up pass is not a step
+        if world == 1:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                grads()
+                apply()
+            self._graphs = (g,)
+        else:
+            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                grads()
+            with torch.cuda.graph(g2):
+                apply()
+            self._graphs = (g1, g2)
+        return self
+
+    def _captured_gradients(self, n, cap):
+        kw = dict(grid_res=self.R, rays_o=self.graph_rays_o, rays_d=self.graph_rays_d, width=n, height=1, ray_begin=0, ray_count=n,
+                  occupancy=self.occ, occupancy_coarse=self.coarse, occupancy_bricks=self.bricks, occupancy_super=self.super_mip,
+                  mode=api.TRACE_DDA, viewing_direction=self.view_dirs, num_hits=self.num_hits, sub_rays=self.sub_rays,
+                  sub_hits=self.sub_hits)
+        api.trace_grid(None, **kw)
+        api.scan_hits(self.num_hits[:n], self.indices[:n], self.total, self.scan_ws)
+        api.trace_grid(None, indices=self.indices, start_points=self.start, end_points=self.end, seg_view=self.seg_view,
+                       num_stored=self.num_stored, segment_capacity=cap, **kw)
+        self._g_total_host.copy_(self.total, non_blocking=True)      # 4 bytes for the NEXT call's truncation check
+        self.dparams.zero_()
+        if self.encoding == "hash":
+            if self.hash_fp16:
+                self.dtable[:self.hashed_lo].zero_()
+                self.dtable_h.zero_()
+            else:
+                self.dtable.zero_()
+        self.loss.zero_()
+        hash_ = self.encoding == "hash"
+        api.train_gradients(self.net, grid=self.hg if hash_ else None, n_dir_freqs=self.hg.n_dir_freqs if hash_ else 0,
+                            table=self.table if hash_ else None, start_points=self.start, end_points=self.end, seg_view=self.seg_view,
+                            num_stored=self.num_stored, indices=self.indices, total_segments=self.total, segment_capacity=cap,
+                            n_rays=n, sample_type=self._stype(), t_scale=self.density_scale if self.mode == "nerf" else 1.0,
+                            vr_mode=api.VR_NERF if self.mode == "nerf" else api.VR_COMPAT, targets=self.graph_targets,
+                            loss_scale=self.loss_scale, encT=self.encT, dencT=self.dencT, workspace=self.ws,
+                            output_half=self.out, radiance=self.radiance, t_vals=self.t_vals, radiance_gradients=self.dout,
+                            pixels=self.pixels, loss_gradients=self.loss_grads, loss_sum=self.loss, dparams=self.dparams,
+                            dtable=self.dtable if hash_ else None, dtable_hashed_half=self.dtable_h if (hash_ and self.hash_fp16) else None)
+
+    def _captured_apply(self, grad_divisor):
+        self._g_step.add_(1)
+        torch.clamp(self._g_step, max=self._LR_TABLE - 1, out=self._g_idx)
+        torch.index_select(self._g_lr_table, 0, self._g_idx, out=self._g_lr)
+        lr_mlp, lr_tab = self._g_lr[0, 0:1], self._g_lr[0, 1:2]
+        ls = self.loss_scale * grad_divisor
+        api.adam_step_captured(self.master, self.params, self.dparams, self.adam_m, self.adam_v, lr_mlp, loss_scale=ls)
+        self.net.set_params_training(self.params)
+        if self.encoding == "hash":
+            lo = self.hashed_lo
+            if self.hash_fp16:
+                if lo > 0:
+                    api.adam_step_captured(self.table_master[:lo], self.table[:lo], self.dtable[:lo], self.table_m[:lo], self.table_v[:lo],
+                                           lr_tab, eps=1e-15, loss_scale=ls)
+                api.adam_step_captured(self.table_master[lo:], self.table[lo:], self.dtable_h, self.table_m[lo:], self.table_v[lo:],
+                                       lr_tab, eps=1e-15, loss_scale=ls)
+            else:
+                api.adam_step_captured(self.table_master, self.table, self.dtable, self.table_m, self.table_v, lr_tab, eps=1e-15,
+                                       loss_scale=ls)
+
+    def step_captured(self):
+        """Replay the captured step on graph_rays_o / graph_rays_d / graph_targets; returns the (device) loss scalar.  Unlike
+        step() it never looks at the segment count on the host: a batch without any sample still runs Adam (on a zero
+        gradient), and a truncated batch is noticed one call later (truncated_steps)."""
+        if getattr(self, "_graphs", None) is None:
+            raise RuntimeError("step_captured: call capture_step() first")
+        need = int(self._g_total_host[0])          # the previous replay's count (a stale read only delays the report)
+        if need > self._g_cap:
+            if self.truncated_steps == 0:
+                import warnings
+                warnings.warn(f"Trainer: a captured batch needed {need} segments, the graph is sized for {self._g_cap}: rays "
+                              f"truncated (capture_step(launch_segments=...)); further truncations are counted in truncated_steps")
+            self.truncated_steps += 1
+            self._g_total_host[0] = 0
+        self.step_count += 1
+        if len(self._graphs) == 1:
+            self._graphs[0].replay()
+        else:
+            self._graphs[0].replay()
+            pending = [dist.all_reduce(self.dparams, async_op=True)]
+            if self.encoding == "hash":
+                pending.extend(self._allreduce_table_grad())
+            for w in pending:
+                w.wait()
+            if self.encoding == "hash" and not self.hash_fp16:
+                self._finish_table_grad()
+            self._graphs[1].replay()
+        return self.loss
+
     # ------------------------------------------------------------------------------------------ occupancy maintenance
     @torch.no_grad()
     def update_occupancy(self, threshold=0.01, chunk=1 << 20):

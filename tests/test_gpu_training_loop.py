@@ -155,3 +155,91 @@ def test_compat_training_step_matches_oracle_chain(gpu, oracle):
     m, v = np.zeros_like(master0), np.zeros_like(master0)
     O.adam_step(master0, got_dp, m, v, 1, lr=1e-3, loss_scale=ls)
     np.testing.assert_allclose(tr.master.cpu().numpy(), master0, rtol=0, atol=2e-6)
+
+
+def _small_trainer(torch, encoding, mode, neurons, layers, seed=3, **kw):
+    import numpy as np
+    from rtx_nerf_amd import scenes
+    from rtx_nerf_amd.train import Trainer
+    R, B = 16, 900
+    words = scenes.pack_occupancy(scenes.sphere_density(R, 0.75))
+    occ = torch.from_numpy(words.view(np.int32).copy()).cuda()
+    hgd = dict(n_levels=4, n_features=2, log2_hashmap_size=11, base_resolution=4, per_level_scale=1.6)
+    return Trainer(R, occ, encoding=encoding, n_neurons=neurons, n_hidden_layers=layers, hashgrid=hgd if encoding == "hash" else None,
+                   n_dir_freqs=4, batch_rays=B, max_segments=B * 30, lr=1e-2, loss_scale=128.0,
+                   density_scale=120.0 if mode == "nerf" else 1.0, mode=mode, seed=seed, **kw)
+
+
+@pytest.mark.parametrize("encoding,mode,neurons,layers", [("hash", "nerf", 64, 4), ("freq", "nerf", 128, 2), ("freq", "compat", 64, 2),
+                                                          ("hash", "compat", 128, 2)])
+def test_captured_step_matches_the_eager_step(gpu, encoding, mode, neurons, layers):
+    """Trainer.capture_step / step_captured (one hipGraph: traversal -> rtxn_train_gradients with the segment count read on the
+    device -> Adam -> re-pack) against Trainer.step (per-stage entry points, segment count on the host) on the same batches:
+    same loss and the same parameters after several steps, up to the order of the fp32 / fp16 atomics.  Covers the recompute
+    path (64 x 4 hash), the saved-activation path with its weight-gradient GEMM (128 wide) and both compositor modes; the graph
+    is sized for MORE segments than any batch has, so every kernel runs with blocks past the live samples."""
+    import numpy as np
+    torch = gpu
+    from rtx_nerf_amd import scenes
+    from rtx_nerf_amd.train import camera_rays
+    a = _small_trainer(torch, encoding, mode, neurons, layers)
+    b = _small_trainer(torch, encoding, mode, neurons, layers)
+    B = 900
+    focal = scenes.lego_focal_length(True)
+    rng = np.random.default_rng(1)
+    batches = []
+    for i in range(6):
+        o, d = camera_rays(scenes.pose_spherical(40.0 + 50.0 * i, -30.0 + 5.0 * i, origin_scale=10.0), focal, 30, 30)
+        batches.append((o, d, torch.from_numpy(rng.uniform(0, 1, (B, 3)).astype(np.float32)).cuda()))
+    b.capture_step(B, launch_segments=B * 30)
+    assert torch.equal(a.params, b.params) and b.step_count == 0          # the warm-up pass of the capture left no trace
+    for i, (o, d, t) in enumerate(batches):
+        la = float(a.step(o, d, t).item())
+        P = int(a.total.item())
+        b.graph_rays_o.copy_(o); b.graph_rays_d.copy_(d); b.graph_targets.copy_(t)
+        lb = float(b.step_captured().item())
+        assert int(b.total.item()) == P and 0 < P < B * 30
+        assert abs(la - lb) <= 5e-4 * abs(la), (i, la, lb)
+        if i == 0:
+            # same parameters going in: the gradients agree to the order of the atomics; Adam at step 1 moves every weight
+            # by ~lr * sign(g), so parameters are compared where the gradient is not noise
+            ga, gb = a.dparams.cpu().numpy(), b.dparams.cpu().numpy()
+            assert np.linalg.norm(ga - gb) <= 1e-3 * np.linalg.norm(ga) and np.linalg.norm(ga) > 0
+            if encoding == "hash":
+                ta, tb = a.table_grad().cpu().numpy(), b.table_grad().cpu().numpy()
+                assert np.linalg.norm(ta - tb) <= 2e-3 * np.linalg.norm(ta) and np.linalg.norm(ta) > 0
+            big = np.abs(ga) > 1e-3 * np.abs(ga).max()
+            pa, pb = a.master.cpu().numpy(), b.master.cpu().numpy()
+            np.testing.assert_allclose(pa[big], pb[big], rtol=0, atol=2e-4)
+    assert a.step_count == b.step_count == 6 and b.truncated_steps == 0
+    pa, pb = a.master.cpu().numpy(), b.master.cpu().numpy()
+    assert np.linalg.norm(pa - pb) <= 3e-2 * np.linalg.norm(pa)          # six Adam steps at lr 1e-2 amplify gradient noise
+
+
+def test_captured_step_truncates_on_the_device_and_reports_it(gpu):
+    """A graph sized for fewer segments than the batch needs: rays are cut off by the traversal (num_stored), nothing is
+    written out of bounds, the step still runs, and the next call reports the truncation."""
+    import warnings
+    import numpy as np
+    torch = gpu
+    from rtx_nerf_amd import scenes
+    from rtx_nerf_amd.train import camera_rays
+    tr = _small_trainer(torch, "hash", "nerf", 64, 4)
+    B = 900
+    o, d = camera_rays(scenes.pose_spherical(40.0, -30.0, origin_scale=10.0), scenes.lego_focal_length(True), 30, 30)
+    t = torch.full((B, 3), 0.5, device="cuda")
+    tr.step(o, d, t)
+    need = int(tr.total.item())
+    cap = need // 2
+    guard = tr.start.clone()
+    tr.capture_step(B, launch_segments=cap)
+    tr.graph_rays_o.copy_(o); tr.graph_rays_d.copy_(d); tr.graph_targets.copy_(t)
+    tr.step_captured()
+    torch.cuda.synchronize()
+    assert int(tr.num_stored[:B].sum().item()) <= cap < int(tr.num_hits[:B].sum().item())
+    assert np.isfinite(float(tr.loss.item()))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        tr.step_captured()
+    assert tr.truncated_steps == 1 and any("truncated" in str(x.message) for x in w)
+    assert torch.equal(tr.start[cap:], guard[cap:])        # nothing stored past the launch capacity
