@@ -418,7 +418,7 @@ class Trainer:
     # ------------------------------------------------------------------------------------------ captured step (hipGraph)
     _LR_TABLE = 1 << 16     # beyond ~2^16 steps the bias correction is exactly 1.0f for beta2 <= 0.999
 
-    def capture_step(self, n_rays, launch_segments=None):
+    def capture_step(self, n_rays, launch_segments=None, prefetch=False):
         """Capture the whole optimisation step for batches of exactly `n_rays` rays as a hipGraph: traversal (count, scan,
         write) -> rtxn_train_gradients (sampler ... backward with the segment count read ON THE DEVICE) -> Adam -> weight
         re-pack, with no host round trip anywhere (the reference synchronises for the segment count, main.cu:632, and so
@@ -429,6 +429,13 @@ class Trainer:
         feature-major workspaces); default: the trainer's max_segments.  A batch that needs more is cut off on the device
         exactly as in step() and counted in truncated_steps; blocks past the live samples exit at once, so an estimate
         ~1.5x the typical count costs nothing measurable while a 20x one costs a few empty-block dispatches per kernel.
+
+        prefetch=True: the traversal runs ONE BATCH AHEAD, as a parallel branch of the graph.  Traversal does not depend on
+        the parameters, and on a 4096-ray batch it is pure latency (the longest ray's walk, ~80 us with the chip almost
+        empty), so step_captured() then traverses the batch it is given beside the gradient kernels of the batch given to
+        the PREVIOUS call: the first call only traverses (returns None), every later call returns the previous batch's loss,
+        and flush_captured() trains on the last batch submitted.  Two segment-buffer sets alternate.  An occupancy grid
+        updated between two calls takes effect one batch later.
 
         Data parallel: gradients and optimizer are captured as two graphs with the all-reduces between them."""
         if not self.fold_sampler:
@@ -443,8 +450,22 @@ class Trainer:
         self.graph_rays_d = torch.zeros((n, 3), device=d)
         self.graph_rays_d[:, 2] = 1.0
         self.graph_targets = torch.zeros((n, 3), device=d)
-        self._g_n, self._g_cap = n, cap
-        self._g_total_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._g_n, self._g_cap, self._g_prefetch = n, cap, bool(prefetch)
+        # the traversal's outputs, once per buffer set (set 0 = the trainer's own buffers)
+        names = ("view_dirs", "num_hits", "indices", "num_stored", "sub_hits", "total", "start", "end", "seg_view")
+        set0 = {k: getattr(self, k) for k in names}
+        sets = [set0]
+        if prefetch:
+            s1 = {k: torch.zeros_like(v) for k, v in set0.items()}
+            for k in ("start", "end", "seg_view"):       # only the launch capacity is ever written
+                s1[k] = torch.zeros((cap,) + tuple(set0[k].shape[1:]), device=d)
+            sets.append(s1)
+        for st in sets:
+            st["targets"] = torch.zeros((n, 3), device=d)
+            st["total_host"] = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._g_sets = sets
+        self._g_pending = None          # prefetch: the set that holds a traversed, not yet trained batch
+        self._g_next = 0
         # bias-corrected rates per step number, computed by the library's own host function (bit-identical to step());
         # the graph looks its entry up with a device-side step counter
         T = self._LR_TABLE
@@ -462,20 +483,17 @@ class Trainer:
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self._g_world = world
 
-        def grads():
-            self._captured_gradients(n, cap)
-
-        def apply():
-            self._captured_apply(float(world))
-
         # one eager pass on a side stream (kernel attributes, lazy module state), then capture
         side = torch.cuda.Stream(device=d)
+        self._g_side = side
         side.wait_stream(torch.cuda.current_stream())
         state = (self.master.clone(), self.params.clone(), self.adam_m.clone(), self.adam_v.clone())
         tstate = (self.table_master.clone(), self.table.clone(), self.table_m.clone(), self.table_v.clone()) if self.encoding == "hash" else None
         with torch.cuda.stream(side):
-            grads()
-            apply()
+            for k in range(len(sets)):
+                self._captured_traverse(k)
+            self._captured_gradients(0)
+            self._captured_apply(float(world))
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         # undo the warm-up step: same parameters and step number as before capture_step()
@@ -487,32 +505,63 @@ class Trainer:
         self.net.set_params_training(self.params)
         self._g_step.fill_(self.step_count)
         torch.cuda.synchronize()
-        self._g_total_host[0] = 0          # the warm-up pass is not a step
-        if world == 1:
+        for st in sets:
+            st["total_host"][0] = 0        # the warm-up pass is not a step
+
+        def capture(fn):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                grads()
-                apply()
-            self._graphs = (g,)
+                fn()
+            return g
+
+        def forked(k_traverse, then):
+            """traversal into set k_traverse on the side stream, `then` on the capturing stream, joined at the end"""
+            def body():
+                main = torch.cuda.current_stream()
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    self._captured_traverse(k_traverse)
+                then()
+                main.wait_stream(side)
+            return body
+
+        def train(k, with_apply):
+            def body():
+                self._captured_gradients(k)
+                if with_apply:
+                    self._captured_apply(float(world))
+            return body
+
+        one = world == 1
+        if not prefetch:
+            def whole():
+                self._captured_traverse(0)
+                train(0, one)()
+            self._graphs = {"step": [capture(whole)]}
         else:
-            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1):
-                grads()
-            with torch.cuda.graph(g2):
-                apply()
-            self._graphs = (g1, g2)
+            # step[k]: traverse into set k beside training on set 1-k; flush[k]: train on set k; prime: traverse into set 0
+            self._graphs = {"step": [capture(forked(k, train(1 - k, one))) for k in (0, 1)],
+                            "flush": [capture(train(k, one)) for k in (0, 1)],
+                            "prime": [capture(lambda k=k: self._captured_traverse(k)) for k in (0, 1)]}
+        if not one:
+            self._graphs["apply"] = capture(lambda: self._captured_apply(float(world)))
         return self
 
-    def _captured_gradients(self, n, cap):
+    def _captured_traverse(self, k):
+        st, n, cap = self._g_sets[k], self._g_n, self._g_cap
         kw = dict(grid_res=self.R, rays_o=self.graph_rays_o, rays_d=self.graph_rays_d, width=n, height=1, ray_begin=0, ray_count=n,
                   occupancy=self.occ, occupancy_coarse=self.coarse, occupancy_bricks=self.bricks, occupancy_super=self.super_mip,
-                  mode=api.TRACE_DDA, viewing_direction=self.view_dirs, num_hits=self.num_hits, sub_rays=self.sub_rays,
-                  sub_hits=self.sub_hits)
+                  mode=api.TRACE_DDA, viewing_direction=st["view_dirs"], num_hits=st["num_hits"], sub_rays=self.sub_rays,
+                  sub_hits=st["sub_hits"])
+        st["targets"].copy_(self.graph_targets)
         api.trace_grid(None, **kw)
-        api.scan_hits(self.num_hits[:n], self.indices[:n], self.total, self.scan_ws)
-        api.trace_grid(None, indices=self.indices, start_points=self.start, end_points=self.end, seg_view=self.seg_view,
-                       num_stored=self.num_stored, segment_capacity=cap, **kw)
-        self._g_total_host.copy_(self.total, non_blocking=True)      # 4 bytes for the NEXT call's truncation check
+        api.scan_hits(st["num_hits"][:n], st["indices"][:n], st["total"], self.scan_ws)
+        api.trace_grid(None, indices=st["indices"], start_points=st["start"], end_points=st["end"], seg_view=st["seg_view"],
+                       num_stored=st["num_stored"], segment_capacity=cap, **kw)
+        st["total_host"].copy_(st["total"], non_blocking=True)      # 4 bytes for a later call's truncation check
+
+    def _captured_gradients(self, k):
+        st, n, cap = self._g_sets[k], self._g_n, self._g_cap
         self.dparams.zero_()
         if self.encoding == "hash":
             if self.hash_fp16:
@@ -520,13 +569,12 @@ class Trainer:
                 self.dtable_h.zero_()
             else:
                 self.dtable.zero_()
-        self.loss.zero_()
         hash_ = self.encoding == "hash"
         api.train_gradients(self.net, grid=self.hg if hash_ else None, n_dir_freqs=self.hg.n_dir_freqs if hash_ else 0,
-                            table=self.table if hash_ else None, start_points=self.start, end_points=self.end, seg_view=self.seg_view,
-                            num_stored=self.num_stored, indices=self.indices, total_segments=self.total, segment_capacity=cap,
+                            table=self.table if hash_ else None, start_points=st["start"], end_points=st["end"], seg_view=st["seg_view"],
+                            num_stored=st["num_stored"], indices=st["indices"], total_segments=st["total"], segment_capacity=cap,
                             n_rays=n, sample_type=self._stype(), t_scale=self.density_scale if self.mode == "nerf" else 1.0,
-                            vr_mode=api.VR_NERF if self.mode == "nerf" else api.VR_COMPAT, targets=self.graph_targets,
+                            vr_mode=api.VR_NERF if self.mode == "nerf" else api.VR_COMPAT, targets=st["targets"],
                             loss_scale=self.loss_scale, encT=self.encT, dencT=self.dencT, workspace=self.ws,
                             output_half=self.out, radiance=self.radiance, t_vals=self.t_vals, radiance_gradients=self.dout,
                             pixels=self.pixels, loss_gradients=self.loss_grads, loss_sum=self.loss, dparams=self.dparams,
@@ -552,33 +600,67 @@ class Trainer:
                 api.adam_step_captured(self.table_master, self.table, self.dtable, self.table_m, self.table_v, lr_tab, eps=1e-15,
                                        loss_scale=ls)
 
-    def step_captured(self):
-        """Replay the captured step on graph_rays_o / graph_rays_d / graph_targets; returns the (device) loss scalar.  Unlike
-        step() it never looks at the segment count on the host: a batch without any sample still runs Adam (on a zero
-        gradient), and a truncated batch is noticed one call later (truncated_steps)."""
-        if getattr(self, "_graphs", None) is None:
-            raise RuntimeError("step_captured: call capture_step() first")
-        need = int(self._g_total_host[0])          # the previous replay's count (a stale read only delays the report)
+    def _check_truncation(self, k):
+        th = self._g_sets[k]["total_host"]
+        need = int(th[0])                  # written by an earlier replay (a stale read only delays the report)
         if need > self._g_cap:
             if self.truncated_steps == 0:
                 import warnings
                 warnings.warn(f"Trainer: a captured batch needed {need} segments, the graph is sized for {self._g_cap}: rays "
                               f"truncated (capture_step(launch_segments=...)); further truncations are counted in truncated_steps")
             self.truncated_steps += 1
-            self._g_total_host[0] = 0
+            th[0] = 0
+
+    def _finish_dp(self):
+        """world > 1: sum the gradients the gradient graph left, then replay the optimizer graph"""
+        pending = [dist.all_reduce(self.dparams, async_op=True)]
+        if self.encoding == "hash":
+            pending.extend(self._allreduce_table_grad())
+        for w in pending:
+            w.wait()
+        if self.encoding == "hash" and not self.hash_fp16:
+            self._finish_table_grad()
+        self._graphs["apply"].replay()
+
+    def step_captured(self):
+        """Replay the captured step on graph_rays_o / graph_rays_d / graph_targets; returns the (device) loss scalar -- with
+        prefetch, of the batch submitted by the previous call (None on the first).  Unlike step() it never looks at the
+        segment count on the host: a batch without any sample still runs Adam (on a zero gradient), and a truncated batch
+        is noticed a call later (truncated_steps)."""
+        if getattr(self, "_graphs", None) is None:
+            raise RuntimeError("step_captured: call capture_step() first")
+        if not self._g_prefetch:
+            self._check_truncation(0)
+            self.step_count += 1
+            self._graphs["step"][0].replay()
+            if self._g_world > 1:
+                self._finish_dp()
+            return self.loss
+        k = self._g_next
+        self._g_next = 1 - k
+        if self._g_pending is None:                     # nothing traversed yet: this call only traverses
+            self._graphs["prime"][k].replay()
+            self._g_pending = k
+            return None
+        self._check_truncation(self._g_pending)
         self.step_count += 1
-        if len(self._graphs) == 1:
-            self._graphs[0].replay()
-        else:
-            self._graphs[0].replay()
-            pending = [dist.all_reduce(self.dparams, async_op=True)]
-            if self.encoding == "hash":
-                pending.extend(self._allreduce_table_grad())
-            for w in pending:
-                w.wait()
-            if self.encoding == "hash" and not self.hash_fp16:
-                self._finish_table_grad()
-            self._graphs[1].replay()
+        self._graphs["step"][k].replay()                # traverse into set k || train on set 1-k (the pending one)
+        self._g_pending = k
+        if self._g_world > 1:
+            self._finish_dp()
+        return self.loss
+
+    def flush_captured(self):
+        """prefetch only: train on the batch the last step_captured() call submitted; returns its loss (None if there is none)."""
+        if not getattr(self, "_g_prefetch", False) or self._g_pending is None:
+            return None
+        k = self._g_pending
+        self._check_truncation(k)
+        self.step_count += 1
+        self._graphs["flush"][k].replay()
+        self._g_pending = None
+        if self._g_world > 1:
+            self._finish_dp()
         return self.loss
 
     # ------------------------------------------------------------------------------------------ occupancy maintenance

@@ -216,6 +216,44 @@ def test_captured_step_matches_the_eager_step(gpu, encoding, mode, neurons, laye
     assert np.linalg.norm(pa - pb) <= 3e-2 * np.linalg.norm(pa)          # six Adam steps at lr 1e-2 amplify gradient noise
 
 
+def test_captured_step_with_the_traversal_one_batch_ahead(gpu):
+    """capture_step(prefetch=True): every step_captured() call traverses the batch it is given as a parallel branch beside the
+    gradient kernels of the batch given to the previous call.  Same losses as the eager step, one call later; flush_captured()
+    trains on the last batch; two buffer sets alternate (an odd and an even number of steps are both exercised)."""
+    import numpy as np
+    torch = gpu
+    from rtx_nerf_amd import scenes
+    from rtx_nerf_amd.train import camera_rays
+    a = _small_trainer(torch, "hash", "nerf", 64, 4)
+    b = _small_trainer(torch, "hash", "nerf", 64, 4)
+    B = 900
+    focal = scenes.lego_focal_length(True)
+    rng = np.random.default_rng(2)
+    batches = []
+    for i in range(5):
+        o, d = camera_rays(scenes.pose_spherical(10.0 + 70.0 * i, -25.0 - 4.0 * i, origin_scale=10.0), focal, 30, 30)
+        batches.append((o, d, torch.from_numpy(rng.uniform(0, 1, (B, 3)).astype(np.float32)).cuda()))
+    b.capture_step(B, launch_segments=B * 20, prefetch=True)
+    eager = [float(a.step(o, d, t).item()) for o, d, t in batches]
+    got = []
+    for o, d, t in batches:
+        b.graph_rays_o.copy_(o); b.graph_rays_d.copy_(d); b.graph_targets.copy_(t)
+        r = b.step_captured()
+        got.append(None if r is None else float(r.item()))
+    assert got[0] is None and b.step_count == 4
+    got = got[1:] + [float(b.flush_captured().item())]
+    assert b.step_count == 5 and b.flush_captured() is None and b.truncated_steps == 0
+    for i, (x, y) in enumerate(zip(eager, got)):
+        assert abs(x - y) <= 1e-3 * abs(x), (i, eager, got)
+    pa, pb = a.master.cpu().numpy(), b.master.cpu().numpy()
+    assert np.linalg.norm(pa - pb) <= 3e-2 * np.linalg.norm(pa)
+    # and on: a new batch after the flush primes again
+    o, d, t = batches[0]
+    b.graph_rays_o.copy_(o); b.graph_rays_d.copy_(d); b.graph_targets.copy_(t)
+    assert b.step_captured() is None
+    assert np.isfinite(float(b.flush_captured().item())) and b.step_count == 6
+
+
 def test_captured_step_truncates_on_the_device_and_reports_it(gpu):
     """A graph sized for fewer segments than the batch needs: rays are cut off by the traversal (num_stored), nothing is
     written out of bounds, the step still runs, and the next call reports the truncation."""

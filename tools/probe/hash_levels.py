@@ -40,14 +40,7 @@ E, Sp = hg.encoded_width(), api.padded_samples(S)
 denc = (torch.randn((E, Sp), device="cuda") * 0.01).half()
 dt = torch.zeros(hg.n_params(), device="cuda")
 dh = torch.zeros(hg.n_params() - hg.hashed_offset(), dtype=torch.float16, device="cuda")
-for lds_floats in (0, 16384, 32768):
-    for agg in (0, 1):
-        os.environ["RTXN_HG_LDS_FLOATS"] = str(lds_floats)
-        os.environ["RTXN_HG_LDS_AGG"] = str(agg)
-        t = timeit(lambda: hg.backward_mixed(samples, denc, dt, dh))
-        print(f"config-3 grid: LDS floats {lds_floats:6d} aggregate-in-LDS {agg}: mixed backward {t*1e3:7.1f} us")
-os.environ.pop("RTXN_HG_LDS_FLOATS"); os.environ.pop("RTXN_HG_LDS_AGG")
-for nl in (1, 2, 3, 4, 6, 8, 10, 12, 14, 16):
+for nl in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16):
     hgn = api.HashGrid(nl, 2, 19, 16, 1.5, n_dir_freqs=4)
     En = hgn.encoded_width()
     dencn = (torch.randn((En, Sp), device="cuda") * 0.01).half()
