@@ -227,7 +227,8 @@ def extra_config5(steps, warmup, kernel_steps):
                     "8x256 ReLU MLP + Composite-Frequency encoding, 32 samples/segment, 4 forward-facing poses, seeded random fp16 weights",
         "ms_per_step": round(1e3 * dt / steps, 4), "mrays_s": round(W * H * steps / dt / 1e6, 4), "steps": steps, "warmup": warmup,
         "rays_per_step": W * H, "segments_per_frame_max": worst, "mean_samples_per_ray": round(smp / (W * H), 2), "dtype": "f16",
-        "roofline": {"kernel": "mlp_fwd256_kernel<3,10,2,12,segments,half4>", "bound": "mfma", "achieved": round(ach, 2),
+        "roofline": {"kernel": ("mlp_fwd256x16_kernel" if net.mfma_shape() == 16 else "mlp_fwd256_kernel") + "<3,10,2,12,segments,half4>",
+                     "mfma": "v_mfma_f32_16x16x32_f16" if net.mfma_shape() == 16 else "v_mfma_f32_32x32x16_f16", "bound": "mfma", "achieved": round(ach, 2),
                      "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_DENSE_PEAK_TFLOPS, 4),
                      "traffic": None, "flop_per_sample": flops, "samples_per_launch": smp, "kernel_ms": round(ms, 4)},
     }
@@ -426,7 +427,8 @@ def main():
         if ms:
             ach = flops * smp / (ms * 1e-3) / 1e12
             out["roofline"] = {
-                "kernel": (f"mlp_fwd16_kernel<{args.neurons},3,10,2,12,segments," if net.mfma_shape() == 16 and not args.fused
+                "kernel": ((f"mlp_fwd256x16_kernel<3,10,2,12,segments," if args.neurons == 256 else f"mlp_fwd16_kernel<{args.neurons},3,10,2,12,segments,")
+                           if net.mfma_shape() == 16 and not args.fused
                            else f"mlp_fwd{'256' if args.neurons == 256 else ''}_kernel<{args.neurons},3,10,2,12,segments,")
                           + f"{'segment-composite' if args.fused else ('half4' if pipe.compact else 'radiance')}>",
                 "mfma": "v_mfma_f32_16x16x32_f16" if net.mfma_shape() == 16 and not args.fused else "v_mfma_f32_32x32x16_f16",

@@ -839,7 +839,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd16_kernel(FwdArgs a) {
   constexpr bool ROT = OUT_MODE != 0;                   // 4-output epilogue: column tile v's outputs land in lane group v
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4, q = g >> 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   // Tile bookkeeping in 32-bit scalars: gfx950 has no 64-bit scalar compare, so `long` counters put every uniform loop
   // and fetch decision through VCC and the staging jobs behind vector branches (measured: +35 % VALU instructions).
@@ -1244,6 +1244,218 @@ __global__ __launch_bounds__(kThreads256, 2) void mlp_fwd256_kernel(FwdArgs a) {
   }
 }
 
+// The 256-wide kernel on v_mfma_f32_16x16x32_f16 (the default; RTXN_MFMA_SHAPE=32 selects mlp_fwd256_kernel).  Same block
+// (8 waves = 8 segments = 256 samples), same three-slot 32-KiB weight ring and one barrier per chunk; what changes is the
+// fragment shape: a wave's 32 samples are two 16-column tiles, lane (c, g) owns samples c and 16 + c and of every 32 features
+// the eight perm_feature16 gives its lane group; a chunk is four 16-row tiles x eight 32-wide k-steps (pipe_chunk16), the
+// encoder is mlp_fwd16_kernel's (lane-group frequency blocks, angle doubling, direction shared across the segment), and the
+// output layer is multiplied in two row-rotated variants so that column tile v's (r, g, b, sigma) land in lane group v.
+// LDS reads per FLOP are those of the 32x32x16 kernel (one 1-KiB fragment per 2 x 8 MFMA passes); the gain is the shape's.
+template <int PD, int PF, int DD, int DF, int IN_MODE, int OUT_MODE>
+__global__ __launch_bounds__(kThreads256, 2) void mlp_fwd256x16_kernel(FwdArgs a) {
+  static_assert(OUT_MODE != 2, "segment-composite epilogue: 32x32 kernel only");
+  using ES = EncSpec16<PD, PF, DD, DF>;
+  constexpr int CT = 2, KS = 8, NB = 8, KS0 = ES::k0 / 32;
+  constexpr bool ROT = OUT_MODE != 0;
+  static_assert(KS0 <= KS, "first-layer K must not exceed the width");
+  constexpr int L0_CHUNK = 4 * KS0 * 1024, HID_CHUNK = 4 * KS * 1024, OUT_CHUNK = 2 * KS * 1024;   // output: rotations 0 and 1
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 3 slots
+  const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  long total_seg = 0;
+  int n_tiles;
+  if (IN_MODE == 1) {
+    total_seg = *a.total_segments;
+    if (total_seg > a.max_segments) total_seg = a.max_segments;
+    n_tiles = (int)((total_seg + 7) / 8);
+  } else {
+    n_tiles = (int)((a.n + 255) / 256);
+  }
+  n_tiles = __builtin_amdgcn_readfirstlane(n_tiles);
+  if ((int)blockIdx.x >= n_tiles) return;
+  const int tile_step = (int)gridDim.x;
+  const int my_tiles = (n_tiles - (int)blockIdx.x + tile_step - 1) / tile_step;
+  const int n_chunks = 4 + 4 * (a.n_hidden - 1) + 1;
+  const int g_end = my_tiles * n_chunks;
+  int gq = 0;  // chunks consumed so far by this block
+
+  const float pos_scale = (float)(1u << (ES::FBP * g)), dir_scale = (float)(1u << (ES::FBD * g));   // 2^(FB g): see EncSpec16
+  float xq[CT][5];
+  auto sample_of = [&](int tile, int ct, bool& valid) -> long {
+    if (IN_MODE == 1) {
+      const long seg = (long)tile * 8 + wave_u;
+      valid = seg < total_seg;
+      return seg * 32 + 16 * ct + c;
+    }
+    const long sidx = (long)tile * 256 + wave_u * 32 + 16 * ct + c;
+    valid = sidx < a.n;
+    return sidx;
+  };
+  auto load_inputs = [&](int tile) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      bool valid_in;
+      const long samp_in = sample_of(tile, ct, valid_in);
+      if (IN_MODE == 1) {
+        const long sg = valid_in ? (samp_in >> 5) : 0;
+        const float t = (float)(16 * ct + c) * (1.0f / 32);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float og = a.start[3 * sg + k];
+          xq[ct][k] = fmaf(t, a.end[3 * sg + k] - og, og) * pos_scale;   // REGULAR sample, sampler.cu:52-66; exact scaling
+        }
+        xq[ct][3] = a.seg_view[2 * sg] * dir_scale;
+        xq[ct][4] = a.seg_view[2 * sg + 1] * dir_scale;
+      } else {
+        const long sidx = valid_in ? samp_in : 0;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) xq[ct][k] = a.input[5 * sidx + k] * (k < PD ? pos_scale : dir_scale);
+      }
+    }
+  };
+  // chunk gi of this block's stream: offset and size in the packed buffer ([layer 0: 4 chunks][hidden: 4 each][output])
+  auto chunk_src = [&](int gi, int& size) -> unsigned {
+    const int i = gi % n_chunks;
+    if (i < 4) { size = L0_CHUNK; return (unsigned)i * L0_CHUNK; }
+    if (i < n_chunks - 1) { size = HID_CHUNK; return 4u * L0_CHUNK + (unsigned)(i - 4) * HID_CHUNK; }
+    size = OUT_CHUNK;
+    return 4u * L0_CHUNK + (unsigned)(n_chunks - 5) * HID_CHUNK;
+  };
+  auto issue = [&](int gi) {
+    int size;
+    const unsigned off = chunk_src(gi, size);
+    stage512(a.packed + off, smem + (gi % 3) * kSlot256, size, tid);
+  };
+  issue(0);
+  if (g_end > 1) issue(1);
+  rtxn::StageJob sj;
+  int chunk_in_tile = 0, prefetch_tile = -1;
+  auto next_chunk = [&]() -> const uint8_t* {
+    rtxn::staged_barrier();  // chunk gq landed; everyone is done with chunk gq-1
+    if (chunk_in_tile++ == 1 && prefetch_tile >= 0) load_inputs(prefetch_tile);   // behind a barrier: never waited on early
+    int size = 0;
+    const unsigned off = gq + 2 < g_end ? chunk_src(gq + 2, size) : 0u;
+    sj.g = a.packed + (unsigned)__builtin_amdgcn_readfirstlane((int)off);
+    sj.lds = smem + (unsigned)__builtin_amdgcn_readfirstlane(((gq + 2) % 3) * kSlot256);
+    sj.nfrags = __builtin_amdgcn_readfirstlane(size / 1024);
+    const uint8_t* p = smem + (gq % 3) * kSlot256;
+    ++gq;
+    return p;
+  };
+
+  load_inputs((int)blockIdx.x);
+
+  for (int tile = (int)blockIdx.x; tile < n_tiles; tile += tile_step) {
+    if (IN_MODE == 1 && OUT_MODE == 1 && a.t_vals) {
+      int lane_t = lane;
+      asm volatile("" : "+v"(lane_t));
+      const long seg = (long)tile * 8 + wave_u;
+      if (seg < total_seg && lane_t < 32) a.t_vals[seg * 32 + lane_t] = (float)(lane_t + 1) * (1.0f / 32);
+    }
+    constexpr bool SHARE = RTXN_SHARE_DIR && IN_MODE == 1 && DirShare16<PD, PF, DD, DF>::possible;
+    int dirs[1][DirShare16<PD, PF, DD, DF>::n_dwords];
+    if constexpr (SHARE) {
+      float dg[DD];
+#pragma unroll
+      for (int dd = 0; dd < DD; ++dd) dg[dd] = xq[0][PD + dd];
+      share_direction16<PD, PF, DD, DF>(dg, lane, dirs[0]);
+    }
+    half8 bf[NB][CT], bg[NB][CT];
+    rtxn::floatx4 acc2[2][CT];
+    encode_layer0_input<ES, PD, PF, DD, DF, KS0, NB, CT, SHARE>(xq, dirs, bf);
+    chunk_in_tile = 0;
+    prefetch_tile = tile + tile_step < n_tiles ? tile + tile_step : -1;
+
+    auto layer = [&](auto ks_tag, auto pend_tag, half8 (&in)[NB][CT], half8 (&out)[NB][CT]) {
+      constexpr int KSL = decltype(ks_tag)::value;
+      constexpr bool PEND0 = decltype(pend_tag)::value;
+      const uint8_t* w = next_chunk();
+      rtxn::pipe_chunk16<KSL, NB, CT, 4, 0, PEND0>(w, sj, in, out, acc2, wave_u, lane);
+      w = next_chunk();
+      rtxn::pipe_chunk16<KSL, NB, CT, 4, 4, true>(w, sj, in, out, acc2, wave_u, lane);
+      w = next_chunk();
+      rtxn::pipe_chunk16<KSL, NB, CT, 4, 8, true>(w, sj, in, out, acc2, wave_u, lane);
+      w = next_chunk();
+      rtxn::pipe_chunk16<KSL, NB, CT, 4, 12, true>(w, sj, in, out, acc2, wave_u, lane);
+    };
+    auto finish = [&](half8 (&in)[NB][CT]) {
+      const uint8_t* w = next_chunk();
+      rtxn::stage_chunk<0, 8>(sj, wave_u, lane);
+      rtxn::stage_chunk<1, 8>(sj, wave_u, lane);
+      rtxn::stage_chunk<2, 8>(sj, wave_u, lane);
+      rtxn::stage_chunk<3, 8>(sj, wave_u, lane);
+      rtxn::convert_units16<NB, CT, 2 * NB - 1, 0, 2 * CT>(acc2[1], in);     // the last hidden layer's pending row tile
+      rtxn::floatx4 z4[CT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) z4[ct][e] = 0.0f;
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          // ROT: column tile ct multiplies by rotation ct of the output layer; otherwise both by the layer as it is
+          const half8 af = *reinterpret_cast<const half8*>(w + (((ROT ? ct : 0) * KS + kk) * 64 + lane) * 16);
+          z4[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, in[kk][ct], z4[ct], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (!ROT) {
+        // output rows 4g .. 4g+3 of sample (ct, c) are this lane's four accumulator registers
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          bool valid;
+          const long samp = sample_of(tile, ct, valid);
+          if (valid) {
+            half4v o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float z = z4[ct][e];
+              o[e] = (_Float16)(a.out_act == RTXN_ACT_SIGMOID ? 1.0f / (1.0f + __expf(-z)) : z);
+            }
+            *reinterpret_cast<half4v*>(a.out_half + samp * 16 + 4 * g) = o;
+          }
+        }
+      } else {
+        // lane (c, g < 2): sample 16 g + c of the wave's 32 -- lanes 0..31 in sample order
+        const rtxn::floatx4 z = g == 0 ? z4[0] : z4[1];
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        bool valid;
+        long samp;
+        if (IN_MODE == 1) {
+          const long seg = (long)tile * 8 + wave_u;
+          valid = seg < total_seg && lane_e < 32;
+          samp = seg * 32 + lane_e;
+        } else {
+          samp = (long)tile * 256 + wave_u * 32 + lane_e;
+          valid = samp < a.n && lane_e < 32;
+        }
+        if (valid) {
+          half4v o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (_Float16)(a.out_act == RTXN_ACT_SIGMOID ? 1.0f / (1.0f + __expf(-z[e])) : z[e]);
+          if (OUT_MODE == 3) *reinterpret_cast<half4v*>(a.out_half + samp * 4) = o;
+          else a.radiance[samp] = make_float4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
+        }
+      }
+    };
+    using std::integral_constant;
+    layer(integral_constant<int, KS0>{}, integral_constant<bool, false>{}, bf, bg);   // layer 0: K = 32*KS0
+    int l = 1;
+    for (; l + 1 < a.n_hidden; l += 2) {
+      layer(integral_constant<int, KS>{}, integral_constant<bool, true>{}, bg, bf);
+      layer(integral_constant<int, KS>{}, integral_constant<bool, true>{}, bf, bg);
+    }
+    if (l < a.n_hidden) {
+      layer(integral_constant<int, KS>{}, integral_constant<bool, true>{}, bg, bf);
+      finish(bf);
+    } else {
+      finish(bg);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -1257,7 +1469,7 @@ struct Variant {
   int threads;        // block size
   int blocks_per_cu;  // persistent grid = CUs x this
   int tile;           // samples per block per iteration (segments: tile / 32)
-  // the same model on v_mfma_f32_16x16x32_f16 (mlp_fwd16_kernel; none for the 256-wide variant): [IN_MODE][OUT_MODE], no OUT_MODE 2
+  // the same model on v_mfma_f32_16x16x32_f16 (mlp_fwd16_kernel / mlp_fwd256x16_kernel): [IN_MODE][OUT_MODE], no OUT_MODE 2
   fwd_fn fn16[2][4];
   int k0_16;          // first-layer K as staged for that kernel
   size_t lds16;
@@ -1323,8 +1535,13 @@ Variant make_variant256() {
   v.blocks_per_cu = 1;
   v.tile = 256;
   memset(v.fn16, 0, sizeof(v.fn16));
-  v.k0_16 = 0;
-  v.lds16 = 0;
+  v.fn16[0][0] = mlp_fwd256x16_kernel<PD, PF, DD, DF, 0, 0>;
+  v.fn16[0][1] = mlp_fwd256x16_kernel<PD, PF, DD, DF, 0, 1>;
+  v.fn16[1][0] = mlp_fwd256x16_kernel<PD, PF, DD, DF, 1, 0>;
+  v.fn16[1][1] = mlp_fwd256x16_kernel<PD, PF, DD, DF, 1, 1>;
+  v.fn16[1][3] = mlp_fwd256x16_kernel<PD, PF, DD, DF, 1, 3>;
+  v.k0_16 = EncSpec16<PD, PF, DD, DF>::k0;
+  v.lds16 = 3 * (size_t)kSlot256;
   return v;
 }
 

@@ -393,6 +393,71 @@ __device__ __forceinline__ void pipe_layer16(const uint8_t* lds_buf, const Stage
   PipeStep16<RT, KS, NB, CT, PEND, 0>::run(addr, bf, nbf, ring, acc, sj, wave_u, lane);
 }
 
+// The same 16x16x32 pipeline over one CHUNK of a streamed layer (the 256-wide kernel: a layer is 128 KiB of fragments and goes
+// through LDS in four 32-KiB chunks of four 16-row tiles): NR row tiles starting at the layer's row tile RT0 (even), KS
+// 32-wide k-steps, 8 waves.  acc[1] arrives holding the row tile before RT0 -- this layer's tile RT0-1 (-> out) or, for a
+// layer's first chunk, the previous layer's last tile 2*NB-1 (-> in[NB-1], dwords 2 and 3, first read at k-step NB-1) -- if
+// PEND; the chunk's own last tile (odd) is left pending in acc[1] in turn.
+template <int KS, int NB, int CT, int NR, int RT0, bool PEND, int I>
+struct PipeStep16c {
+  static constexpr int D = RTXN_PIPE16, N = NR * KS, WAVES = 8;
+  // A finished tile's units run in k-steps 1 .. KS-1 of the NEXT tile, never in its k-step 0: with two column tiles a k-step
+  // is only two 8-pass MFMAs, and a unit hoisted above them by the compiler (asm volatile orders it against other asm only)
+  // would read an accumulator one MFMA after its last write -- partial sums, timing-dependent.  One k-step later the
+  // writer is at least three MFMAs behind whatever the scheduler does inside the step.
+  static constexpr int SPAN = KS - 1;
+  static constexpr int U = (2 * CT + SPAN - 1) / SPAN;
+  static constexpr int WIN = KS - 1 > 1 ? KS - 1 : 1;
+  static constexpr int UP = (2 * CT + WIN - 1) / WIN;
+  static constexpr int CHUNKS = 4;                                  // 32 KiB / (8 waves x 1 KiB)
+  __device__ static __forceinline__ void run(unsigned addr, half8 (&in)[NB][CT], half8 (&out)[NB][CT], half8 (&ring)[D],
+                                             floatx4 (&acc)[2][CT], const StageJob& sj, int wave_u, int lane) {
+    constexpr int r = I / KS, kk = I % KS, cur = r & 1;
+    constexpr int outstanding = (N - 1 - I) < (D - 1) ? (N - 1 - I) : (D - 1);
+    lds_wait<outstanding>();
+    const half8 a = ring[I % D];
+    if (kk == 0) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[cur][ct][e] = 0.0f;
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) acc[cur][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, in[kk][ct], acc[cur][ct], 0, 0, 0);
+    if constexpr (r > 0) {
+      if constexpr (kk >= 1) convert_slice16<NB, CT, RT0 + r - 1, U, kk - 1>(acc[cur ^ 1], out);
+    } else if constexpr (PEND && kk < WIN) {
+      if constexpr (RT0 > 0) convert_slice16<NB, CT, RT0 - 1, UP, kk>(acc[1], out);
+      else convert_slice16<NB, CT, 2 * NB - 1, UP, kk>(acc[1], in);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (I + D < N) lds_read_frag<(I + D) * 1024>(ring[I % D], addr);
+    if constexpr (I < CHUNKS) {
+      stage_chunk<I, WAVES>(sj, wave_u, lane);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (I + 1 < N) PipeStep16c<KS, NB, CT, NR, RT0, PEND, I + 1>::run(addr, in, out, ring, acc, sj, wave_u, lane);
+  }
+};
+
+template <int KS, int NB, int CT, int NR, int RT0, bool PEND>
+__device__ __forceinline__ void pipe_chunk16(const uint8_t* lds_buf, const StageJob& sj, half8 (&in)[NB][CT], half8 (&out)[NB][CT],
+                                             floatx4 (&acc)[2][CT], int wave_u, int lane) {
+  constexpr int D = RTXN_PIPE16, N = NR * KS;
+  static_assert(RT0 % 2 == 0 && NR % 2 == 0, "chunks start on an even row tile and leave an odd one pending");
+  static_assert(CT >= 2, "a unit must never read the accumulator of the MFMA issued just before it");
+  static_assert(!PEND || RT0 > 0 || KS == NB, "a tile pending across a layer boundary lands in in[NB-1]");
+  static_assert(!PEND || KS >= 2, "the pending tile is converted during k-steps < KS-1");
+  static_assert(N * 1024 <= 65535 + 1024, "fragment offsets must fit the 16-bit ds offset");
+  half8 ring[D];
+  const unsigned addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) uint8_t*)lds_buf + lane * 16;
+  lds_read_frag<0>(ring[0], addr);
+  if constexpr (D > 1 && N > 1) lds_read_frag<1024>(ring[1 % D], addr);
+  if constexpr (D > 2 && N > 2) lds_read_frag<2048>(ring[2 % D], addr);
+  if constexpr (D > 3 && N > 3) lds_read_frag<3072>(ring[3 % D], addr);
+  PipeStep16c<KS, NB, CT, NR, RT0, PEND, 0>::run(addr, in, out, ring, acc, sj, wave_u, lane);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Compiler-scheduled layers (training kernels)
 // One layer: out rows [32*rt, 32*rt+32) for rt < RT, K = 16*KS, for the wave's two column

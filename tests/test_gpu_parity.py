@@ -313,7 +313,7 @@ def test_volrender_nerf_mode(gpu, oracle):
 @pytest.fixture(params=["16", "32"])
 def mfma_shape(request, monkeypatch):
     """Both fused inference kernels: mlp_fwd16_kernel (v_mfma_f32_16x16x32_f16, the default) and mlp_fwd_kernel
-    (32x32x16); rtxn_mlp_create reads the switch.  The 256-wide model has one kernel and ignores it."""
+    (32x32x16); rtxn_mlp_create reads the switch.  All three widths have both."""
     monkeypatch.setenv("RTXN_MFMA_SHAPE", request.param)
     return request.param
 
