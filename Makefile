@@ -8,9 +8,13 @@ HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -Iincl
 
 all: rtx_nerf_amd/librtxn.so oracle examples/render_host
 
+# train.hip: -amdgpu-mfma-vgpr-form.  Its one kernel above 256 registers (mlp_bwd_fused64_kernel, one wave per SIMD) keeps the
+# weight-gradient accumulators in AGPRs by hand (asm "+a"); left to its heuristic, hipcc put the destination of EVERY MFMA of
+# that kernel in AGPRs and copied each chain accumulator back for the fp16 conversion (816 v_accvgpr_read per tile).
+build/train.o: EXTRA := -mllvm -amdgpu-mfma-vgpr-form
 build/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/mlp_internal.h include/rtxn.h
 	@mkdir -p build
-	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) $(EXTRA) -c $< -o $@
 
 build/loader.o: $(CSRC)/loader.cpp $(CSRC)/common.h include/rtxn.h
 	@mkdir -p build

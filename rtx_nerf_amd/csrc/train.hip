@@ -703,8 +703,13 @@ __device__ __forceinline__ half8 tr_operand(const uint8_t* image, unsigned lane_
   return __builtin_shufflevector(l4, h4, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+// L hidden layers and KS0 = encoded width / 16 are template parameters: with them in registers the body was full of
+// `if (l < L)` exec-mask branches, every accumulator was zeroed by 16 v_mov (now the first MFMA takes C = 0) and scalar
+// registers spilled into VGPR lanes.
+template <int L, int KS0>
 __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_fused64_kernel(FusedArgs a) {
   constexpr int W = 64, RT = 2, KS = 4;
+  static_assert(L >= 1 && L <= kFusedMaxL && KS0 >= 1 && KS0 <= KS, "model outside the fused kernel's range");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -713,7 +718,6 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_fused64_kernel(FusedArgs 
     a.n_tiles = (int)(padded_dev(a.S) / kTile);
   }
   if ((int)blockIdx.x >= a.n_tiles) return;
-  const int L = a.L, KS0 = a.KS0;
   const int rt_e = (a.E + 31) / 32;
   const int fwd_bytes = (KS0 * RT + (L - 1) * KS * RT) * 1024;
   const int t_bytes = (RT + (L - 1) * RT * KS + rt_e * KS) * 1024;
@@ -752,7 +756,9 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_fused64_kernel(FusedArgs 
       for (int ks = 0; ks < 4; ++ks) {
         const half8 af = tr_operand(img + (v * 2) * kImgBytes, lane_tr, a_tile, ks);
         const half8 bf = tr_operand(img + (v * 2 + 1) * kImgBytes, lane_tr, b_tile, ks);
-        q = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, q, 0, 0, 0);
+        // the gradient quadrants live in AGPRs for the whole kernel (only these MFMAs touch them): said explicitly, so that the
+        // 256 architectural VGPRs are left to the chain and the compiler has no accumulator to shuttle
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(q) : "v"(af), "v"(bf));
         if (ks == 3) __builtin_amdgcn_sched_barrier(0);   // one image's eight operand reads in flight at a time (all 32 hoisted: spills)
       }
   };
@@ -845,15 +851,28 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_fused64_kernel(FusedArgs 
     for (int j = 0; j < 8; ++j) zero8[j] = (_Float16)0.0f;
 
     // dZ_l (accumulator tile rt of W_{l+1}^T dZ_{l+1}) masked with relu'(act) and packed as the next chain fragment
+    // relu' on the PACKED halves: the activation is post-ReLU fp16 (bits 0 or a positive number), so min(bits, 1) is 0 / 1 per
+    // half and an integer multiply of the gradient's bits by it keeps or clears the half -- two packed ops per two values
+    // (v_pk_min_u16, v_pk_mul_lo_u16) where convert-compare-select on fp32 took seven.
+    // (spelled in asm: written as vector min / multiply, hipcc turns it back into per-half compares, selects and v_perm.)
+    const int ones16 = 0x00010001;
     auto mask_pack = [&](const floatx16 (&d)[2], int rt, const half8 (&actl)[KS][2], half8 (&dst)[KS][2]) {
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
-        floatx16 m;
+      for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) m[e] = (float)actl[2 * rt + (e >> 3)][ct][e & 7] > 0.0f ? d[ct][e] : 0.0f;
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const rtxn::int4v g = __builtin_bit_cast(rtxn::int4v, pack8<false>(d[ct], s2));
+          const rtxn::int4v x = __builtin_bit_cast(rtxn::int4v, actl[2 * rt + s2][ct]);
+          rtxn::int4v r;
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) dst[2 * rt + s2][ct] = pack8<false>(m, s2);
-      }
+          for (int q = 0; q < 4; ++q) {
+            int keep, out;
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(keep) : "v"(x[q]), "s"(ones16));
+            asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(out) : "v"(g[q]), "v"(keep));
+            r[q] = out;
+          }
+          dst[2 * rt + s2][ct] = __builtin_bit_cast(half8, r);
+        }
     };
 
     // ---- output layer: weight gradient dW_L[16 x 64] = dZ_out act_{L-1}^T, then dZ_{L-1} ----
@@ -1488,8 +1507,15 @@ static int train_backward_recompute_impl(const rtxn_mlp* m, const void* encT, co
   RTXN_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
   if (n_cu <= 0) n_cu = 256;
   const int grid = a.n_tiles < n_cu ? a.n_tiles : n_cu;   // persistent: one block per CU (LDS- and register-bound)
-  RTXN_HIP(set_lds_once(reinterpret_cast<const void*>(mlp_bwd_fused64_kernel), (int)lds));
-  hipLaunchKernelGGL(mlp_bwd_fused64_kernel, dim3((unsigned)grid), dim3(kThreads), lds, rtxn::as_stream(stream), a);
+  typedef void (*fused_fn)(FusedArgs);
+  static const fused_fn table[kFusedMaxL][4] = {
+      {mlp_bwd_fused64_kernel<1, 1>, mlp_bwd_fused64_kernel<1, 2>, mlp_bwd_fused64_kernel<1, 3>, mlp_bwd_fused64_kernel<1, 4>},
+      {mlp_bwd_fused64_kernel<2, 1>, mlp_bwd_fused64_kernel<2, 2>, mlp_bwd_fused64_kernel<2, 3>, mlp_bwd_fused64_kernel<2, 4>},
+      {mlp_bwd_fused64_kernel<3, 1>, mlp_bwd_fused64_kernel<3, 2>, mlp_bwd_fused64_kernel<3, 3>, mlp_bwd_fused64_kernel<3, 4>},
+      {mlp_bwd_fused64_kernel<4, 1>, mlp_bwd_fused64_kernel<4, 2>, mlp_bwd_fused64_kernel<4, 3>, mlp_bwd_fused64_kernel<4, 4>}};
+  const fused_fn fn = table[L - 1][a.KS0 - 1];
+  RTXN_HIP(set_lds_once(reinterpret_cast<const void*>(fn), (int)lds));
+  hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(kThreads), lds, rtxn::as_stream(stream), a);
   RTXN_LAUNCH_CHECK("mlp_bwd_fused64_kernel");
   return RTXN_OK;
 }
