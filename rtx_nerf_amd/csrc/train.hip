@@ -228,6 +228,45 @@ __global__ __launch_bounds__(kThreads) void hashgrid_encode_kernel(HgLevels lv, 
 // gradient table -- half the atomics -- which is also what tiny-cuda-nn does (its grid gradient is __half2).  Entries of the
 // hashed levels receive ~10 contributions each, so the fp16 accumulation costs ~1e-3 relative; the densely stored coarse
 // levels, which receive thousands per entry, stay fp32.
+// Wave-level run sums without the LDS crossbar.  A run = consecutive lanes whose samples sit in the same grid cell; all of a
+// sample's 8 x F corner contributions share the run structure, so the per-step "may I add my neighbour" decisions are
+// worked out once as 0 / 1 multipliers and every value then takes seven DPP multiply-adds: a segmented Hillis-Steele scan
+// inside each row of 16 lanes (row_shr 1, 2, 4, 8; lanes before the row read 0) and a carry handed from row to row through
+// lane 15 (row_bcast:15 into rows 1, 2, 3 in turn).  The run's LAST lane ends up with the run's sum.  The __shfl_up form
+// this replaces cost 12 dependent ds_bpermute per corner: with the atomics switched off the kernel took the same time, i.e.
+// it was bound by exactly those shuffles (tools/probe: 222.7 vs 219.7 us on the configs[2] batch).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, true);
+}
+struct RunSteps { float m1, m2, m4, m8, c1, c2, c3; };
+__device__ __forceinline__ RunSteps run_steps(int lane, int run_start) {
+  const int row = lane >> 4;
+  RunSteps k;
+  k.m1 = lane - 1 >= run_start ? 1.0f : 0.0f;
+  k.m2 = lane - 2 >= run_start ? 1.0f : 0.0f;
+  k.m4 = lane - 4 >= run_start ? 1.0f : 0.0f;
+  k.m8 = lane - 8 >= run_start ? 1.0f : 0.0f;
+  k.c1 = row == 1 && run_start < 16 ? 1.0f : 0.0f;     // the run began in an earlier row: take that row's carry
+  k.c2 = row == 2 && run_start < 32 ? 1.0f : 0.0f;
+  k.c3 = row == 3 && run_start < 48 ? 1.0f : 0.0f;
+  return k;
+}
+__device__ __forceinline__ float run_sum(float v, const RunSteps& k) {
+  v = fmaf(dpp_f<0x111, 0xf>(v), k.m1, v);
+  v = fmaf(dpp_f<0x112, 0xf>(v), k.m2, v);
+  v = fmaf(dpp_f<0x114, 0xf>(v), k.m4, v);
+  v = fmaf(dpp_f<0x118, 0xf>(v), k.m8, v);
+  v = fmaf(dpp_f<0x142, 0x2>(v), k.c1, v);
+  v = fmaf(dpp_f<0x142, 0x4>(v), k.c2, v);
+  v = fmaf(dpp_f<0x142, 0x8>(v), k.c3, v);
+  return v;
+}
+
 template <bool PK>
 __global__ __launch_bounds__(kThreads) void hashgrid_backward_kernel(HgLevels lv, int level0, SampleSrc src,
                                                                      const _Float16* __restrict__ dencT, long S, long Sp,
@@ -242,6 +281,15 @@ __global__ __launch_bounds__(kThreads) void hashgrid_backward_kernel(HgLevels lv
   const int lane = threadIdx.x & 63;
   const long s = (long)blockIdx.x * kThreads + threadIdx.x;     // every lane stays: the aggregation shuffles across the wave
   const bool ok = s < S;
+  float d[8];
+  bool any_grad = false;
+  for (int f = 0; f < F && f < 8; ++f) {
+    d[f] = ok ? (float)dencT[(long)(l * F + f) * Sp + s] : 0.0f;
+    any_grad |= d[f] != 0.0f;
+  }
+  // A wave whose 64 samples all have a zero gradient at this level adds nothing: most of a NeRF batch (samples behind the
+  // surface: transmittance 0) -- on the configs[2] batch 71 % of the waves leave here.
+  if (__ballot(any_grad) == 0) return;
   float fr[3], x3[3];
   unsigned g[3];
   sample_pos(src, s, ok, x3);
@@ -252,23 +300,26 @@ __global__ __launch_bounds__(kThreads) void hashgrid_backward_kernel(HgLevels lv
     g[a] = (unsigned)(int)fl;
     fr[a] = p - fl;
   }
-  float d[8];
-  for (int f = 0; f < F && f < 8; ++f) d[f] = ok ? (float)dencT[(long)(l * F + f) * Sp + s] : 0.0f;
   int run_start = lane;
   bool run_last = true;
   const unsigned k0 = ok ? (g[0] | (g[1] << 16)) : 0xffffffffu, k1 = ok ? g[2] : (unsigned)lane;
-  const unsigned p0 = __shfl_up(k0, 1, 64), p1 = __shfl_up(k1, 1, 64);
+  const unsigned p0 = (unsigned)dpp_i<0x138, 0xf>((int)k0), p1 = (unsigned)dpp_i<0x138, 0xf>((int)k1);   // wave_shr:1: lane - 1's keys
   const bool head = lane == 0 || p0 != k0 || p1 != k1;
   const bool aggregate = __ballot(head) != ~0ull;   // wave-uniform: finest levels have no runs and skip the scans
+  RunSteps steps = {};
   if (aggregate) {
-    run_start = head ? lane : 0;
-#pragma unroll
-    for (int dlt = 1; dlt < 64; dlt <<= 1) {
-      const int t = __shfl_up(run_start, dlt, 64);
-      if (lane >= dlt && t > run_start) run_start = t;
-    }
-    const int next_head = __shfl_down((int)head, 1, 64);
+    // run_start = the nearest head at or below the lane: an inclusive max scan of (head ? lane : 0)
+    int rs = head ? lane : 0;
+    rs = max(rs, dpp_i<0x111, 0xf>(rs));
+    rs = max(rs, dpp_i<0x112, 0xf>(rs));
+    rs = max(rs, dpp_i<0x114, 0xf>(rs));
+    rs = max(rs, dpp_i<0x118, 0xf>(rs));
+    rs = max(rs, dpp_i<0x142, 0xa>(rs));
+    rs = max(rs, dpp_i<0x143, 0xc>(rs));
+    run_start = rs;
+    const int next_head = dpp_i<0x130, 0xf>((int)head);      // wave_shl:1: lane + 1's flag
     run_last = lane == 63 || next_head != 0;
+    steps = run_steps(lane, run_start);
   }
 #pragma unroll
   for (int corner = 0; corner < 8; ++corner) {
@@ -284,11 +335,8 @@ __global__ __launch_bounds__(kThreads) void hashgrid_backward_kernel(HgLevels lv
     if (PK) {
       float v0 = w * d[0], v1 = w * d[1];
       if (aggregate) {
-#pragma unroll
-        for (int dlt = 1; dlt < 64; dlt <<= 1) {
-          const float t0 = __shfl_up(v0, dlt, 64), t1 = __shfl_up(v1, dlt, 64);
-          if (lane - dlt >= run_start) { v0 += t0; v1 += t1; }
-        }
+        v0 = run_sum(v0, steps);
+        v1 = run_sum(v1, steps);
       }
       if (ok && run_last && (v0 != 0.0f || v1 != 0.0f)) {
         const half2v hv = {(_Float16)v0, (_Float16)v1};
@@ -297,13 +345,7 @@ __global__ __launch_bounds__(kThreads) void hashgrid_backward_kernel(HgLevels lv
     } else {
       for (int f = 0; f < F && f < 8; ++f) {
         float v = w * d[f];
-        if (aggregate) {
-#pragma unroll
-          for (int dlt = 1; dlt < 64; dlt <<= 1) {
-            const float t = __shfl_up(v, dlt, 64);
-            if (lane - dlt >= run_start) v += t;
-          }
-        }
+        if (aggregate) v = run_sum(v, steps);
         if (ok && run_last && v != 0.0f) atomicAdd(&gdst[(size_t)idx * F + f], v);
       }
     }
@@ -773,6 +815,42 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_fused64_kernel(FusedArgs 
       ok_s[ct] = sidx < a.S;
       lane_off[ct] = (unsigned)((sidx + 4L * h * a.Sp) * 2);
     }
+    // ---- output layer: dZ_out = dout (*) act'(out) -- first, because a tile whose loss gradients are ALL zero contributes
+    // exactly nothing to any gradient and is skipped whole (no recompute, no chain, no weight-gradient pass): in NeRF
+    // training most samples lie behind the surface, where the transmittance and with it dL/d(radiance) is 0 (configs[2]
+    // batch: 12 % of the samples carry a gradient).  Block-uniform decision; the tile's d(encoding) is written as zeros.
+    half8 bo[2];
+    bool any_grad = false;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      half8 v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.0f;
+      const long sidx = tile0 + ct * 32 + col;
+      if (ok_s[ct] && h == 0) {
+        const half4v g = *reinterpret_cast<const half4v*>(a.dout + sidx * 4);
+        const half4v y = *reinterpret_cast<const half4v*>(a.out_half + sidx * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float gg = (float)g[j];
+          if (a.out_act == RTXN_ACT_SIGMOID) { const float yy = (float)y[j]; gg = gg * yy * (1.0f - yy); }
+          v[j] = (_Float16)gg;
+          any_grad |= v[j] != (_Float16)0.0f;
+        }
+      }
+      bo[ct] = v;
+    }
+    if (!__syncthreads_or(any_grad)) {
+      if (a.dencT) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+          for (int f = 0; f < a.E; f += 8)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (f + j < a.E) *row_elem(a.dencT, f + j, a.Sp, lane_off[ct]) = (_Float16)0.0f;   // rows f + j + 4h: lane halves interleave
+      }
+      continue;
+    }
     // ---- encoded input as layer-0 B fragments (X_0); read again for layer 0's weight gradient (a cache hit) rather than
     // held in 32 VGPRs through the whole backward chain ----
     auto load_x0 = [&](half8 (&x)[KS][2]) {
@@ -826,26 +904,6 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_fused64_kernel(FusedArgs 
         layer_mma<RT, KS, KS, 2>(wF + foff, act[l - 1], act[l], lane);
         foff += KS * RT * 1024;
       }
-    // ---- output layer: dZ_out = dout (*) act'(out) ----
-    half8 bo[2];
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      half8 v;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.0f;
-      const long sidx = tile0 + ct * 32 + col;
-      if (ok_s[ct] && h == 0) {
-        const half4v g = *reinterpret_cast<const half4v*>(a.dout + sidx * 4);
-        const half4v y = *reinterpret_cast<const half4v*>(a.out_half + sidx * 16);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float gg = (float)g[j];
-          if (a.out_act == RTXN_ACT_SIGMOID) { const float yy = (float)y[j]; gg = gg * yy * (1.0f - yy); }
-          v[j] = (_Float16)gg;
-        }
-      }
-      bo[ct] = v;
-    }
     half8 zero8;
 #pragma unroll
     for (int j = 0; j < 8; ++j) zero8[j] = (_Float16)0.0f;

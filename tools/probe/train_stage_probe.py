@@ -76,3 +76,11 @@ def both():
     api.volrender_l2_train(tr.radiance, tr.t_vals, tr.num_stored, tr.indices, B, K, tg, 128.0, tr.pixels[:B], tr.loss_grads[:B], tr.loss, tr.dout)
     torch.cuda.current_stream().wait_stream(s2)
 timeit(both, name="compositor || traversal count pass + scan (2 streams)")
+
+# how sparse is the gradient that reaches the hash scatter?
+de = tr.dencT[:32, :S]
+nz = (de != 0).any(dim=0)
+w = nz.view(-1, 64).any(dim=1) if S % 64 == 0 else nz[: S // 64 * 64].view(-1, 64).any(dim=1)
+print(f"samples with any non-zero grid gradient: {100.0 * nz.float().mean().item():.1f} %   waves (64 samples) with any: {100.0 * w.float().mean().item():.1f} %")
+do = tr.dout[:S].float()
+print(f"samples with non-zero dout: {100.0 * (do != 0).any(dim=1).float().mean().item():.1f} %")
