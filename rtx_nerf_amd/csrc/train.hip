@@ -369,6 +369,7 @@ struct TrainArgs {
   _Float16* dz;             // [L][W][Sp]
   _Float16* dzL;            // [16][Sp]
   _Float16* dencT;          // [E][Sp] or NULL
+  uint8_t* live_tiles;      // [Sp / 256]: backward: 1 where the tile carries a non-zero loss gradient (weight-gradient kernels skip the others)
 };
 
 // Element (feature row f0 + 4h, sample s) of a feature-major tensor X[feature][Sp]: the address is split into a wave-uniform
@@ -571,9 +572,32 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_bwd_kernel(TrainArgs a) {
       }
     }
     bo[ct] = v;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) *row_elem(a.dzL, perm_feature(0, 0, j), a.Sp, lane_off[ct]) = v[j];
   }
+  // A tile whose loss gradients are all zero (most of a NeRF batch: samples behind the surface) contributes nothing to any
+  // gradient: it is marked dead for the weight-gradient kernels, its d(encoding) is written as zeros, and the block leaves.
+  {
+    bool any_grad = false;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) any_grad |= bo[ct][j] != (_Float16)0.0f;
+    const bool live = __syncthreads_or(any_grad);
+    if (a.live_tiles && threadIdx.x == 0) a.live_tiles[blockIdx.x] = live ? 1 : 0;
+    if (!live && a.live_tiles) {
+      if (a.dencT) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+          for (int f = 0; f < a.E; f += 8)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *row_elem(a.dencT, f + j, a.Sp, lane_off[ct]) = (_Float16)0.0f;
+      }
+      return;
+    }
+  }
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *row_elem(a.dzL, perm_feature(0, 0, j), a.Sp, lane_off[ct]) = bo[ct][j];
   // One accumulator pair at a time: row tile rt of dA_{l} = W^T dZ is masked with relu'(act_l), rounded to fp16 and packed
   // straight into the B fragments of the next (earlier) layer's MFMAs -- the backward chain stays in registers exactly as the
   // forward does, and no full-layer fp32 dA is ever held (the first version kept one: 128 VGPRs at W = 128, 378 spills).
@@ -1072,6 +1096,7 @@ struct WgradArgs {
   long Sp, chunk;
   int lds_path;   // layers with >= 2 tiles are left to wgrad_lds_kernel
   DevCount dc;    // contraction length from the device (see DevCount); Sp stays the row stride
+  const uint8_t* live_tiles;   // [Sp / 256] from mlp_bwd_kernel, or NULL: 256-sample tiles with dZ == 0 are not read
 };
 
 __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
@@ -1102,6 +1127,10 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
   const _Float16* pb1 = X + (long)(col1 < N ? col1 : 0) * Sp + 8 * h;
   constexpr int U = 4;   // Sp and the chunk are multiples of 256: whole groups of U k-steps
   for (long s = s_begin; s < s_end; s += 16 * U) {
+    if (a.live_tiles && (s & (kTile - 1)) == 0 && !a.live_tiles[s / kTile]) {   // wave-uniform: a dead tile (dZ == 0) adds nothing
+      s += kTile - 16 * U;
+      continue;
+    }
     half8 a0[U], a1[U], b0[U], b1[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -1174,11 +1203,20 @@ __global__ __launch_bounds__(kThreads) void wgrad_lds_kernel(WgradArgs a) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-  stage(0, s_begin);
+  // stages of dead tiles (dZ == 0: mlp_bwd_kernel's live_tiles) are stepped over: block-uniform
+  auto live_from = [&](long s) -> long {
+    if (a.live_tiles)
+      while (s < s_end && (s & (kTile - 1)) == 0 && !a.live_tiles[s / kTile]) s += kTile;
+    return s;
+  };
+  long s = live_from(s_begin);
+  if (s >= s_end) return;
+  stage(0, s);
   int buf = 0;
-  for (long s = s_begin; s < s_end; s += 16 * kWgK) {
+  while (s < s_end) {
     rtxn::staged_barrier();                              // this stage landed; everyone is done with the other buffer
-    if (s + 16 * kWgK < s_end) stage(buf ^ 1, s + 16 * kWgK);
+    const long sn = live_from(s + 16 * kWgK);
+    if (sn < s_end) stage(buf ^ 1, sn);
     const uint8_t* st = wsm + buf * kWgStage + lane * 16;
 #pragma unroll
     for (int kk = 0; kk < kWgK; ++kk) {
@@ -1192,6 +1230,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_lds_kernel(WgradArgs a) {
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
     }
     buf ^= 1;
+    s = sn;
   }
   float* __restrict__ dW = L.dW;
 #pragma unroll
@@ -1318,7 +1357,8 @@ extern "C" long rtxn_padded_samples(long n_samples) { return n_samples < 0 ? -1 
 extern "C" size_t rtxn_mlp_train_workspace_bytes(const rtxn_mlp* m, long n_samples) {
   if (!m || n_samples < 0) return 0;
   const long Sp = padded(n_samples), W = m->cfg.n_neurons, L = m->cfg.n_hidden_layers;
-  return (size_t)((2 * L * W + 16 + 8 * L) * Sp) * sizeof(_Float16);   // acts | dz | dzL | sign masks (16 B per sample and layer)
+  // acts | dz | dzL | sign masks (16 B per sample and layer) | one live flag per 256-sample tile
+  return (size_t)((2 * L * W + 16 + 8 * L) * Sp) * sizeof(_Float16) + (size_t)((Sp / kTile + 15) / 16 * 16);
 }
 
 // In every *_impl below: dc.total_segments == NULL: n_samples is the batch's; otherwise n_samples is the CAPACITY (grids, row
@@ -1456,6 +1496,7 @@ static int train_backward_impl(const rtxn_mlp* m, const void* encT, const void* 
   a.dz = ws + (long)L * W * Sp;
   a.dzL = ws + 2L * L * W * Sp;
   a.masks = reinterpret_cast<unsigned long long*>(ws + (2L * L * W + 16) * Sp);
+  a.live_tiles = reinterpret_cast<uint8_t*>(ws + (2L * L * W + 16 + 8L * L) * Sp);
   a.out_half = const_cast<_Float16*>(static_cast<const _Float16*>(output_half));
   a.dout = static_cast<const _Float16*>(dout_half4);
   a.dencT = static_cast<_Float16*>(dencT);
@@ -1475,6 +1516,7 @@ static int train_backward_impl(const rtxn_mlp* m, const void* encT, const void* 
   WgradArgs wa;
   wa.Sp = Sp;
   wa.dc = dc;
+  wa.live_tiles = a.live_tiles;
   wa.chunk = 1024;
   const unsigned kblocks = (unsigned)((Sp + 4 * wa.chunk - 1) / (4 * wa.chunk));
   long poff = 0;
