@@ -160,6 +160,15 @@ __device__ __forceinline__ unsigned hg_index(unsigned x, unsigned y, unsigned z,
   return ((x * 1u) ^ (y * 2654435761u) ^ (z * 805459861u)) % size;
 }
 
+// hg_index without the integer division: a hashed level's size is the table cap, a power of two (mask); a densely stored
+// level's index is below twice its size (x, y, z <= res), so one conditional subtract is the modulo.  `hashed` is uniform
+// per launch row (one level), so the choice is a scalar branch.
+__device__ __forceinline__ unsigned hg_index_nodiv(unsigned x, unsigned y, unsigned z, unsigned res, unsigned size, bool hashed) {
+  if (hashed) return ((x * 1u) ^ (y * 2654435761u) ^ (z * 805459861u)) & (size - 1u);
+  const unsigned i = x + y * res + z * res * res;
+  return i >= size ? i - size : i;
+}
+
 // grid.y = level (0..L-1: hash levels; L: direction frequencies + padding)
 __global__ __launch_bounds__(kThreads) void hashgrid_encode_kernel(HgLevels lv, int n_dir_freqs, const _Float16* __restrict__ table,
                                                                    SampleSrc src, _Float16* __restrict__ encT, float* __restrict__ t_vals,
@@ -210,6 +219,79 @@ __global__ __launch_bounds__(kThreads) void hashgrid_encode_kernel(HgLevels lv, 
     }
     for (; j < E; ++j) encT[(long)j * Sp + s] = ok ? (_Float16)1.0f : (_Float16)0.0f;
   }
+}
+
+// F == 2 (tcnn's default and BASELINE configs[2]): ONE thread per sample walks all levels.  The per-(sample, level) launch
+// above spent most of its time in vector ALU work that does not depend on the level -- forming the sample from its segment,
+// 64-bit addresses, an integer division per corner index (rocprofv3: 259 VALU instructions per wave and level) -- so here
+// the position is formed once, level constants are scalar, indices need no division (hg_index_nodiv), the loads take a
+// 32-bit offset from a scalar level base, and (x y) is shared by the two z corners (same products, same rounding).  The
+// gathers: both features of a corner are one 4-byte entry, and the two corners that differ in x share an aligned 8-byte pair
+// on the hashed levels whenever x is even -- the hash is x ^ (y p1) ^ (z p2) modulo a power of two, so x + 1 = x ^ 1 flips
+// only the lowest index bit -- and then one 8-byte load serves both; odd x (and the densely stored levels) take a second
+// 4-byte load.  Bit-identical to the general kernel (tests/test_gpu_train.py).
+__global__ __launch_bounds__(kThreads) void hashgrid_encode_f2_kernel(HgLevels lv, int n_dir_freqs, const _Float16* __restrict__ table,
+                                                                      SampleSrc src, _Float16* __restrict__ encT, float* __restrict__ t_vals,
+                                                                      float t_scale, long S, long Sp, int E, DevCount dc) {
+  const long s = (long)blockIdx.x * kThreads + threadIdx.x;
+  S = live_samples(dc, S);
+  if (s >= padded_dev(S)) return;
+  const bool ok = s < S;
+  float x3[3], x01[3];
+  sample_pos(src, s, ok, x3);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) x01[a] = fmaf(x3[a], 0.5f, 0.5f);
+  _Float16* out = encT + s;
+  for (int l = 0; l < lv.n_levels; ++l) {
+    const unsigned res = lv.res[l], size = lv.size[l];
+    const float scale = lv.scale[l];
+    const bool hashed = (unsigned long long)res * res * res > size;
+    const uint8_t* base = reinterpret_cast<const uint8_t*>(table) + (size_t)lv.offset[l] * 4;     // scalar
+    float fr[3];
+    unsigned g[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float p = fmaf(x01[a], scale, 0.5f), fl = floorf(p);
+      g[a] = (unsigned)(int)fl;
+      fr[a] = p - fl;
+    }
+    const bool shared = hashed && (g[0] & 1u) == 0;
+    unsigned e[8];
+#pragma unroll
+    for (int yz = 0; yz < 4; ++yz) {
+      const unsigned py = g[1] + (unsigned)(yz & 1), pz = g[2] + (unsigned)(yz >> 1);
+      const unsigned i_lo = hg_index_nodiv(g[0], py, pz, res, size, hashed);
+      const uint2 pr = *reinterpret_cast<const uint2*>(base + ((i_lo & ~1u) << 2));
+      e[2 * yz] = (i_lo & 1u) ? pr.y : pr.x;
+      e[2 * yz + 1] = (i_lo & 1u) ? pr.x : pr.y;
+      if (!shared) e[2 * yz + 1] = *reinterpret_cast<const unsigned*>(base + (hg_index_nodiv(g[0] + 1u, py, pz, res, size, hashed) << 2));
+    }
+    float acc0 = 0.0f, acc1 = 0.0f;
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner) {        // weights ((x) y) z and corner order of the general kernel
+      float w = 1.0f;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) w *= ((corner >> a) & 1) ? fr[a] : 1.0f - fr[a];
+      const half2v v = __builtin_bit_cast(half2v, e[corner]);
+      acc0 = fmaf(w, (float)v[0], acc0);
+      acc1 = fmaf(w, (float)v[1], acc1);
+    }
+    // rounded to fp32 and THEN to fp16, as the oracle does: without the barrier hipcc folds the last multiply-add and the
+    // conversion into v_fma_mixlo_f16 -- one rounding, 2 of 96,000 values an fp16 ulp apart
+    asm volatile("" : "+v"(acc0), "+v"(acc1));
+    out[(long)(2 * l) * Sp] = ok ? (_Float16)acc0 : (_Float16)0.0f;
+    out[(long)(2 * l + 1) * Sp] = ok ? (_Float16)acc1 : (_Float16)0.0f;
+  }
+  int j = lv.n_levels * 2;
+  float v2[2];
+  sample_dir(src, s, ok, v2);
+  if (!src.in && t_vals && ok) t_vals[s] = sample_tval(src, s, t_scale);
+  for (int d = 0; d < 2; ++d) {
+    const float x = v2[d];
+    for (int f = 0; f < n_dir_freqs; ++f)
+      for (int ph = 0; ph < 2; ++ph, ++j) out[(long)j * Sp] = ok ? (_Float16)sin_turns(x, f, ph) : (_Float16)0.0f;
+  }
+  for (; j < E; ++j) out[(long)j * Sp] = ok ? (_Float16)1.0f : (_Float16)0.0f;
 }
 
 // Scatter-add of dL/d(encoding) into the table gradient: one atomic per (sample, corner) and feature (fp32), or per
@@ -276,6 +358,7 @@ __global__ __launch_bounds__(kThreads) void hashgrid_backward_kernel(HgLevels lv
   if ((long)blockIdx.x * kThreads >= S) return;                 // whole block past the live samples (block-uniform)
   const int l = level0 + blockIdx.y;
   const int F = lv.n_features;
+  const bool hashed_level = (unsigned long long)lv.res[l] * lv.res[l] * lv.res[l] > lv.size[l];
   float* gdst = dtable + (size_t)lv.offset[l] * F;
   half2v* gdst_h = reinterpret_cast<half2v*>(dtable_h + ((size_t)lv.offset[l] * F - (size_t)hashed_lo));   // PK: F == 2
   const int lane = threadIdx.x & 63;
@@ -331,7 +414,7 @@ __global__ __launch_bounds__(kThreads) void hashgrid_backward_kernel(HgLevels lv
       w *= hi ? fr[a] : 1.0f - fr[a];
       p[a] = g[a] + (unsigned)hi;
     }
-    const unsigned idx = hg_index(p[0], p[1], p[2], lv.res[l], lv.size[l]);
+    const unsigned idx = hg_index_nodiv(p[0], p[1], p[2], lv.res[l], lv.size[l], hashed_level);
     if (PK) {
       float v0 = w * d[0], v1 = w * d[1];
       if (aggregate) {
@@ -1709,9 +1792,14 @@ static int hashgrid_encode_impl(const rtxn_hashgrid* g, int n_dir_freqs, const v
                                 float* t_vals, float t_scale, long n_samples, DevCount dc, rtxn_stream_t stream) {
   const long Sp = padded(n_samples);
   const int E = rtxn_hashgrid_encoded_width(g, n_dir_freqs);
-  hashgrid_encode_kernel<<<dim3((unsigned)(Sp / kThreads), (unsigned)(g->cfg.n_levels + 1)), kThreads, 0, rtxn::as_stream(stream)>>>(
-      levels_of(g), n_dir_freqs, static_cast<const _Float16*>(table_fp16), src, static_cast<_Float16*>(encT), t_vals, t_scale,
-      n_samples, Sp, E, dc);
+  if (g->cfg.n_features == 2 && ((uintptr_t)table_fp16 & 7) == 0)
+    hashgrid_encode_f2_kernel<<<dim3((unsigned)(Sp / kThreads)), kThreads, 0, rtxn::as_stream(stream)>>>(
+        levels_of(g), n_dir_freqs, static_cast<const _Float16*>(table_fp16), src, static_cast<_Float16*>(encT), t_vals, t_scale,
+        n_samples, Sp, E, dc);
+  else
+    hashgrid_encode_kernel<<<dim3((unsigned)(Sp / kThreads), (unsigned)(g->cfg.n_levels + 1)), kThreads, 0, rtxn::as_stream(stream)>>>(
+        levels_of(g), n_dir_freqs, static_cast<const _Float16*>(table_fp16), src, static_cast<_Float16*>(encT), t_vals, t_scale,
+        n_samples, Sp, E, dc);
   RTXN_LAUNCH_CHECK("hashgrid_encode_kernel");
   return RTXN_OK;
 }
