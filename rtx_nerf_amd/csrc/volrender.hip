@@ -43,11 +43,12 @@ __device__ __forceinline__ float lane63(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-  return v;
-}
+// Sum over the wave, returned in every lane: the DPP inclusive scan above leaves the total in lane 63, read back as a scalar
+// (six VALU adds + v_readlane; the __shfl_xor butterfly was six dependent ds_swizzle / ds_bpermute round trips, three times
+// per ray in the compositors).
+__device__ __forceinline__ float wave_sum(float v) { return lane63(wave_incl_scan_f(v, 0)); }
+// lane - 1's value (lane 0: 0): DPP wave_shr:1
+__device__ __forceinline__ float lane_below(float v) { return dpp_term<0x138, 0xf>(v); }
 
 struct alignas(8) half4 {
   __half x, y, z, w;
@@ -85,21 +86,21 @@ __global__ __launch_bounds__(256) void volrender_fwd_kernel(const float4* __rest
     }
     float x, w;
     if (MODE == RTXN_VR_COMPAT) {
-      float tp = __shfl_up(t, 1, 64);
+      float tp = lane_below(t);
       if (lane == 0) tp = t_carry;
       const float delta = fabsf(t - tp);
       x = act ? delta * c.w : 0.0f;
       const float T = T_carry + wave_incl_scan_f(x, lane);
       w = act ? expf(-T) * (1.0f - expf(-x)) : 0.0f;
-      T_carry = __shfl(T, 63, 64);
+      T_carry = lane63(T);
       // last ACTIVE lane's t carries over; inactive lanes only occur in the final step
-      t_carry = __shfl(t, 63, 64);
+      t_carry = lane63(t);
     } else {
       x = act ? t * c.w : 0.0f;  // ray_hit = step length
       const float incl = wave_incl_scan_f(x, lane);
       const float T_excl = T_carry + incl - x;
       w = act ? expf(-T_excl) * (1.0f - expf(-x)) : 0.0f;
-      T_carry += __shfl(incl, 63, 64);
+      T_carry += lane63(incl);
     }
     ar = fmaf(w, c.x, ar);
     ag = fmaf(w, c.y, ag);
@@ -140,60 +141,81 @@ __global__ __launch_bounds__(256) void volrender_fwd_pair_kernel(const float4* _
   const int my = ray0 + lane < batch_size && lane < kRaysPerWave ? ray0 + lane : ray0;
   const int idx_l = indices[my], nh_l = num_hits[my];
   float out = 0.0f;                                   // lane 3 r + ch of the wave holds pixel channel ch of ray r
-  for (int r = 0; r < kRaysPerWave && ray0 + r < batch_size; ++r) {
-    const long base = (long)__shfl(idx_l, r, 64) * K;
-    const long n = (long)__shfl(nh_l, r, 64) * K;     // even
-    auto load = [&](long s0, Pair& p) {
-      const long i0 = s0 + 2 * lane;
-      p.c0 = p.c1 = make_float4(0.f, 0.f, 0.f, 0.f);
-      p.t0 = p.t1 = 0.0f;
-      if (i0 < n) {
-        if (COMPACT) {
-          const uint4 raw = *reinterpret_cast<const uint4*>(reinterpret_cast<const half4*>(radiance) + base + i0);   // two half4
-          const __half2 a = *reinterpret_cast<const __half2*>(&raw.x), b = *reinterpret_cast<const __half2*>(&raw.y);
-          const __half2 c = *reinterpret_cast<const __half2*>(&raw.z), d = *reinterpret_cast<const __half2*>(&raw.w);
-          p.c0 = make_float4(__low2float(a), __high2float(a), __low2float(b), __high2float(b));
-          p.c1 = make_float4(__low2float(c), __high2float(c), __low2float(d), __high2float(d));
-          p.t0 = (float)((int)(i0 % K) + 1) * rK;    // REGULAR t_vals (sampler.cu:52-66): (i + 1) / K of the index in the segment
-          p.t1 = (float)((int)((i0 + 1) % K) + 1) * rK;
-        } else {
-          p.c0 = radiance[base + i0];
-          p.c1 = radiance[base + i0 + 1];
-          const float2 tt = *reinterpret_cast<const float2*>(ray_hit + base + i0);
-          p.t0 = tt.x;
-          p.t1 = tt.y;
-        }
+  // sample counts of one ray fit 32 bits (<= 3R segments x K); only the ray's base offset is 64-bit.  K is a power of two in
+  // every configuration of the reference (32): the index within the segment is then a mask, not a division.
+  const int kmask = (K & (K - 1)) == 0 ? K - 1 : 0;
+  auto load = [&](long base, int n, int s0, Pair& p) {
+    const int i0 = s0 + 2 * lane;
+    p.c0 = p.c1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    p.t0 = p.t1 = 0.0f;
+    if (i0 < n) {
+      if (COMPACT) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(reinterpret_cast<const half4*>(radiance) + base + i0);   // two half4
+        const __half2 a = *reinterpret_cast<const __half2*>(&raw.x), b = *reinterpret_cast<const __half2*>(&raw.y);
+        const __half2 c = *reinterpret_cast<const __half2*>(&raw.z), d = *reinterpret_cast<const __half2*>(&raw.w);
+        p.c0 = make_float4(__low2float(a), __high2float(a), __low2float(b), __high2float(b));
+        p.c1 = make_float4(__low2float(c), __high2float(c), __low2float(d), __high2float(d));
+        // REGULAR t_vals (sampler.cu:52-66): (i + 1) / K of the index in the segment; i0 is even and K even: no wrap inside a pair
+        const int k0 = kmask ? (i0 & kmask) : i0 % K;
+        p.t0 = (float)(k0 + 1) * rK;
+        p.t1 = (float)(k0 + 2) * rK;
+      } else {
+        p.c0 = radiance[base + i0];
+        p.c1 = radiance[base + i0 + 1];
+        const float2 tt = *reinterpret_cast<const float2*>(ray_hit + base + i0);
+        p.t0 = tt.x;
+        p.t1 = tt.y;
       }
-    };
+    }
+  };
+  // The frame has few samples per ray (70 % of the bench frame's rays have none, the rest ~500), so a wave's time is its
+  // chain of dependent memory round trips: the first step of ALL its rays is requested before any ray is composited.
+  long base_r[kRaysPerWave];
+  int n_r[kRaysPerWave];
+  Pair first[kRaysPerWave];
+#pragma unroll
+  for (int r = 0; r < kRaysPerWave; ++r) {
+    base_r[r] = (long)__shfl(idx_l, r, 64) * K;
+    n_r[r] = ray0 + r < batch_size ? __shfl(nh_l, r, 64) * K : 0;     // even
+    if (n_r[r] > 0) load(base_r[r], n_r[r], 0, first[r]);
+  }
+#pragma unroll
+  for (int r = 0; r < kRaysPerWave; ++r) {
+    if (ray0 + r >= batch_size) break;
+    const long base = base_r[r];
+    const int n = n_r[r];
     float T_carry = 0.0f, t_carry = 0.0f;
     float ar = 0.0f, ag = 0.0f, ab = 0.0f;
-    Pair cur, nxt;
-    if (n > 0) load(0, cur);
-    for (long s0 = 0; s0 < n; s0 += 128) {
-      if (s0 + 128 < n) load(s0 + 128, nxt);          // in flight under this step's scan
+    Pair cur = first[r], nxt;
+    for (int s0 = 0; s0 < n; s0 += 128) {
+      if (s0 + 128 < n) load(base, n, s0 + 128, nxt);          // in flight under this step's scan
       const bool act = s0 + 2 * lane < n;
       float x0, x1, w0, w1;
       if (MODE == RTXN_VR_COMPAT) {
-        float tp = __shfl_up(cur.t1, 1, 64);          // previous sample's t: the neighbour lane's second sample
+        float tp = lane_below(cur.t1);          // previous sample's t: the neighbour lane's second sample
         if (lane == 0) tp = t_carry;
         x0 = act ? fabsf(cur.t0 - tp) * cur.c0.w : 0.0f;
         x1 = act ? fabsf(cur.t1 - cur.t0) * cur.c1.w : 0.0f;
         const float pr = x0 + x1;
         const float T0 = (T_carry + (wave_incl_scan_f(pr, lane) - pr)) + x0;   // inclusive optical depth at sample 0 of the pair
         const float T1 = T0 + x1;
-        w0 = act ? expf(-T0) * (1.0f - expf(-x0)) : 0.0f;
-        w1 = act ? expf(-T1) * (1.0f - expf(-x1)) : 0.0f;
-        T_carry = __shfl(T1, 63, 64);
-        t_carry = __shfl(cur.t1, 63, 64);             // inactive lanes only occur in the final step
+        // three hardware exponentials per pair (v_exp_f32 on x log2 e; exp(-T1) = exp(-T0) exp(-x1)) instead of four libm
+        // expf of ~12 instructions each: the compact form of this kernel is bound by its instruction count, not by HBM
+        const float e0 = __expf(-T0), ex0 = __expf(-x0), ex1 = __expf(-x1);
+        w0 = act ? e0 * (1.0f - ex0) : 0.0f;
+        w1 = act ? (e0 * ex1) * (1.0f - ex1) : 0.0f;
+        T_carry = lane63(T1);
+        t_carry = lane63(cur.t1);             // inactive lanes only occur in the final step
       } else {
         x0 = act ? cur.t0 * cur.c0.w : 0.0f;          // ray_hit = step length
         x1 = act ? cur.t1 * cur.c1.w : 0.0f;
         const float pr = x0 + x1;
         const float incl = wave_incl_scan_f(pr, lane);
         const float T0 = T_carry + (incl - pr);       // exclusive transmittance exponent of sample 0
-        w0 = act ? expf(-T0) * (1.0f - expf(-x0)) : 0.0f;
-        w1 = act ? expf(-(T0 + x0)) * (1.0f - expf(-x1)) : 0.0f;
-        T_carry += __shfl(incl, 63, 64);
+        const float e0 = __expf(-T0), ex0 = __expf(-x0), ex1 = __expf(-x1);
+        w0 = act ? e0 * (1.0f - ex0) : 0.0f;
+        w1 = act ? (e0 * ex0) * (1.0f - ex1) : 0.0f;
+        T_carry += lane63(incl);
       }
       ar = fmaf(w1, cur.c1.x, fmaf(w0, cur.c0.x, ar));
       ag = fmaf(w1, cur.c1.y, fmaf(w0, cur.c0.y, ag));
@@ -238,9 +260,9 @@ __global__ __launch_bounds__(256) void volrender_bwd_compat_kernel(const __half*
       c = radiance[base + s0 + lane];
       t = t_hit[base + s0 + lane];
     }
-    float tp = __shfl_up(t, 1, 64);
+    float tp = lane_below(t);
     if (lane == 0) tp = t_carry;
-    t_carry = __shfl(t, 63, 64);
+    t_carry = lane63(t);
     if (act) {
       const float delta = fabsf(t - tp);
       const float sigma = c.w;
@@ -294,7 +316,7 @@ __global__ __launch_bounds__(256) void volrender_bwd_nerf_kernel(const __half* _
     const float incl = wave_incl_scan_f(x, lane);
     const float w = expf(-(T_carry + incl - x)) * (1.0f - expf(-x));
     S += w * (g0 * c.x + g1 * c.y + g2 * c.z);
-    T_carry += __shfl(incl, 63, 64);
+    T_carry += lane63(incl);
   }
   S = wave_sum(S);
   // sweep 2: per-sample gradients
@@ -325,8 +347,8 @@ __global__ __launch_bounds__(256) void volrender_bwd_nerf_kernel(const __half* _
       o.w = __float2half(d * (Ti * ex * gc - suffix));
       grads[base + s0 + lane] = o;
     }
-    T_carry += __shfl(incl, 63, 64);
-    P_carry = __shfl(pincl, 63, 64);
+    T_carry += lane63(incl);
+    P_carry = lane63(pincl);
   }
 }
 
@@ -365,7 +387,7 @@ __global__ __launch_bounds__(256) void volrender_l2_fused_kernel(const float4* _
     ar = fmaf(w, c.x, ar);
     ag = fmaf(w, c.y, ag);
     ab = fmaf(w, c.z, ab);
-    T_carry += __shfl(incl, 63, 64);
+    T_carry += lane63(incl);
   }
   ar = wave_sum(ar);
   ag = wave_sum(ag);
@@ -415,8 +437,8 @@ __global__ __launch_bounds__(256) void volrender_l2_fused_kernel(const float4* _
       o.w = __float2half(d * (Ti * ex * gc - suffix));
       grads[base + s0 + lane] = o;
     }
-    T_carry += __shfl(incl, 63, 64);
-    P_carry = __shfl(pincl, 63, 64);
+    T_carry += lane63(incl);
+    P_carry = lane63(pincl);
   }
 }
 
@@ -590,7 +612,7 @@ __global__ __launch_bounds__(256) void composite_segments_kernel(const float4* _
     ar = fmaf(w, c.x, ar);
     ag = fmaf(w, c.y, ag);
     ab = fmaf(w, c.z, ab);
-    T_carry += __shfl(incl, 63, 64);
+    T_carry += lane63(incl);
   }
   ar = wave_sum(ar);
   ag = wave_sum(ag);
