@@ -948,13 +948,10 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_fused64_kernel(FusedArgs 
       bo[ct] = v;
     }
     if (!__syncthreads_or(any_grad)) {
-      if (a.dencT) {
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-          for (int f = 0; f < a.E; f += 8)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (f + j < a.E) *row_elem(a.dencT, f + j, a.Sp, lane_off[ct]) = (_Float16)0.0f;   // rows f + j + 4h: lane halves interleave
+      if (a.dencT) {      // the tile's 256 columns of every row: 512 contiguous bytes per row, 16 bytes per thread and store
+        _Float16* base = a.dencT + (long)tile * kTile;
+        for (int i = tid; i < a.E * (kTile / 8); i += kThreads)
+          *reinterpret_cast<uint4*>(base + (long)(i / (kTile / 8)) * a.Sp + (i % (kTile / 8)) * 8) = make_uint4(0u, 0u, 0u, 0u);
       }
       continue;
     }
