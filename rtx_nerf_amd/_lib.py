@@ -91,7 +91,7 @@ class TrainBatch(C.Structure):
                 ("encT", C.c_void_p), ("dencT", C.c_void_p), ("workspace", C.c_void_p), ("output_half", C.c_void_p),
                 ("radiance", C.c_void_p), ("t_vals", C.c_void_p), ("radiance_gradients", C.c_void_p),
                 ("pixels", C.c_void_p), ("loss_gradients_half", C.c_void_p), ("loss_sum", C.c_void_p),
-                ("dparams", C.c_void_p), ("dtable", C.c_void_p), ("dtable_hashed_half", C.c_void_p)]
+                ("dparams", C.c_void_p), ("dtable", C.c_void_p), ("dtable_hashed_half", C.c_void_p), ("live_ws", C.c_void_p)]
 
 
 # every symbol include/rtxn.h declares: name -> (restype, argtypes)
@@ -154,6 +154,10 @@ SYMBOLS = {
     "rtxn_adam_effective_lr": (_F, [_F, _F, _F, _I]),
     "rtxn_adam_step_captured": (_I, [_L, _P, _P, _P, _I, _P, _P, _P, _F, _F, _F, _F, _P]),
     "rtxn_train_gradients": (_I, [C.POINTER(TrainBatch), _P]),
+    "rtxn_live_segments_workspace_bytes": (C.c_size_t, [_L]),
+    "rtxn_live_segments": (_I, [_P, _L, _L, _P, _P]),
+    "rtxn_mlp_train_backward_recompute_live": (_I, [_P, _P, _P, _P, _L, _P, _P, _P, _P]),
+    "rtxn_hashgrid_backward_segments_live": (_I, [_P, _P, _P, _L, _I, _P, _P, _P, _P, _P]),
     "rtxn_load_images_json": (_I, [C.c_char_p, C.c_char_p, _I, C.POINTER(ImageDataset)]),
     "rtxn_free_image_dataset": (None, [C.POINTER(ImageDataset)]),
     "rtxn_load_llff": (_I, [C.c_char_p, _I, _I, C.POINTER(ImageDataset), C.POINTER(C.POINTER(C.c_float))]),

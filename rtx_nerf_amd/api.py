@@ -378,7 +378,16 @@ class HashGrid:
               "rtxn_hashgrid_encode_segments")
         return encT
 
-    def backward_segments(self, start_points, end_points, n_segments, sample_type, dencT, dtable, dtable_hashed_half=None):
+    def backward_segments(self, start_points, end_points, n_segments, sample_type, dencT, dtable, dtable_hashed_half=None, live_ws=None):
+        """live_ws (from live_segments): visit only the segments that carry a loss gradient."""
+        if live_ws is not None:
+            check(_lib.lib().rtxn_hashgrid_backward_segments_live(self._h, _ptr(start_points, torch.float32, "start_points"),
+                                                                  _ptr(end_points, torch.float32, "end_points"), n_segments, sample_type,
+                                                                  _ptr(dencT, torch.float16, "dencT"), _ptr(live_ws, None, "live_ws"),
+                                                                  _ptr(dtable, torch.float32, "dtable"),
+                                                                  _ptr(dtable_hashed_half, torch.float16, "dtable_hashed_half"), _stream()),
+                  "rtxn_hashgrid_backward_segments_live")
+            return dtable
         check(_lib.lib().rtxn_hashgrid_backward_segments(self._h, _ptr(start_points, torch.float32, "start_points"),
                                                          _ptr(end_points, torch.float32, "end_points"), n_segments, sample_type,
                                                          _ptr(dencT, torch.float16, "dencT"), _ptr(dtable, torch.float32, "dtable"),
@@ -475,6 +484,14 @@ Network.train_forward_outputs = _net_train_forward_outputs
 Network.train_backward_recompute = _net_train_backward_recompute
 Network.encode_frequency = _net_encode_frequency
 Network.encode_frequency_segments = _net_encode_frequency_segments
+def _net_train_backward_recompute_live(self, encT, output, dout, n, live_ws, dparams, dencT=None):
+    check(_lib.lib().rtxn_mlp_train_backward_recompute_live(self._h, _ptr(encT, torch.float16, "encT"), _ptr(output, torch.float16, "output"),
+                                                           _ptr(dout, torch.float16, "dout"), n, _ptr(live_ws, None, "live_ws"),
+                                                           _ptr(dparams, torch.float32, "dparams"), _ptr(dencT, torch.float16, "dencT"),
+                                                           _stream()), "rtxn_mlp_train_backward_recompute_live")
+
+
+Network.train_backward_recompute_live = _net_train_backward_recompute_live
 Network.train_workspace = _net_train_workspace
 Network.train_forward = _net_train_forward
 Network.train_backward = _net_train_backward
@@ -524,7 +541,7 @@ def adam_step_captured(master, params_fp16, grads, m, v, effective_lr, beta1=0.9
 def train_gradients(net, *, grid=None, n_dir_freqs=0, table=None, start_points, end_points, seg_view, num_stored, indices,
                     total_segments, segment_capacity, n_rays, sample_type, t_scale=1.0, vr_mode, targets, loss_scale,
                     encT, dencT=None, workspace=None, output_half, radiance, t_vals, radiance_gradients, pixels, loss_gradients,
-                    loss_sum=None, dparams, dtable=None, dtable_hashed_half=None):
+                    loss_sum=None, dparams, dtable=None, dtable_hashed_half=None, live_ws=None):
     """rtxn_train_gradients: sampler ... backward of one batch with the segment count taken on the device (main.cu:703-781)."""
     b = _lib.TrainBatch()
     b.mlp, b.grid = net._h, (grid._h if grid is not None else None)
@@ -544,6 +561,9 @@ def train_gradients(net, *, grid=None, n_dir_freqs=0, table=None, start_points, 
     b.loss_sum = _ptr(loss_sum, torch.float32, "loss_sum")
     b.dparams, b.dtable = _ptr(dparams, torch.float32, "dparams"), _ptr(dtable, torch.float32, "dtable")
     b.dtable_hashed_half = _ptr(dtable_hashed_half, torch.float16, "dtable_hashed_half")
+    if live_ws is not None and live_ws.numel() * live_ws.element_size() < live_segments_workspace_bytes(segment_capacity):
+        raise _lib.RtxnError("train_gradients: live_ws smaller than live_segments_workspace_bytes(segment_capacity)")
+    b.live_ws = _ptr(live_ws, None, "live_ws")
     for nm, t, need in (("encT", encT, net.encoded_width() * padded_samples(32 * int(segment_capacity))),
                         ("output_half", output_half, 32 * int(segment_capacity) * 16), ("radiance", radiance, 32 * int(segment_capacity) * 4),
                         ("t_vals", t_vals, 32 * int(segment_capacity)), ("radiance_gradients", radiance_gradients, 32 * int(segment_capacity) * 4),
@@ -553,6 +573,21 @@ def train_gradients(net, *, grid=None, n_dir_freqs=0, table=None, start_points, 
         if t.numel() < need:
             raise _lib.RtxnError(f"train_gradients: {nm} holds {t.numel()} elements, {need} needed for capacity {segment_capacity} / {n_rays} rays")
     check(_lib.lib().rtxn_train_gradients(C.byref(b), _stream()), "rtxn_train_gradients")
+
+
+def live_segments_workspace_bytes(segment_capacity):
+    return int(_lib.lib().rtxn_live_segments_workspace_bytes(int(segment_capacity)))
+
+
+def live_segments_workspace(segment_capacity, device="cuda"):
+    """[int count | pad | int list[capacity] | flags]: see rtxn_live_segments (include/rtxn.h)."""
+    return torch.zeros((live_segments_workspace_bytes(segment_capacity) + 3) // 4, dtype=torch.int32, device=device)
+
+
+def live_segments(radiance_gradients, n_segments, segment_capacity, live_ws):
+    """List the 32-sample segments whose radiance gradient is not all zero; count = live_ws[0], list = live_ws[4:4+count]."""
+    check(_lib.lib().rtxn_live_segments(_ptr(radiance_gradients, torch.float16, "radiance_gradients"), int(n_segments),
+                                        int(segment_capacity), _ptr(live_ws, None, "live_ws"), _stream()), "rtxn_live_segments")
 
 
 def convert_f32_to_f16(src, dst):

@@ -353,8 +353,10 @@ template <bool PK>
 __global__ __launch_bounds__(kThreads) void hashgrid_backward_kernel(HgLevels lv, int level0, SampleSrc src,
                                                                      const _Float16* __restrict__ dencT, long S, long Sp,
                                                                      float* __restrict__ dtable, _Float16* __restrict__ dtable_h,
-                                                                     long hashed_lo, DevCount dc) {
+                                                                     long hashed_lo, DevCount dc, const int* __restrict__ live_list,
+                                                                     const int* __restrict__ live_count) {
   S = live_samples(dc, S);
+  if (live_list) S = 32L * *live_count;                         // the launch walks the listed segments only
   if ((long)blockIdx.x * kThreads >= S) return;                 // whole block past the live samples (block-uniform)
   const int l = level0 + blockIdx.y;
   const int F = lv.n_features;
@@ -362,8 +364,9 @@ __global__ __launch_bounds__(kThreads) void hashgrid_backward_kernel(HgLevels lv
   float* gdst = dtable + (size_t)lv.offset[l] * F;
   half2v* gdst_h = reinterpret_cast<half2v*>(dtable_h + ((size_t)lv.offset[l] * F - (size_t)hashed_lo));   // PK: F == 2
   const int lane = threadIdx.x & 63;
-  const long s = (long)blockIdx.x * kThreads + threadIdx.x;     // every lane stays: the aggregation shuffles across the wave
+  long s = (long)blockIdx.x * kThreads + threadIdx.x;           // every lane stays: the aggregation reads across the wave
   const bool ok = s < S;
+  if (live_list) s = ok ? (long)live_list[s >> 5] * 32 + (s & 31) : 0;
   float d[8];
   bool any_grad = false;
   for (int f = 0; f < F && f < 8; ++f) {
@@ -837,6 +840,8 @@ struct FusedArgs {
   const _Float16* dout;        // [S][4]
   _Float16* dencT;             // [E][Sp] or NULL
   float* dparams;              // tcnn layout, accumulated into
+  const int* live_list;        // segments (32 samples) that carry a loss gradient, ascending, or NULL: all samples in order
+  const int* live_count;       // device count of live_list
 };
 
 typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
@@ -866,6 +871,10 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_fused64_kernel(FusedArgs 
     a.S = live_samples(a.dc, a.S);
     a.n_tiles = (int)(padded_dev(a.S) / kTile);
   }
+  // Live list: a column tile of 32 samples is exactly one segment, so a block tile is any eight segments -- with the list the
+  // kernel visits only segments that carry a loss gradient (rtxn_live_segments), wherever they lie in the batch.
+  const int live_n = a.live_list ? *a.live_count : 0;
+  if (a.live_list) a.n_tiles = (live_n + 7) / 8;
   if ((int)blockIdx.x >= a.n_tiles) return;
   const int rt_e = (a.E + 31) / 32;
   const int fwd_bytes = (KS0 * RT + (L - 1) * KS * RT) * 1024;
@@ -916,10 +925,17 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_fused64_kernel(FusedArgs 
     const long tile0 = (long)tile * kTile + wave * 64;
     unsigned lane_off[2];
     bool ok_s[2];
+    long sidx_ct[2];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
-      const long sidx = tile0 + ct * 32 + col;
+      long sidx = tile0 + ct * 32 + col;
       ok_s[ct] = sidx < a.S;
+      if (a.live_list) {
+        const int slot = tile * 8 + wave * 2 + ct;
+        ok_s[ct] = slot < live_n;
+        sidx = (long)(ok_s[ct] ? a.live_list[slot] : 0) * 32 + col;     // slots past the list read segment 0 and add zeros
+      }
+      sidx_ct[ct] = sidx;
       lane_off[ct] = (unsigned)((sidx + 4L * h * a.Sp) * 2);
     }
     // ---- output layer: dZ_out = dout (*) act'(out) -- first, because a tile whose loss gradients are ALL zero contributes
@@ -933,7 +949,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_fused64_kernel(FusedArgs 
       half8 v;
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.0f;
-      const long sidx = tile0 + ct * 32 + col;
+      const long sidx = sidx_ct[ct];
       if (ok_s[ct] && h == 0) {
         const half4v g = *reinterpret_cast<const half4v*>(a.dout + sidx * 4);
         const half4v y = *reinterpret_cast<const half4v*>(a.out_half + sidx * 16);
@@ -948,7 +964,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_fused64_kernel(FusedArgs 
       bo[ct] = v;
     }
     if (!__syncthreads_or(any_grad)) {
-      if (a.dencT) {      // the tile's 256 columns of every row: 512 contiguous bytes per row, 16 bytes per thread and store
+      if (a.dencT && !a.live_list) {      // the tile's 256 columns of every row: 512 contiguous bytes per row, 16 bytes per thread and store
         _Float16* base = a.dencT + (long)tile * kTile;
         for (int i = tid; i < a.E * (kTile / 8); i += kThreads)
           *reinterpret_cast<uint4*>(base + (long)(i / (kTile / 8)) * a.Sp + (i % (kTile / 8)) * 8) = make_uint4(0u, 0u, 0u, 0u);
@@ -1130,7 +1146,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_fused64_kernel(FusedArgs 
 #pragma unroll
               for (int e = 0; e < 16; ++e) {
                 const int feat0 = 32 * rt + (e & 3) + 8 * (e >> 2);
-                if (feat0 + 4 * h < a.E) *row_elem(a.dencT, feat0, a.Sp, lane_off[ct]) = ok_s[ct] ? (_Float16)d[ct][e] : (_Float16)0.0f;
+                if (feat0 + 4 * h < a.E && (ok_s[ct] || !a.live_list)) *row_elem(a.dencT, feat0, a.Sp, lane_off[ct]) = ok_s[ct] ? (_Float16)d[ct][e] : (_Float16)0.0f;
               }
           }
         }
@@ -1323,6 +1339,69 @@ __global__ __launch_bounds__(kThreads) void wgrad_lds_kernel(WgradArgs a) {
         const int c = 64 * tn + 32 * j + r;
         if (o < M && c < N) atomicAdd(&dW[(long)o * N + c], acc[i][j][e]);
       }
+}
+
+// ------------------------------------------------------------------------- segments that carry a loss gradient
+// In NeRF training most samples lie behind the first surface, where the transmittance and with it dL/d(radiance) is exactly
+// zero (configs[2] batch: 12 % of the samples, 30 % of the 64-sample waves carry a gradient).  The backward kernels do not
+// have to visit the others: live_flags_kernel marks every 32-sample segment with a non-zero radiance gradient, live_compact_
+// kernel (one block) writes their indices in ascending order and their count, and mlp_bwd_fused64_kernel /
+// hashgrid_backward_kernel walk that list (a column tile of the fused kernel is exactly one segment).
+__global__ __launch_bounds__(kThreads) void live_flags_kernel(const uint2* __restrict__ dout_half4, long S, DevCount dc, uint8_t* __restrict__ flags) {
+  S = live_samples(dc, S);
+  const long s = (long)blockIdx.x * kThreads + threadIdx.x;
+  if ((long)blockIdx.x * kThreads >= S) return;
+  bool nz = false;
+  if (s < S) {
+    const uint2 g = dout_half4[s];
+    nz = ((g.x | g.y) & 0x7fff7fffu) != 0;            // four halves; -0.0 is zero
+  }
+  const unsigned long long b = __ballot(nz);
+  const int lane = threadIdx.x & 63;
+  if ((lane & 31) == 0 && s < S) flags[s >> 5] = ((b >> lane) & 0xffffffffull) != 0 ? 1 : 0;
+}
+constexpr int kCompactThreads = 1024;
+// one block: every thread takes FOUR consecutive flags per round (one 4-byte load), so a round covers 4096 segments
+__global__ __launch_bounds__(kCompactThreads) void live_compact_kernel(const uint8_t* __restrict__ flags, long S, DevCount dc,
+                                                                       int* __restrict__ list, int* __restrict__ count) {
+  __shared__ int wave_tot[kCompactThreads / 64];
+  S = live_samples(dc, S);
+  const int P = (int)(S >> 5);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int base = 0;                                       // every thread keeps the running total: no broadcast round
+  for (int p0 = 0; p0 < P; p0 += 4 * kCompactThreads) {
+    const int p = p0 + 4 * tid;
+    unsigned f = 0;
+    if (p + 3 < P) f = *reinterpret_cast<const unsigned*>(flags + p);          // flags is 16-byte aligned, p a multiple of 4
+    else
+      for (int k = 0; k < 4; ++k)
+        if (p + k < P) f |= (unsigned)flags[p + k] << (8 * k);
+    const int mine = (f & 1u) + ((f >> 8) & 1u) + ((f >> 16) & 1u) + ((f >> 24) & 1u);
+    // exclusive prefix of `mine` inside the wave (DPP adds), then across the block's 16 waves through LDS
+    int incl = mine;
+    incl += dpp_i<0x111, 0xf>(incl);
+    incl += dpp_i<0x112, 0xf>(incl);
+    incl += dpp_i<0x114, 0xf>(incl);
+    incl += dpp_i<0x118, 0xf>(incl);
+    incl += dpp_i<0x142, 0xa>(incl);
+    incl += dpp_i<0x143, 0xc>(incl);
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int off = base, total = 0;
+#pragma unroll
+    for (int w = 0; w < kCompactThreads / 64; ++w) {
+      const int t = wave_tot[w];
+      if (w < wave) off += t;
+      total += t;
+    }
+    off += incl - mine;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if ((f >> (8 * k)) & 1u) list[off++] = p + k;
+    base += total;
+    __syncthreads();                                  // wave_tot is rewritten in the next round
+  }
+  if (tid == 0) *count = base;
 }
 
 // ------------------------------------------------------------------------- loss, optimizer
@@ -1674,7 +1753,8 @@ extern "C" int rtxn_mlp_train_forward_outputs(const rtxn_mlp* m, const void* enc
 }
 
 static int train_backward_recompute_impl(const rtxn_mlp* m, const void* encT, const void* output_half, const void* dout_half4,
-                                         long n_samples, float* dparams, void* dencT, DevCount dc, rtxn_stream_t stream) {
+                                         long n_samples, float* dparams, void* dencT, DevCount dc, rtxn_stream_t stream,
+                                         const int* live_list = nullptr, const int* live_count = nullptr) {
   const int L = m->cfg.n_hidden_layers, E = m->enc_padded;
   FusedArgs a;
   memset(&a, 0, sizeof(a));
@@ -1693,6 +1773,8 @@ static int train_backward_recompute_impl(const rtxn_mlp* m, const void* encT, co
   a.dout = static_cast<const _Float16*>(dout_half4);
   a.dencT = static_cast<_Float16*>(dencT);
   a.dparams = dparams;
+  a.live_list = live_list;
+  a.live_count = live_count;
   const int RT = 2, KS = 4;
   const size_t lds = (size_t)(a.KS0 * RT + (L - 1) * KS * RT) * 1024 + (size_t)(RT + (L - 1) * RT * KS + ((E + 31) / 32) * KS) * 1024 +
                      8 * (size_t)kImgBytes;
@@ -1843,7 +1925,8 @@ extern "C" int rtxn_hashgrid_encode_segments(const rtxn_hashgrid* g, int n_dir_f
 // dtable_hashed_half == NULL: every level into the fp32 table.  Otherwise (n_features == 2): the hashed levels go to the fp16
 // buffer, which holds the parameters from the first hashed level on.
 static int hashgrid_backward_impl(const rtxn_hashgrid* g, const SampleSrc& input, const void* dencT, long n_samples,
-                                  float* dtable, void* dtable_hashed_half, DevCount dc, rtxn_stream_t stream) {
+                                  float* dtable, void* dtable_hashed_half, DevCount dc, rtxn_stream_t stream,
+                                  const int* live_list = nullptr, const int* live_count = nullptr) {
   const long Sp = padded(n_samples);
   const int NL = g->cfg.n_levels, F = g->cfg.n_features;
   int first_hashed = NL;
@@ -1857,12 +1940,12 @@ static int hashgrid_backward_impl(const rtxn_hashgrid* g, const SampleSrc& input
   const unsigned sblocks = (unsigned)((n_samples + kThreads - 1) / kThreads);
   if (first_hashed > 0) {
     hashgrid_backward_kernel<false><<<dim3(sblocks, (unsigned)first_hashed), kThreads, 0, st>>>(
-        lv, 0, input, de, n_samples, Sp, dtable, nullptr, 0, dc);
+        lv, 0, input, de, n_samples, Sp, dtable, nullptr, 0, dc, live_list, live_count);
     RTXN_LAUNCH_CHECK("hashgrid_backward_kernel");
   }
   if (first_hashed < NL) {
     hashgrid_backward_kernel<true><<<dim3(sblocks, (unsigned)(NL - first_hashed)), kThreads, 0, st>>>(
-        lv, first_hashed, input, de, n_samples, Sp, dtable, static_cast<_Float16*>(dtable_hashed_half), hashed_lo, dc);
+        lv, first_hashed, input, de, n_samples, Sp, dtable, static_cast<_Float16*>(dtable_hashed_half), hashed_lo, dc, live_list, live_count);
     RTXN_LAUNCH_CHECK("hashgrid_backward_kernel<pk_f16>");
   }
   return RTXN_OK;
@@ -1966,6 +2049,72 @@ extern "C" int rtxn_adam_step_captured(long n, float* master, void* params_fp16,
                    loss_scale, stream);
 }
 
+// ------------------------------------------------------------------------- live segments
+// workspace: [int count | 12 B pad | int list[capacity] | uint8 flags[capacity]]
+static size_t live_ws_bytes(long capacity) { return (size_t)(16 + 4 * capacity + ((capacity + 15) / 16) * 16); }
+static const int* live_count_of(const void* ws) { return static_cast<const int*>(ws); }
+static const int* live_list_of(const void* ws) { return reinterpret_cast<const int*>(static_cast<const uint8_t*>(ws) + 16); }
+
+extern "C" size_t rtxn_live_segments_workspace_bytes(long segment_capacity) {
+  return segment_capacity < 0 ? 0 : live_ws_bytes(segment_capacity);
+}
+
+static int live_segments_impl(const void* dout_half4, long n_segments, long capacity, void* live_ws, DevCount dc, rtxn_stream_t stream) {
+  uint8_t* ws = static_cast<uint8_t*>(live_ws);
+  uint8_t* flags = ws + 16 + 4 * capacity;
+  const long S = n_segments * 32;
+  hipStream_t st = rtxn::as_stream(stream);
+  live_flags_kernel<<<(unsigned)((S + kThreads - 1) / kThreads), kThreads, 0, st>>>(static_cast<const uint2*>(dout_half4), S, dc, flags);
+  RTXN_LAUNCH_CHECK("live_flags_kernel");
+  live_compact_kernel<<<1, kCompactThreads, 0, st>>>(flags, S, dc, reinterpret_cast<int*>(ws + 16), reinterpret_cast<int*>(ws));
+  RTXN_LAUNCH_CHECK("live_compact_kernel");
+  return RTXN_OK;
+}
+
+extern "C" int rtxn_live_segments(const void* radiance_gradients_half4, long n_segments, long segment_capacity, void* live_ws,
+                                  rtxn_stream_t stream) {
+  RTXN_REQUIRE(n_segments >= 0 && segment_capacity >= n_segments && segment_capacity <= kMaxTrainSamples / 32,
+               "rtxn_live_segments: n_segments = %ld, segment_capacity = %ld", n_segments, segment_capacity);
+  RTXN_REQUIRE(live_ws && ((uintptr_t)live_ws & 15) == 0, "rtxn_live_segments: workspace NULL or not 16-byte aligned");
+  RTXN_DEVICE_OR_FAIL();
+  if (n_segments == 0) {
+    RTXN_HIP(hipMemsetAsync(live_ws, 0, 16, rtxn::as_stream(stream)));
+    return RTXN_OK;
+  }
+  RTXN_REQUIRE(radiance_gradients_half4 && ((uintptr_t)radiance_gradients_half4 & 7) == 0, "rtxn_live_segments: gradients NULL or not 8-byte aligned");
+  return live_segments_impl(radiance_gradients_half4, n_segments, segment_capacity, live_ws, DevCount{nullptr, 0}, stream);
+}
+
+extern "C" int rtxn_mlp_train_backward_recompute_live(const rtxn_mlp* m, const void* encT, const void* output_half,
+                                                      const void* dout_half4, long n_samples, const void* live_ws, float* dparams,
+                                                      void* dencT, rtxn_stream_t stream) {
+  int rc = check_train(m, "rtxn_mlp_train_backward_recompute_live");
+  if (rc != RTXN_OK) return rc;
+  RTXN_REQUIRE(rtxn_mlp_train_recompute_supported(m), "rtxn_mlp_train_backward_recompute_live: this model has no recompute path");
+  RTXN_REQUIRE(n_samples >= 0 && n_samples <= kMaxTrainSamples && n_samples % 32 == 0,
+               "rtxn_mlp_train_backward_recompute_live: n_samples = %ld must be whole segments in [0, %ld]", n_samples, kMaxTrainSamples);
+  RTXN_DEVICE_OR_FAIL();
+  if (n_samples == 0) return RTXN_OK;
+  RTXN_REQUIRE(encT && output_half && dout_half4 && dparams && live_ws, "rtxn_mlp_train_backward_recompute_live: NULL buffer");
+  return train_backward_recompute_impl(m, encT, output_half, dout_half4, n_samples, dparams, dencT, DevCount{nullptr, 0}, stream,
+                                       live_list_of(live_ws), live_count_of(live_ws));
+}
+
+extern "C" int rtxn_hashgrid_backward_segments_live(const rtxn_hashgrid* g, const float* start_points, const float* end_points,
+                                                    long n_segments, int sample_type, const void* dencT, const void* live_ws,
+                                                    float* dtable, void* dtable_hashed_half, rtxn_stream_t stream) {
+  RTXN_REQUIRE(g, "rtxn_hashgrid_backward_segments_live: NULL grid");
+  int rc = check_segments("rtxn_hashgrid_backward_segments_live", start_points, end_points, start_points, n_segments, sample_type);
+  if (rc != RTXN_OK) return rc;
+  RTXN_REQUIRE(!dtable_hashed_half || g->cfg.n_features == 2, "rtxn_hashgrid_backward_segments_live: packed fp16 atomics need n_features == 2 (got %d)", g->cfg.n_features);
+  RTXN_DEVICE_OR_FAIL();
+  if (n_segments == 0) return RTXN_OK;
+  RTXN_REQUIRE(dencT && dtable && live_ws, "rtxn_hashgrid_backward_segments_live: NULL buffer");
+  const SampleSrc src{nullptr, start_points, end_points, nullptr, sample_type == RTXN_SAMPLING_MIDPOINT_WORLD};
+  return hashgrid_backward_impl(g, src, dencT, n_segments * 32, dtable, dtable_hashed_half, DevCount{nullptr, 0}, stream,
+                                live_list_of(live_ws), live_count_of(live_ws));
+}
+
 // ------------------------------------------------------------------------- a whole batch, segment count on the device
 extern "C" int rtxn_train_gradients(const rtxn_train_batch* b, rtxn_stream_t stream) {
   RTXN_REQUIRE(b && b->mlp, "rtxn_train_gradients: NULL batch or model");
@@ -2020,14 +2169,22 @@ extern "C" int rtxn_train_gradients(const rtxn_train_batch* b, rtxn_stream_t str
                             b->radiance_gradients, b->vr_mode, stream);
     if (rc != RTXN_OK) return rc;
   }
-  // network->backward (main.cu:781)
-  rc = recompute ? train_backward_recompute_impl(m, b->encT, b->output_half, b->radiance_gradients, cap_samples, b->dparams, b->dencT, dc, stream)
+  // network->backward (main.cu:781); with live_ws only over the segments that carry a loss gradient
+  const bool use_live = b->live_ws != nullptr && recompute;
+  if (use_live) {
+    RTXN_REQUIRE(((uintptr_t)b->live_ws & 15) == 0, "rtxn_train_gradients: live_ws not 16-byte aligned");
+    rc = live_segments_impl(b->radiance_gradients, b->segment_capacity, b->segment_capacity, b->live_ws, dc, stream);
+    if (rc != RTXN_OK) return rc;
+  }
+  const int* ll = use_live ? live_list_of(b->live_ws) : nullptr;
+  const int* lc = use_live ? live_count_of(b->live_ws) : nullptr;
+  rc = recompute ? train_backward_recompute_impl(m, b->encT, b->output_half, b->radiance_gradients, cap_samples, b->dparams, b->dencT, dc, stream, ll, lc)
                  : train_backward_impl(m, b->encT, b->output_half, b->radiance_gradients, cap_samples, b->workspace, b->dparams,
                                        hash ? b->dencT : nullptr, dc, stream);
   if (rc != RTXN_OK) return rc;
   if (hash) {
     const SampleSrc bsrc{nullptr, b->start_points, b->end_points, nullptr, b->sample_type == RTXN_SAMPLING_MIDPOINT_WORLD};
-    rc = hashgrid_backward_impl(b->grid, bsrc, b->dencT, cap_samples, b->dtable, b->dtable_hashed_half, dc, stream);
+    rc = hashgrid_backward_impl(b->grid, bsrc, b->dencT, cap_samples, b->dtable, b->dtable_hashed_half, dc, stream, ll, lc);
   }
   return rc;
 }

@@ -108,6 +108,10 @@ class Trainer:
         self.fold_sampler = os.environ.get("RTXN_TRAIN_FOLD_SAMPLER", "1") != "0"
         # "nerf" mode: compositor forward + L2 + compositor backward as one launch (RTXN_TRAIN_FUSE_COMPOSITOR=0: three)
         self.fuse_compositor = os.environ.get("RTXN_TRAIN_FUSE_COMPOSITOR", "1") != "0"
+        # The backward visits only the segments that carry a loss gradient (librtxn: rtxn_live_segments; most of a NeRF batch
+        # lies behind the first surface, where dL/d(radiance) is exactly 0).  Needs the recompute path (a column tile of its
+        # kernel is one segment) and the folded sampler.  RTXN_TRAIN_LIVE_SEGMENTS=0: every segment.
+        self.live_segments = (self.recompute and self.fold_sampler and os.environ.get("RTXN_TRAIN_LIVE_SEGMENTS", "1") != "0")
         # ---- per-step buffers at capacity ---------------------------------------------------------
         B = batch_rays
         self.max_segments = int(max_segments) if max_segments else 64 * B
@@ -134,6 +138,7 @@ class Trainer:
         self.out = torch.empty((M * K, 16), dtype=torch.float16, device=d)
         self.radiance = torch.empty((M * K, 4), device=d)
         self.dout = torch.empty((M * K, 4), dtype=torch.float16, device=d)
+        self.live_ws = api.live_segments_workspace(M, device=d) if self.live_segments else None
         self.pixels = torch.empty((B, 3), device=d)
         self.loss_grads = torch.empty((B, 3), dtype=torch.float16, device=d)
         self.loss = torch.zeros(1, device=d)
@@ -254,8 +259,13 @@ class Trainer:
             with _Stage(self, "composite_bwd"):
                 api.launch_volrender_backward_cuda(None, self.loss_grads, self.radiance, self.t_vals, self.num_stored,
                                                    self.indices, n, K, self.dout, mode=vr)
+        if self.live_segments:
+            with _Stage(self, "live_segments"):
+                api.live_segments(self.dout, P, self.max_segments, self.live_ws)
         with _Stage(self, "mlp_bwd+wgrad"):
-            if self.recompute:
+            if self.live_segments:
+                self.net.train_backward_recompute_live(self.encT, self.out, self.dout, S, self.live_ws, self.dparams, self.dencT)
+            elif self.recompute:
                 self.net.train_backward_recompute(self.encT, self.out, self.dout, S, self.dparams, self.dencT)
             else:
                 self.net.train_backward(self.encT, self.out, self.dout, S, self.ws, self.dparams, self.dencT)
@@ -263,7 +273,7 @@ class Trainer:
             with _Stage(self, "hash_bwd"):
                 if self.fold_sampler:
                     self.hg.backward_segments(self.start, self.end, P, self._stype(), self.dencT, self.dtable,
-                                              self.dtable_h if self.hash_fp16 else None)
+                                              self.dtable_h if self.hash_fp16 else None, live_ws=self.live_ws if self.live_segments else None)
                 elif self.hash_fp16:
                     self.hg.backward_mixed(self.samples[:S], self.dencT, self.dtable, self.dtable_h)
                 else:
@@ -578,7 +588,8 @@ class Trainer:
                             loss_scale=self.loss_scale, encT=self.encT, dencT=self.dencT, workspace=self.ws,
                             output_half=self.out, radiance=self.radiance, t_vals=self.t_vals, radiance_gradients=self.dout,
                             pixels=self.pixels, loss_gradients=self.loss_grads, loss_sum=self.loss, dparams=self.dparams,
-                            dtable=self.dtable if hash_ else None, dtable_hashed_half=self.dtable_h if (hash_ and self.hash_fp16) else None)
+                            dtable=self.dtable if hash_ else None, dtable_hashed_half=self.dtable_h if (hash_ and self.hash_fp16) else None,
+                            live_ws=self.live_ws if self.live_segments else None)
 
     def _captured_apply(self, grad_divisor):
         self._g_step.add_(1)

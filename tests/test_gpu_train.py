@@ -351,3 +351,72 @@ def test_fused_compositor_l2_backward_matches_the_three_calls(gpu, oracle):
     assert abs(float(loss.item()) - o_loss) < 1e-4 * o_loss
     want = oracle.volrender_bwd_nerf(lg.cpu().numpy(), rad, step, nh, idx, K=K)[:P * K]
     np.testing.assert_allclose(a, want, rtol=1.5e-3, atol=2e-5)
+
+
+def test_live_segment_backward_equals_the_full_backward(gpu):
+    """rtxn_live_segments + the two _live backward entry points against the unrestricted calls on a batch whose radiance
+    gradient is zero on most segments (as in NeRF training): the list is exactly the segments with a non-zero gradient, in
+    ascending order; weight and table gradients agree to the order of the atomics; d(encoding) of the listed segments is
+    identical, the other columns are left alone."""
+    torch = gpu
+    from rtx_nerf_amd import api
+    rng = np.random.default_rng(11)
+    P, K = 700, 32
+    S = P * K
+    hg = api.HashGrid(8, 2, 14, 8, 1.6, n_dir_freqs=4)
+    E = hg.encoded_width()
+    net = api.Network(n_neurons=64, n_hidden_layers=3, n_encoded_features=E)
+    net.set_params(_dev(torch, scenes.xavier_params_fp16(64, 3, E, seed=4)))
+    sp = rng.uniform(-0.9, 0.9, (P, 3)).astype(np.float32)
+    ep = (sp + rng.uniform(-0.02, 0.02, (P, 3))).astype(np.float32)
+    sv = rng.uniform(0, 3, (P, 2)).astype(np.float32)
+    sp_d, ep_d, sv_d = _dev(torch, sp), _dev(torch, ep), _dev(torch, sv)
+    table = _dev(torch, rng.uniform(-1, 1, hg.n_params()).astype(np.float16))
+    Sp = api.padded_samples(S)
+    encT = torch.zeros((E, Sp), dtype=torch.float16, device="cuda")
+    t_vals = torch.zeros(S, device="cuda")
+    hg.encode_segments(table, sp_d, ep_d, sv_d, P, api.SAMPLING_REGULAR, encT, t_vals, 1.0)
+    out = torch.zeros((S, 16), dtype=torch.float16, device="cuda")
+    rad = torch.zeros((S, 4), device="cuda")
+    net.train_forward_outputs(encT, S, out, rad)
+    live = np.zeros(P, bool)
+    live[rng.choice(P, 90, replace=False)] = True
+    live[[0, P - 1]] = True
+    dout = np.zeros((P, K, 4), np.float16)
+    dout[live] = (rng.standard_normal((int(live.sum()), K, 4)) * 0.05).astype(np.float16)
+    dout[live, 1:, :] *= (rng.uniform(size=(int(live.sum()), K - 1, 1)) < 0.5)     # some zero samples inside live segments
+    dout[5, :, :] = 0
+    dout[5, 7, 2] = np.float16(-0.0)                                             # -0.0 is zero: segment 5 stays dead
+    live[5] = False
+    dout_d = _dev(torch, dout.reshape(S, 4))
+    cap = P + 37
+    ws = api.live_segments_workspace(cap)
+    api.live_segments(dout_d, P, cap, ws)
+    n = int(ws[0].item())
+    np.testing.assert_array_equal(ws[4:4 + n].cpu().numpy(), np.nonzero(live)[0])
+    # full backward
+    dp_full = torch.zeros(net.n_params(), device="cuda")
+    de_full = torch.full((E, Sp), 7.0, dtype=torch.float16, device="cuda")
+    net.train_backward_recompute(encT, out, dout_d, S, dp_full, de_full)
+    lo = hg.hashed_offset()
+    dt_full, dh_full = torch.zeros(hg.n_params(), device="cuda"), torch.zeros(hg.n_params() - lo, dtype=torch.float16, device="cuda")
+    hg.backward_segments(sp_d, ep_d, P, api.SAMPLING_REGULAR, de_full, dt_full, dh_full)
+    # live backward
+    dp_live = torch.zeros(net.n_params(), device="cuda")
+    de_live = torch.full((E, Sp), 7.0, dtype=torch.float16, device="cuda")
+    net.train_backward_recompute_live(encT, out, dout_d, S, ws, dp_live, de_live)
+    dt_live, dh_live = torch.zeros(hg.n_params(), device="cuda"), torch.zeros(hg.n_params() - lo, dtype=torch.float16, device="cuda")
+    hg.backward_segments(sp_d, ep_d, P, api.SAMPLING_REGULAR, de_live, dt_live, dh_live, live_ws=ws)
+    assert float((dp_full - dp_live).norm()) <= 1e-5 * float(dp_full.norm()) and float(dp_full.norm()) > 0
+    cols = np.repeat(live, K)
+    a, b = de_full.cpu().numpy()[:, :S], de_live.cpu().numpy()[:, :S]
+    np.testing.assert_array_equal(a[:, cols], b[:, cols])
+    assert np.all(b[:, ~cols] == 7.0) and np.all(a[:, ~cols] == 0.0)
+    assert float((dt_full - dt_live).abs().max()) <= 1e-5 * float(dt_full.abs().max()) and float(dt_full.abs().max()) > 0
+    assert float((dh_full.float() - dh_live.float()).abs().max()) <= 4e-3 * float(dh_full.float().abs().max())
+    # nothing live: count 0, gradients untouched
+    api.live_segments(torch.zeros_like(dout_d), P, cap, ws)
+    assert int(ws[0].item()) == 0
+    dp0 = torch.zeros(net.n_params(), device="cuda")
+    net.train_backward_recompute_live(encT, out, torch.zeros_like(dout_d), S, ws, dp0, de_live)
+    assert float(dp0.abs().max()) == 0.0

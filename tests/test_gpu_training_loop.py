@@ -83,7 +83,20 @@ def test_config3_training_step_matches_oracle_chain(gpu, oracle):
     dp, denc = O.mlpe_backward(64, 4, 1, params0, enc_g, acts_g, tr.out[:S].cpu().numpy(), tr.dout[:S].cpu().numpy())
     got_dp = tr.dparams.cpu().numpy()
     assert np.linalg.norm(got_dp - dp) < 2e-2 * np.linalg.norm(dp) and np.abs(dp).max() > 0
-    dt = O.hg_backward(ocfg, samples, tr.dencT.reshape(-1)[:tr.E * Sp].reshape(tr.E, Sp)[:, :S].t().contiguous().cpu().numpy())
+    denc_g = tr.dencT.reshape(-1)[:tr.E * Sp].reshape(tr.E, Sp)[:, :S].t().contiguous().cpu().numpy()
+    if tr.live_segments:
+        # the backward visited only the segments with a loss gradient (rtxn_live_segments): d(encoding) of the others was never
+        # written and nothing reads it -- for the oracle, which walks every sample, those columns are the zeros they stand for
+        n_live = int(tr.live_ws[0].item())
+        listed = tr.live_ws[4:4 + n_live].cpu().numpy()
+        want_live = np.nonzero((tr.dout[:S].cpu().numpy().reshape(P, 32, 4).view(np.uint16) & 0x7fff).any(axis=(1, 2)))[0]
+        np.testing.assert_array_equal(listed, want_live)
+        assert 0 < n_live < P
+        dead = np.ones(P, bool)
+        dead[listed] = False
+        assert np.abs(denc[np.repeat(dead, 32)]).max() == 0.0          # and the oracle agrees that they are zero
+        denc_g[np.repeat(dead, 32)] = 0
+    dt = O.hg_backward(ocfg, samples, denc_g)
     got_dt = tr.table_grad().cpu().numpy()
     # hashed levels are accumulated in fp16 (packed atomics): 11-bit contributions
     assert np.abs(got_dt - dt).max() < (3e-3 if tr.hash_fp16 else 1e-3) * max(1e-6, np.abs(dt).max())
