@@ -12,21 +12,23 @@ dense = scenes.lego_standin_density(R, seed=0)
 occ = torch.from_numpy(scenes.pack_occupancy(dense).view(np.int32).copy()).cuda()
 hgd = dict(n_levels=16, n_features=2, log2_hashmap_size=19, base_resolution=16, per_level_scale=1.5)
 focal = scenes.lego_focal_length(True)
-ro, rd = [], []
+def make(batch_rays=B):
+    return Trainer(R, occ, encoding="hash", n_neurons=64, n_hidden_layers=4, hashgrid=hgd, n_dir_freqs=4, batch_rays=batch_rays,
+                   max_segments=batch_rays * 16, lr=1e-2, loss_scale=128.0, density_scale=300.0, mode="nerf")
+
+
+# targets from the analytic teacher field, as in bench.py: the step's cost depends on how much of the batch carries a gradient
+ro, rd, tg = [], [], []
+_t = make(128 * 128)
 for i in range(4):
     o, d = camera_rays(scenes.pose_spherical(90.0 * i + 15.0, -30.0, origin_scale=10.0), focal, 128, 128)
-    ro.append(o); rd.append(d)
-ro, rd = torch.cat(ro), torch.cat(rd)
-tg = torch.rand((ro.shape[0], 3), device="cuda")
-
-
-def make():
-    return Trainer(R, occ, encoding="hash", n_neurons=64, n_hidden_layers=4, hashgrid=hgd, n_dir_freqs=4, batch_rays=B,
-                   max_segments=B * 16, lr=1e-2, loss_scale=128.0, density_scale=300.0, mode="nerf")
+    ro.append(o); rd.append(d); tg.append(_t.render_rays(o, d, radiance_fn=scenes.teacher_field).clone())
+ro, rd, tg = torch.cat(ro), torch.cat(rd), torch.cat(tg)
+del _t
 
 
 def wall(fn, n=40):
-    for _ in range(5):
+    for _ in range(20):          # every variant has trained the same number of steps when it is timed
         fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
