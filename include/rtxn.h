@@ -389,9 +389,12 @@ int rtxn_adam_step_half_grads(long n, float* master, void* params_fp16, const vo
  * depends on the step number, which must not be baked into the captured launch, so it is read from DEVICE memory
  * (*effective_lr) -- the caller refreshes it before every replay (e.g. an H2D copy node from pinned memory holding
  * rtxn_adam_effective_lr(lr, beta1, beta2, t), which is exactly the value rtxn_adam_step computes on the host).
- * grads_fp16 != 0: `grads` is half[n] (as rtxn_adam_step_half_grads), else float[n]. */
+ * grad_flags: RTXN_ADAM_GRADS_FP16: `grads` is half[n] (as rtxn_adam_step_half_grads), else float[n];
+ * RTXN_ADAM_ZERO_GRADS: the gradient is cleared as it is consumed, so the next step accumulates into zeros without a
+ * separate fill pass over the (tens of MB of) table gradient. */
+enum rtxn_adam_grad_flags { RTXN_ADAM_GRADS_FP16 = 1, RTXN_ADAM_ZERO_GRADS = 2 };
 float rtxn_adam_effective_lr(float lr, float beta1, float beta2, int step);
-int rtxn_adam_step_captured(long n, float* master, void* params_fp16, const void* grads, int grads_fp16, float* m, float* v,
+int rtxn_adam_step_captured(long n, float* master, void* params_fp16, void* grads, int grad_flags, float* m, float* v,
                             const float* effective_lr, float beta1, float beta2, float eps, float loss_scale,
                             rtxn_stream_t stream);
 

@@ -526,13 +526,17 @@ def adam_effective_lr(lr, beta1, beta2, step):
     return float(_lib.lib().rtxn_adam_effective_lr(lr, beta1, beta2, int(step)))
 
 
-def adam_step_captured(master, params_fp16, grads, m, v, effective_lr, beta1=0.9, beta2=0.999, eps=1e-8, loss_scale=1.0):
+ADAM_GRADS_FP16, ADAM_ZERO_GRADS = 1, 2
+
+
+def adam_step_captured(master, params_fp16, grads, m, v, effective_lr, beta1=0.9, beta2=0.999, eps=1e-8, loss_scale=1.0, zero_grads=False):
     """adam_step / adam_step_half_grads (by the dtype of `grads`) with the bias-corrected rate read from the device float
-    `effective_lr`: the form a hipGraph can replay."""
+    `effective_lr`: the form a hipGraph can replay.  zero_grads: clear the gradient as it is consumed."""
     half = grads.dtype == torch.float16
+    flags = (ADAM_GRADS_FP16 if half else 0) | (ADAM_ZERO_GRADS if zero_grads else 0)
     check(_lib.lib().rtxn_adam_step_captured(master.numel(), _ptr(master, torch.float32, "master"),
                                              _ptr(params_fp16, torch.float16, "params"),
-                                             _ptr(grads, torch.float16 if half else torch.float32, "grads"), 1 if half else 0,
+                                             _ptr(grads, torch.float16 if half else torch.float32, "grads"), flags,
                                              _ptr(m, torch.float32, "m"), _ptr(v, torch.float32, "v"),
                                              _ptr(effective_lr, torch.float32, "effective_lr"), beta1, beta2, eps, loss_scale,
                                              _stream()), "rtxn_adam_step_captured")

@@ -1436,14 +1436,15 @@ __device__ __forceinline__ void adam_one(float g, float& mi, float& vi, float& w
   w = w - lr_eff * mi / (sqrtf(vi) + eps);
 }
 // HBM-bound (22-28 B per parameter): four parameters per thread, 16-byte accesses
-template <bool HALF_GRADS>
+// ZERO: the gradient is cleared as it is consumed (the next step accumulates into zeros without a separate fill pass)
+template <bool HALF_GRADS, bool ZERO>
 __global__ __launch_bounds__(kThreads) void adam_kernel(long n, float* __restrict__ master, __half* __restrict__ params,
-                                                        const void* __restrict__ grads_v, float* __restrict__ m,
+                                                        void* __restrict__ grads_v, float* __restrict__ m,
                                                         float* __restrict__ v, float lr_eff, float beta1, float beta2,
                                                         float eps, float inv_loss_scale, const float* __restrict__ lr_dev) {
   if (lr_dev) lr_eff = *lr_dev;      // captured steps: the bias-corrected rate changes every replay, the graph does not
-  const float* gf = static_cast<const float*>(grads_v);
-  const __half* gh = static_cast<const __half*>(grads_v);
+  float* gf = static_cast<float*>(grads_v);
+  __half* gh = static_cast<__half*>(grads_v);
   const bool vec = (((uintptr_t)master | (uintptr_t)m | (uintptr_t)v | (uintptr_t)grads_v) & 15) == 0 && ((uintptr_t)params & 7) == 0;
   const long n4 = vec ? n / 4 : 0;
   for (long q = (long)blockIdx.x * kThreads + threadIdx.x; q < n4; q += (long)gridDim.x * kThreads) {
@@ -1453,9 +1454,11 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(long n, float* __restric
       const half4v h = reinterpret_cast<const half4v*>(gh)[q];
 #pragma unroll
       for (int e = 0; e < 4; ++e) g[e] = (float)h[e] * inv_loss_scale;
+      if (ZERO) reinterpret_cast<uint2*>(gh)[q] = make_uint2(0u, 0u);
     } else {
       const float4 f = reinterpret_cast<const float4*>(gf)[q];
       g[0] = f.x * inv_loss_scale; g[1] = f.y * inv_loss_scale; g[2] = f.z * inv_loss_scale; g[3] = f.w * inv_loss_scale;
+      if (ZERO) reinterpret_cast<float4*>(gf)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     adam_one(g[0], m4.x, v4.x, w4.x, lr_eff, beta1, beta2, eps);
     adam_one(g[1], m4.y, v4.y, w4.y, lr_eff, beta1, beta2, eps);
@@ -1469,6 +1472,7 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(long n, float* __restric
   }
   for (long i = 4 * n4 + (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
     const float g = (HALF_GRADS ? __half2float(gh[i]) : gf[i]) * inv_loss_scale;
+    if (ZERO) { if (HALF_GRADS) gh[i] = __float2half(0.0f); else gf[i] = 0.0f; }
     float mi = m[i], vi = v[i], w = master[i];
     adam_one(g, mi, vi, w, lr_eff, beta1, beta2, eps);
     m[i] = mi;
@@ -2004,7 +2008,7 @@ extern "C" int rtxn_l2_loss(const float* pred, const float* target, long n, floa
 static float adam_lr_eff(float lr, float beta1, float beta2, int step) {
   return lr * sqrtf(1.0f - powf(beta2, (float)step)) / (1.0f - powf(beta1, (float)step));
 }
-static int adam_impl(const char* who, long n, float* master, void* params_fp16, const void* grads, int grads_fp16, float* m, float* v,
+static int adam_impl(const char* who, long n, float* master, void* params_fp16, void* grads, int grads_fp16, bool zero, float* m, float* v,
                      float lr_eff, const float* lr_dev, float beta1, float beta2, float eps, float loss_scale, rtxn_stream_t stream) {
   RTXN_REQUIRE(loss_scale != 0.0f, "%s: loss_scale = 0", who);
   RTXN_DEVICE_OR_FAIL();
@@ -2012,12 +2016,16 @@ static int adam_impl(const char* who, long n, float* master, void* params_fp16, 
   RTXN_REQUIRE(master && params_fp16 && grads && m && v, "%s: NULL buffer", who);
   const long work = (n + 3) / 4;
   const unsigned blocks = (unsigned)((work + kThreads - 1) / kThreads < 4096 ? (work + kThreads - 1) / kThreads : 4096);
-  if (grads_fp16)
-    adam_kernel<true><<<blocks, kThreads, 0, rtxn::as_stream(stream)>>>(n, master, static_cast<__half*>(params_fp16), grads, m, v, lr_eff,
-                                                                       beta1, beta2, eps, 1.0f / loss_scale, lr_dev);
-  else
-    adam_kernel<false><<<blocks, kThreads, 0, rtxn::as_stream(stream)>>>(n, master, static_cast<__half*>(params_fp16), grads, m, v, lr_eff,
-                                                                        beta1, beta2, eps, 1.0f / loss_scale, lr_dev);
+  hipStream_t st = rtxn::as_stream(stream);
+  __half* p16 = static_cast<__half*>(params_fp16);
+  const float ils = 1.0f / loss_scale;
+  if (grads_fp16) {
+    if (zero) adam_kernel<true, true><<<blocks, kThreads, 0, st>>>(n, master, p16, grads, m, v, lr_eff, beta1, beta2, eps, ils, lr_dev);
+    else adam_kernel<true, false><<<blocks, kThreads, 0, st>>>(n, master, p16, grads, m, v, lr_eff, beta1, beta2, eps, ils, lr_dev);
+  } else {
+    if (zero) adam_kernel<false, true><<<blocks, kThreads, 0, st>>>(n, master, p16, grads, m, v, lr_eff, beta1, beta2, eps, ils, lr_dev);
+    else adam_kernel<false, false><<<blocks, kThreads, 0, st>>>(n, master, p16, grads, m, v, lr_eff, beta1, beta2, eps, ils, lr_dev);
+  }
   RTXN_LAUNCH_CHECK("adam_kernel");
   return RTXN_OK;
 }
@@ -2025,28 +2033,29 @@ static int adam_impl(const char* who, long n, float* master, void* params_fp16, 
 extern "C" int rtxn_adam_step(long n, float* master, void* params_fp16, const float* grads, float* m, float* v, int step,
                               float lr, float beta1, float beta2, float eps, float loss_scale, rtxn_stream_t stream) {
   RTXN_REQUIRE(n >= 0 && step >= 1, "rtxn_adam_step: n = %ld, step = %d", n, step);
-  return adam_impl("rtxn_adam_step", n, master, params_fp16, grads, 0, m, v, adam_lr_eff(lr, beta1, beta2, step), nullptr, beta1, beta2,
-                   eps, loss_scale, stream);
+  return adam_impl("rtxn_adam_step", n, master, params_fp16, const_cast<float*>(grads), 0, false, m, v, adam_lr_eff(lr, beta1, beta2, step),
+                   nullptr, beta1, beta2, eps, loss_scale, stream);
 }
 
 extern "C" int rtxn_adam_step_half_grads(long n, float* master, void* params_fp16, const void* grads_fp16, float* m, float* v,
                                          int step, float lr, float beta1, float beta2, float eps, float loss_scale,
                                          rtxn_stream_t stream) {
   RTXN_REQUIRE(n >= 0 && step >= 1, "rtxn_adam_step_half_grads: n = %ld, step = %d", n, step);
-  return adam_impl("rtxn_adam_step_half_grads", n, master, params_fp16, grads_fp16, 1, m, v, adam_lr_eff(lr, beta1, beta2, step), nullptr,
-                   beta1, beta2, eps, loss_scale, stream);
+  return adam_impl("rtxn_adam_step_half_grads", n, master, params_fp16, const_cast<void*>(grads_fp16), 1, false, m, v,
+                   adam_lr_eff(lr, beta1, beta2, step), nullptr, beta1, beta2, eps, loss_scale, stream);
 }
 
 extern "C" float rtxn_adam_effective_lr(float lr, float beta1, float beta2, int step) {
   return step >= 1 ? adam_lr_eff(lr, beta1, beta2, step) : 0.0f;
 }
 
-extern "C" int rtxn_adam_step_captured(long n, float* master, void* params_fp16, const void* grads, int grads_fp16, float* m,
+extern "C" int rtxn_adam_step_captured(long n, float* master, void* params_fp16, void* grads, int grad_flags, float* m,
                                        float* v, const float* effective_lr, float beta1, float beta2, float eps, float loss_scale,
                                        rtxn_stream_t stream) {
   RTXN_REQUIRE(n >= 0 && effective_lr, "rtxn_adam_step_captured: n = %ld, effective_lr = %p", n, (const void*)effective_lr);
-  return adam_impl("rtxn_adam_step_captured", n, master, params_fp16, grads, grads_fp16, m, v, 0.0f, effective_lr, beta1, beta2, eps,
-                   loss_scale, stream);
+  RTXN_REQUIRE((grad_flags & ~3) == 0, "rtxn_adam_step_captured: grad_flags = %d (RTXN_ADAM_GRADS_FP16 | RTXN_ADAM_ZERO_GRADS)", grad_flags);
+  return adam_impl("rtxn_adam_step_captured", n, master, params_fp16, grads, grad_flags & RTXN_ADAM_GRADS_FP16,
+                   (grad_flags & RTXN_ADAM_ZERO_GRADS) != 0, m, v, 0.0f, effective_lr, beta1, beta2, eps, loss_scale, stream);
 }
 
 // ------------------------------------------------------------------------- live segments

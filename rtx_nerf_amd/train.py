@@ -232,6 +232,7 @@ class Trainer:
         vr = api.VR_NERF if self.mode == "nerf" else api.VR_COMPAT
         P = self._segments(rays_o, rays_d, n)
         S = P * K
+        self._grads_clean = False          # the eager optimizer leaves the gradients in place (the captured one clears them)
         with _Stage(self, "zero_grads"):
             self.dparams.zero_()
             if self.encoding == "hash":
@@ -499,7 +500,9 @@ class Trainer:
         side.wait_stream(torch.cuda.current_stream())
         state = (self.master.clone(), self.params.clone(), self.adam_m.clone(), self.adam_v.clone())
         tstate = (self.table_master.clone(), self.table.clone(), self.table_m.clone(), self.table_v.clone()) if self.encoding == "hash" else None
+        clear_grads = self._clear_grads
         with torch.cuda.stream(side):
+            clear_grads()
             for k in range(len(sets)):
                 self._captured_traverse(k)
             self._captured_gradients(0)
@@ -514,6 +517,7 @@ class Trainer:
                 dst.copy_(src)
         self.net.set_params_training(self.params)
         self._g_step.fill_(self.step_count)
+        clear_grads()
         torch.cuda.synchronize()
         for st in sets:
             st["total_host"][0] = 0        # the warm-up pass is not a step
@@ -557,6 +561,14 @@ class Trainer:
             self._graphs["apply"] = capture(lambda: self._captured_apply(float(world)))
         return self
 
+    def _clear_grads(self):
+        self.dparams.zero_()
+        if self.encoding == "hash":
+            self.dtable.zero_()
+            if self.dtable_h is not None:
+                self.dtable_h.zero_()
+        self._grads_clean = True
+
     def _captured_traverse(self, k):
         st, n, cap = self._g_sets[k], self._g_n, self._g_cap
         kw = dict(grid_res=self.R, rays_o=self.graph_rays_o, rays_d=self.graph_rays_d, width=n, height=1, ray_begin=0, ray_count=n,
@@ -572,13 +584,7 @@ class Trainer:
 
     def _captured_gradients(self, k):
         st, n, cap = self._g_sets[k], self._g_n, self._g_cap
-        self.dparams.zero_()
-        if self.encoding == "hash":
-            if self.hash_fp16:
-                self.dtable[:self.hashed_lo].zero_()
-                self.dtable_h.zero_()
-            else:
-                self.dtable.zero_()
+        # no fills: the captured Adam clears every gradient as it consumes it (zero_grads), capture_step() clears them once
         hash_ = self.encoding == "hash"
         api.train_gradients(self.net, grid=self.hg if hash_ else None, n_dir_freqs=self.hg.n_dir_freqs if hash_ else 0,
                             table=self.table if hash_ else None, start_points=st["start"], end_points=st["end"], seg_view=st["seg_view"],
@@ -597,19 +603,19 @@ class Trainer:
         torch.index_select(self._g_lr_table, 0, self._g_idx, out=self._g_lr)
         lr_mlp, lr_tab = self._g_lr[0, 0:1], self._g_lr[0, 1:2]
         ls = self.loss_scale * grad_divisor
-        api.adam_step_captured(self.master, self.params, self.dparams, self.adam_m, self.adam_v, lr_mlp, loss_scale=ls)
+        api.adam_step_captured(self.master, self.params, self.dparams, self.adam_m, self.adam_v, lr_mlp, loss_scale=ls, zero_grads=True)
         self.net.set_params_training(self.params)
         if self.encoding == "hash":
             lo = self.hashed_lo
             if self.hash_fp16:
                 if lo > 0:
                     api.adam_step_captured(self.table_master[:lo], self.table[:lo], self.dtable[:lo], self.table_m[:lo], self.table_v[:lo],
-                                           lr_tab, eps=1e-15, loss_scale=ls)
+                                           lr_tab, eps=1e-15, loss_scale=ls, zero_grads=True)
                 api.adam_step_captured(self.table_master[lo:], self.table[lo:], self.dtable_h, self.table_m[lo:], self.table_v[lo:],
-                                       lr_tab, eps=1e-15, loss_scale=ls)
+                                       lr_tab, eps=1e-15, loss_scale=ls, zero_grads=True)
             else:
                 api.adam_step_captured(self.table_master, self.table, self.dtable, self.table_m, self.table_v, lr_tab, eps=1e-15,
-                                       loss_scale=ls)
+                                       loss_scale=ls, zero_grads=True)
 
     def _check_truncation(self, k):
         th = self._g_sets[k]["total_host"]
@@ -640,6 +646,8 @@ class Trainer:
         is noticed a call later (truncated_steps)."""
         if getattr(self, "_graphs", None) is None:
             raise RuntimeError("step_captured: call capture_step() first")
+        if not getattr(self, "_grads_clean", False):
+            self._clear_grads()                       # an eager step() ran in between: its gradients are still in the buffers
         if not self._g_prefetch:
             self._check_truncation(0)
             self.step_count += 1
@@ -665,6 +673,8 @@ class Trainer:
         """prefetch only: train on the batch the last step_captured() call submitted; returns its loss (None if there is none)."""
         if not getattr(self, "_g_prefetch", False) or self._g_pending is None:
             return None
+        if not getattr(self, "_grads_clean", False):
+            self._clear_grads()
         k = self._g_pending
         self._check_truncation(k)
         self.step_count += 1

@@ -214,16 +214,21 @@ def test_captured_step_matches_the_eager_step(gpu, encoding, mode, neurons, laye
         assert int(b.total.item()) == P and 0 < P < B * 30
         assert abs(la - lb) <= 5e-4 * abs(la), (i, la, lb)
         if i == 0:
-            # same parameters going in: the gradients agree to the order of the atomics; Adam at step 1 moves every weight
-            # by ~lr * sign(g), so parameters are compared where the gradient is not noise
-            ga, gb = a.dparams.cpu().numpy(), b.dparams.cpu().numpy()
-            assert np.linalg.norm(ga - gb) <= 1e-3 * np.linalg.norm(ga) and np.linalg.norm(ga) > 0
+            # same parameters going in.  The captured optimizer clears every gradient as it consumes it (nothing to compare
+            # there: they must read zero), so the first step is compared through the parameters it produced: Adam at step 1
+            # moves every weight by ~lr * sign(g), which is compared where the gradient is not noise
+            ga = a.dparams.cpu().numpy()
+            assert np.linalg.norm(ga) > 0 and float(b.dparams.abs().max()) == 0.0
             if encoding == "hash":
-                ta, tb = a.table_grad().cpu().numpy(), b.table_grad().cpu().numpy()
-                assert np.linalg.norm(ta - tb) <= 2e-3 * np.linalg.norm(ta) and np.linalg.norm(ta) > 0
+                assert float(b.table_grad().abs().max()) == 0.0
             big = np.abs(ga) > 1e-3 * np.abs(ga).max()
             pa, pb = a.master.cpu().numpy(), b.master.cpu().numpy()
             np.testing.assert_allclose(pa[big], pb[big], rtol=0, atol=2e-4)
+            if encoding == "hash":
+                ta, tb = a.table_master.cpu().numpy(), b.table_master.cpu().numpy()
+                tg = a.table_grad().cpu().numpy()
+                tbig = np.abs(tg) > 1e-2 * np.abs(tg).max()
+                np.testing.assert_allclose(ta[tbig], tb[tbig], rtol=0, atol=2e-3)
     assert a.step_count == b.step_count == 6 and b.truncated_steps == 0
     pa, pb = a.master.cpu().numpy(), b.master.cpu().numpy()
     assert np.linalg.norm(pa - pb) <= 3e-2 * np.linalg.norm(pa)          # six Adam steps at lr 1e-2 amplify gradient noise
