@@ -446,7 +446,7 @@ typedef struct rtxn_train_batch {
   float* dparams;                   /* float[rtxn_mlp_n_params], accumulated into */
   float* dtable;                    /* hash grid: float[n_params], accumulated into */
   void* dtable_hashed_half;         /* hash grid, optional: as rtxn_hashgrid_backward_segments */
-  void* live_ws;                    /* optional (recompute path): rtxn_live_segments_workspace_bytes(capacity); the backward then
+  void* live_ws;                    /* optional: rtxn_live_segments_workspace_bytes(capacity); the backward then
                                        visits only the segments that carry a loss gradient (rtxn_live_segments) */
 } rtxn_train_batch;
 int rtxn_train_gradients(const rtxn_train_batch* batch, rtxn_stream_t stream);
@@ -455,7 +455,7 @@ int rtxn_train_gradients(const rtxn_train_batch* batch, rtxn_stream_t stream);
  * In NeRF training most samples lie behind the first surface: their transmittance, and with it dL/d(radiance), is exactly
  * zero, and so is everything the backward pass would add for them.  rtxn_live_segments lists the 32-sample segments with a
  * non-zero radiance gradient (ascending segment indices + their count, in live_ws); the two _live entry points below are
- * rtxn_mlp_train_backward_recompute / rtxn_hashgrid_backward_segments visiting only those segments.  Same sums, fewer
+ * rtxn_mlp_train_backward_recompute / rtxn_mlp_train_backward / rtxn_hashgrid_backward_segments visiting only those segments.  Same sums, fewer
  * terms: results equal to the unrestricted calls up to the order of fp32 / fp16 atomics.  d(encoding) is written for the
  * listed segments only (no reader of the other columns remains).  No counterpart in the reference (tiny-cuda-nn backpropagates
  * every sample). */
@@ -465,6 +465,11 @@ int rtxn_live_segments(const void* radiance_gradients_half4, long n_segments, lo
 int rtxn_mlp_train_backward_recompute_live(const rtxn_mlp* m, const void* encT, const void* output_half,
                                            const void* dout_half4, long n_samples, const void* live_ws, float* dparams,
                                            void* dencT, rtxn_stream_t stream);
+/* rtxn_mlp_train_backward (the saved-activation path, any built width) over the live segments: the chain visits only
+ * them and writes their dZ compactly, the weight-gradient kernels contract over 32 * count samples. */
+int rtxn_mlp_train_backward_live(const rtxn_mlp* m, const void* encT, const void* output_half, const void* dout_half4,
+                                 long n_samples, void* workspace, const void* live_ws, float* dparams, void* dencT,
+                                 rtxn_stream_t stream);
 int rtxn_hashgrid_backward_segments_live(const rtxn_hashgrid* g, const float* start_points, const float* end_points,
                                          long n_segments, int sample_type, const void* dencT, const void* live_ws,
                                          float* dtable, void* dtable_hashed_half, rtxn_stream_t stream);

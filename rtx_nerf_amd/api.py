@@ -491,7 +491,15 @@ def _net_train_backward_recompute_live(self, encT, output, dout, n, live_ws, dpa
                                                            _stream()), "rtxn_mlp_train_backward_recompute_live")
 
 
+def _net_train_backward_live(self, encT, output, dout, n, workspace, live_ws, dparams, dencT=None):
+    check(_lib.lib().rtxn_mlp_train_backward_live(self._h, _ptr(encT, torch.float16, "encT"), _ptr(output, torch.float16, "output"),
+                                                 _ptr(dout, torch.float16, "dout"), n, _ptr(workspace, torch.float16, "workspace"),
+                                                 _ptr(live_ws, None, "live_ws"), _ptr(dparams, torch.float32, "dparams"),
+                                                 _ptr(dencT, torch.float16, "dencT"), _stream()), "rtxn_mlp_train_backward_live")
+
+
 Network.train_backward_recompute_live = _net_train_backward_recompute_live
+Network.train_backward_live = _net_train_backward_live
 Network.train_workspace = _net_train_workspace
 Network.train_forward = _net_train_forward
 Network.train_backward = _net_train_backward

@@ -456,6 +456,8 @@ struct TrainArgs {
   _Float16* dzL;            // [16][Sp]
   _Float16* dencT;          // [E][Sp] or NULL
   uint8_t* live_tiles;      // [Sp / 256]: backward: 1 where the tile carries a non-zero loss gradient (weight-gradient kernels skip the others)
+  const int* live_list;     // backward: segments that carry a loss gradient (rtxn_live_segments), or NULL.  The chain then visits
+  const int* live_count;    // only those, and dz / dzL are written COMPACT (slot * 32 + sample) for the weight-gradient kernels
 };
 
 // Element (feature row f0 + 4h, sample s) of a feature-major tensor X[feature][Sp]: the address is split into a wave-uniform
@@ -630,20 +632,36 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_bwd_kernel(TrainArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
   a.S = live_samples(a.dc, a.S);
-  if ((long)blockIdx.x * kTile >= a.S) return;
-  const long tile0 = (long)blockIdx.x * kTile + wave * 64;
+  const int live_n = a.live_list ? *a.live_count : 0;
+  if (a.live_list ? (int)blockIdx.x * 8 >= live_n : (long)blockIdx.x * kTile >= a.S) return;
+  const long tile0 = (long)blockIdx.x * kTile + wave * 64;      // also the COMPACT position of the wave's 64 samples (live list)
   const int L = a.n_hidden;
   long off = 0;
-  unsigned lane_off[2];   // see row_elem
+  // lane_off: where the lane's sample sits in the tensors the forward wrote (encT, acts, masks; d(encoding) goes there too);
+  // lane_dst: where its dZ goes -- the same place, or with the live list the compact position slot * 32 + col
+  unsigned lane_off[2], lane_dst[2];   // see row_elem
+  long samp[2];
+  bool ok_s[2];
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct) lane_off[ct] = (unsigned)((tile0 + ct * 32 + col + 4L * h * a.Sp) * 2);
+  for (int ct = 0; ct < 2; ++ct) {
+    long sidx = tile0 + ct * 32 + col;
+    ok_s[ct] = sidx < a.S;
+    lane_dst[ct] = (unsigned)((sidx + 4L * h * a.Sp) * 2);
+    if (a.live_list) {
+      const int slot = (int)blockIdx.x * 8 + wave * 2 + ct;
+      ok_s[ct] = slot < live_n;
+      sidx = (long)(ok_s[ct] ? a.live_list[slot] : 0) * 32 + col;      // slots past the list read segment 0 and add zeros
+    }
+    samp[ct] = sidx;
+    lane_off[ct] = (unsigned)((sidx + 4L * h * a.Sp) * 2);
+  }
 
   // ---- output layer: dZ_out = dout (*) act'(out), one k-step (16 rows) ----
   half8 bo[2];
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct) {
-    const long s = tile0 + ct * 32 + col;
-    const bool ok = s < a.S;
+    const long s = samp[ct];
+    const bool ok = ok_s[ct];
     half8 v;
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.0f;
@@ -670,7 +688,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_bwd_kernel(TrainArgs a) {
     const bool live = __syncthreads_or(any_grad);
     if (a.live_tiles && threadIdx.x == 0) a.live_tiles[blockIdx.x] = live ? 1 : 0;
     if (!live && a.live_tiles) {
-      if (a.dencT) {
+      if (a.dencT && !a.live_list) {
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
           for (int f = 0; f < a.E; f += 8)
@@ -683,7 +701,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_bwd_kernel(TrainArgs a) {
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) *row_elem(a.dzL, perm_feature(0, 0, j), a.Sp, lane_off[ct]) = bo[ct][j];
+    for (int j = 0; j < 8; ++j) *row_elem(a.dzL, perm_feature(0, 0, j), a.Sp, lane_dst[ct]) = bo[ct][j];
   // One accumulator pair at a time: row tile rt of dA_{l} = W^T dZ is masked with relu'(act_l), rounded to fp16 and packed
   // straight into the B fragments of the next (earlier) layer's MFMAs -- the backward chain stays in registers exactly as the
   // forward does, and no full-layer fp32 dA is ever held (the first version kept one: 128 VGPRs at W = 128, 378 spills).
@@ -697,7 +715,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_bwd_kernel(TrainArgs a) {
     if constexpr (!kUseMasks) return;
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
-      const uint2 w = *reinterpret_cast<const uint2*>(a.masks + ((long)l * a.Sp + tile0 + ct * 32 + col) * 2 + h);
+      const uint2 w = *reinterpret_cast<const uint2*>(a.masks + ((long)l * a.Sp + samp[ct]) * 2 + h);
       mk[ct][0] = w.x;
       mk[ct][1] = w.y;
     }
@@ -725,7 +743,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_bwd_kernel(TrainArgs a) {
         const half8 v = pack8<false>(m, s2);
         dst[2 * rt + s2][ct] = v;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) *row_elem(dzl, perm_feature(2 * rt + s2, 0, j), a.Sp, lane_off[ct]) = v[j];
+        for (int j = 0; j < 8; ++j) *row_elem(dzl, perm_feature(2 * rt + s2, 0, j), a.Sp, lane_dst[ct]) = v[j];
       }
     }
   };
@@ -796,7 +814,8 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_bwd_kernel(TrainArgs a) {
     }
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
-      const bool ok = tile0 + ct * 32 + col < a.S;
+      const bool ok = ok_s[ct];
+      if (a.live_list && !ok) continue;                  // a slot past the list has no column of its own to write
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int feat0 = 32 * rt + (e & 3) + 8 * (e >> 2);
@@ -1193,6 +1212,8 @@ struct WgradArgs {
   int lds_path;   // layers with >= 2 tiles are left to wgrad_lds_kernel
   DevCount dc;    // contraction length from the device (see DevCount); Sp stays the row stride
   const uint8_t* live_tiles;   // [Sp / 256] from mlp_bwd_kernel, or NULL: 256-sample tiles with dZ == 0 are not read
+  const int* live_list;        // live segments: dZ is COMPACT (slot * 32 + sample), X sits where the forward wrote it; the
+  const int* live_count;       // contraction runs over 32 * count samples
 };
 
 __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
@@ -1204,10 +1225,18 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
   const long Sp = a.Sp;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int tm = blockIdx.x / L.tiles_n, tn = blockIdx.x % L.tiles_n;
-  const long Send = a.dc.total_segments ? padded_dev(live_samples(a.dc, 0)) : Sp;
+  long Send = a.dc.total_segments ? padded_dev(live_samples(a.dc, 0)) : Sp;
+  if (a.live_list) Send = padded_dev(32L * *a.live_count);        // dZ beyond 32 * count in the last tile: zero rows of mlp_bwd_kernel
   const long s_begin = ((long)blockIdx.y * 4 + wave) * a.chunk;
   const long s_end = s_begin + a.chunk < Send ? s_begin + a.chunk : Send;
   if (s_begin >= Send) return;
+  const int live_n = a.live_list ? *a.live_count : 0;
+  // X position of compact sample position s (a multiple of 16): segments are 32 samples, a 16-sample k-step never straddles one
+  auto x_of = [&](long s) -> long {
+    if (!a.live_list) return s;
+    const int slot = (int)(s >> 5);
+    return (long)(slot < live_n ? a.live_list[slot] : 0) * 32 + (s & 31);
+  };
   floatx16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -1232,8 +1261,9 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
     for (int u = 0; u < U; ++u) {
       a0[u] = *reinterpret_cast<const half8*>(pa0 + s + 16 * u);
       a1[u] = *reinterpret_cast<const half8*>(pa1 + s + 16 * u);
-      b0[u] = *reinterpret_cast<const half8*>(pb0 + s + 16 * u);
-      b1[u] = *reinterpret_cast<const half8*>(pb1 + s + 16 * u);
+      const long xs = x_of(s + 16 * u);
+      b0[u] = *reinterpret_cast<const half8*>(pb0 + xs);
+      b1[u] = *reinterpret_cast<const half8*>(pb1 + xs);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -1275,7 +1305,9 @@ __global__ __launch_bounds__(kThreads) void wgrad_lds_kernel(WgradArgs a) {
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tm = wave >> 1, tn = wave & 1;
-  const long Send = a.dc.total_segments ? padded_dev(live_samples(a.dc, 0)) : Sp;
+  long Send = a.dc.total_segments ? padded_dev(live_samples(a.dc, 0)) : Sp;
+  const int live_n = a.live_list ? *a.live_count : 0;
+  if (a.live_list) Send = padded_dev(32L * live_n);
   const long s_begin = (long)blockIdx.x * a.chunk;
   const long s_end = s_begin + a.chunk < Send ? s_begin + a.chunk : Send;
   if (s_begin >= Send) return;
@@ -1287,9 +1319,17 @@ __global__ __launch_bounds__(kThreads) void wgrad_lds_kernel(WgradArgs a) {
     src[q] = (q < 4 ? dZ : X) + (long)(row < lim ? row : 0) * Sp + 16 * wave + 8 * h;   // rows beyond the layer: row 0, masked at the store
   }
   auto stage = [&](int buf, long s0) {
+    // live list: dZ rows (q < 4) are compact, X rows sit where the forward wrote them -- this wave's k-step is the 16 samples
+    // at compact position s0 + 16 wave, inside ONE segment
+    long x0 = s0;
+    if (a.live_list) {
+      const long sc = s0 + 16 * wave;
+      const int slot = (int)(sc >> 5);
+      x0 = (long)(slot < live_n ? a.live_list[slot] : 0) * 32 + (sc & 31) - 16 * wave;
+    }
 #pragma unroll
     for (int q = 0; q < 8; ++q)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[q] + s0),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[q] + (q < 4 ? s0 : x0)),
                                        (__attribute__((address_space(3))) void*)(wsm + buf * kWgStage + (wave * 8 + q) * 1024), 16, 0, 0);
   };
   floatx16 acc[2][2];
@@ -1655,7 +1695,8 @@ extern "C" int rtxn_mlp_train_forward(const rtxn_mlp* m, const void* encT, long 
 }
 
 static int train_backward_impl(const rtxn_mlp* m, const void* encT, const void* output_half, const void* dout_half4,
-                               long n_samples, void* workspace, float* dparams, void* dencT, DevCount dc, rtxn_stream_t stream) {
+                               long n_samples, void* workspace, float* dparams, void* dencT, DevCount dc, rtxn_stream_t stream,
+                               const int* live_list = nullptr, const int* live_count = nullptr) {
   const int W = m->cfg.n_neurons, L = m->cfg.n_hidden_layers, E = m->enc_padded;
   const long Sp = padded(n_samples);
   _Float16* ws = static_cast<_Float16*>(workspace);
@@ -1674,6 +1715,8 @@ static int train_backward_impl(const rtxn_mlp* m, const void* encT, const void* 
   a.dzL = ws + 2L * L * W * Sp;
   a.masks = reinterpret_cast<unsigned long long*>(ws + (2L * L * W + 16) * Sp);
   a.live_tiles = reinterpret_cast<uint8_t*>(ws + (2L * L * W + 16 + 8L * L) * Sp);
+  a.live_list = live_list;
+  a.live_count = live_count;
   a.out_half = const_cast<_Float16*>(static_cast<const _Float16*>(output_half));
   a.dout = static_cast<const _Float16*>(dout_half4);
   a.dencT = static_cast<_Float16*>(dencT);
@@ -1694,6 +1737,8 @@ static int train_backward_impl(const rtxn_mlp* m, const void* encT, const void* 
   wa.Sp = Sp;
   wa.dc = dc;
   wa.live_tiles = a.live_tiles;
+  wa.live_list = live_list;
+  wa.live_count = live_count;
   wa.chunk = 1024;
   const unsigned kblocks = (unsigned)((Sp + 4 * wa.chunk - 1) / (4 * wa.chunk));
   long poff = 0;
@@ -2109,6 +2154,20 @@ extern "C" int rtxn_mlp_train_backward_recompute_live(const rtxn_mlp* m, const v
                                        live_list_of(live_ws), live_count_of(live_ws));
 }
 
+extern "C" int rtxn_mlp_train_backward_live(const rtxn_mlp* m, const void* encT, const void* output_half, const void* dout_half4,
+                                            long n_samples, void* workspace, const void* live_ws, float* dparams, void* dencT,
+                                            rtxn_stream_t stream) {
+  int rc = check_train(m, "rtxn_mlp_train_backward_live");
+  if (rc != RTXN_OK) return rc;
+  RTXN_REQUIRE(n_samples >= 0 && n_samples <= kMaxTrainSamples && n_samples % 32 == 0,
+               "rtxn_mlp_train_backward_live: n_samples = %ld must be whole segments in [0, %ld]", n_samples, kMaxTrainSamples);
+  RTXN_DEVICE_OR_FAIL();
+  if (n_samples == 0) return RTXN_OK;
+  RTXN_REQUIRE(encT && output_half && dout_half4 && workspace && dparams && live_ws, "rtxn_mlp_train_backward_live: NULL buffer");
+  return train_backward_impl(m, encT, output_half, dout_half4, n_samples, workspace, dparams, dencT, DevCount{nullptr, 0}, stream,
+                             live_list_of(live_ws), live_count_of(live_ws));
+}
+
 extern "C" int rtxn_hashgrid_backward_segments_live(const rtxn_hashgrid* g, const float* start_points, const float* end_points,
                                                     long n_segments, int sample_type, const void* dencT, const void* live_ws,
                                                     float* dtable, void* dtable_hashed_half, rtxn_stream_t stream) {
@@ -2179,7 +2238,7 @@ extern "C" int rtxn_train_gradients(const rtxn_train_batch* b, rtxn_stream_t str
     if (rc != RTXN_OK) return rc;
   }
   // network->backward (main.cu:781); with live_ws only over the segments that carry a loss gradient
-  const bool use_live = b->live_ws != nullptr && recompute;
+  const bool use_live = b->live_ws != nullptr;
   if (use_live) {
     RTXN_REQUIRE(((uintptr_t)b->live_ws & 15) == 0, "rtxn_train_gradients: live_ws not 16-byte aligned");
     rc = live_segments_impl(b->radiance_gradients, b->segment_capacity, b->segment_capacity, b->live_ws, dc, stream);
@@ -2189,7 +2248,7 @@ extern "C" int rtxn_train_gradients(const rtxn_train_batch* b, rtxn_stream_t str
   const int* lc = use_live ? live_count_of(b->live_ws) : nullptr;
   rc = recompute ? train_backward_recompute_impl(m, b->encT, b->output_half, b->radiance_gradients, cap_samples, b->dparams, b->dencT, dc, stream, ll, lc)
                  : train_backward_impl(m, b->encT, b->output_half, b->radiance_gradients, cap_samples, b->workspace, b->dparams,
-                                       hash ? b->dencT : nullptr, dc, stream);
+                                       hash ? b->dencT : nullptr, dc, stream, ll, lc);
   if (rc != RTXN_OK) return rc;
   if (hash) {
     const SampleSrc bsrc{nullptr, b->start_points, b->end_points, nullptr, b->sample_type == RTXN_SAMPLING_MIDPOINT_WORLD};

@@ -109,9 +109,9 @@ class Trainer:
         # "nerf" mode: compositor forward + L2 + compositor backward as one launch (RTXN_TRAIN_FUSE_COMPOSITOR=0: three)
         self.fuse_compositor = os.environ.get("RTXN_TRAIN_FUSE_COMPOSITOR", "1") != "0"
         # The backward visits only the segments that carry a loss gradient (librtxn: rtxn_live_segments; most of a NeRF batch
-        # lies behind the first surface, where dL/d(radiance) is exactly 0).  Needs the recompute path (a column tile of its
-        # kernel is one segment) and the folded sampler.  RTXN_TRAIN_LIVE_SEGMENTS=0: every segment.
-        self.live_segments = (self.recompute and self.fold_sampler and os.environ.get("RTXN_TRAIN_LIVE_SEGMENTS", "1") != "0")
+        # lies behind the first surface, where dL/d(radiance) is exactly 0).  A column tile of the backward kernels is one
+        # segment, so a block tile can be any eight of them.  Needs the folded sampler.  RTXN_TRAIN_LIVE_SEGMENTS=0: every segment.
+        self.live_segments = self.fold_sampler and os.environ.get("RTXN_TRAIN_LIVE_SEGMENTS", "1") != "0"
         # ---- per-step buffers at capacity ---------------------------------------------------------
         B = batch_rays
         self.max_segments = int(max_segments) if max_segments else 64 * B
@@ -264,8 +264,10 @@ class Trainer:
             with _Stage(self, "live_segments"):
                 api.live_segments(self.dout, P, self.max_segments, self.live_ws)
         with _Stage(self, "mlp_bwd+wgrad"):
-            if self.live_segments:
+            if self.live_segments and self.recompute:
                 self.net.train_backward_recompute_live(self.encT, self.out, self.dout, S, self.live_ws, self.dparams, self.dencT)
+            elif self.live_segments:
+                self.net.train_backward_live(self.encT, self.out, self.dout, S, self.ws, self.live_ws, self.dparams, self.dencT)
             elif self.recompute:
                 self.net.train_backward_recompute(self.encT, self.out, self.dout, S, self.dparams, self.dencT)
             else:

@@ -420,3 +420,46 @@ def test_live_segment_backward_equals_the_full_backward(gpu):
     dp0 = torch.zeros(net.n_params(), device="cuda")
     net.train_backward_recompute_live(encT, out, torch.zeros_like(dout_d), S, ws, dp0, de_live)
     assert float(dp0.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("W,L", [(128, 3), (64, 2)])
+def test_live_segment_backward_of_the_saved_activation_path(gpu, W, L):
+    """rtxn_mlp_train_backward_live (dgrad chain over the live segments, dZ written compactly, weight-gradient kernels
+    contracting over the list) against rtxn_mlp_train_backward on the same saved activations: same weight gradients to fp32
+    atomic order, identical d(encoding) on the listed segments.  Segment counts chosen so that the list ends inside a
+    256-sample tile and inside a weight-gradient chunk."""
+    torch = gpu
+    from rtx_nerf_amd import api
+    rng = np.random.default_rng(W + L)
+    P, K, E = 330, 32, 48
+    S = P * K
+    net = api.Network(n_neurons=W, n_hidden_layers=L, n_encoded_features=E)
+    net.set_params(_dev(torch, scenes.xavier_params_fp16(W, L, E, seed=9)))
+    Sp = api.padded_samples(S)
+    encT = torch.zeros((E, Sp), dtype=torch.float16, device="cuda")
+    encT[:, :S] = _dev(torch, rng.uniform(-1, 1, (E, S)).astype(np.float16))
+    ws = net.train_workspace(S)
+    out = torch.zeros((S, 16), dtype=torch.float16, device="cuda")
+    net.train_forward(encT, S, ws, out, None)
+    live = np.zeros(P, bool)
+    live[rng.choice(P, 75, replace=False)] = True
+    live[[0, P - 1]] = True
+    dout = np.zeros((P, K, 4), np.float16)
+    dout[live] = (rng.standard_normal((int(live.sum()), K, 4)) * 0.05).astype(np.float16)
+    dout_d = _dev(torch, dout.reshape(S, 4))
+    lws = api.live_segments_workspace(P)
+    api.live_segments(dout_d, P, P, lws)
+    assert int(lws[0].item()) == int(live.sum())
+    dp_full = torch.zeros(net.n_params(), device="cuda")
+    de_full = torch.full((E, Sp), 7.0, dtype=torch.float16, device="cuda")
+    ws_full = ws.clone()
+    net.train_backward(encT, out, dout_d, S, ws_full, dp_full, de_full)
+    dp_live = torch.zeros(net.n_params(), device="cuda")
+    de_live = torch.full((E, Sp), 7.0, dtype=torch.float16, device="cuda")
+    ws_live = ws.clone()
+    net.train_backward_live(encT, out, dout_d, S, ws_live, lws, dp_live, de_live)
+    assert float(dp_full.norm()) > 0 and float((dp_full - dp_live).norm()) <= 1e-5 * float(dp_full.norm())
+    cols = np.repeat(live, K)
+    a, b = de_full.cpu().numpy()[:, :S], de_live.cpu().numpy()[:, :S]
+    np.testing.assert_array_equal(a[:, cols], b[:, cols])
+    assert np.all(b[:, ~cols] == 7.0)
