@@ -55,7 +55,7 @@ timeit(lambda: api.launch_volrender_backward_cuda(None, tr.loss_grads, tr.radian
 timeit(lambda: tr.loss.zero_(), name="loss.zero_ (launch floor)")
 
 st = tr._stype()
-timeit(lambda: tr.hg.backward_segments(tr.start, tr.end, P, st, tr.dencT, tr.dtable, tr.dtable_h), name="hash backward (2 launches; RTXN_HASH_BWD_FORK=%s)" % os.environ.get("RTXN_HASH_BWD_FORK", "1"))
+timeit(lambda: tr.hg.backward_segments(tr.start, tr.end, P, st, tr.dencT, tr.dtable, tr.dtable_h), name="hash backward (2 launches)")
 timeit(lambda: tr.hg.encode_segments(tr.table, tr.start, tr.end, tr.seg_view, P, st, tr.encT, tr.t_vals, 300.0), name="hash encode")
 timeit(lambda: tr.net.train_forward_outputs(tr.encT, S, tr.out, tr.radiance), name="mlp fwd outputs")
 timeit(lambda: tr.net.train_backward_recompute(tr.encT, tr.out, tr.dout, S, tr.dparams, tr.dencT), name="fused64 backward")
