@@ -299,3 +299,32 @@ def test_captured_step_truncates_on_the_device_and_reports_it(gpu):
         tr.step_captured()
     assert tr.truncated_steps == 1 and any("truncated" in str(x.message) for x in w)
     assert torch.equal(tr.start[cap:], guard[cap:])        # nothing stored past the launch capacity
+
+
+def test_captured_step_on_a_batch_that_misses_the_grid(gpu):
+    """Every ray misses the occupied cells: the device-side segment count is 0, every kernel of the captured step must leave at
+    once (no tile, no live segment, no atomics), the loss is the mean squared target, and Adam on an all-zero gradient with
+    zero moments leaves the parameters where they were.  Then a normal batch trains as usual (nothing was left in a bad state)."""
+    import numpy as np
+    torch = gpu
+    from rtx_nerf_amd import scenes
+    from rtx_nerf_amd.train import camera_rays
+    tr = _small_trainer(torch, "hash", "nerf", 64, 4)
+    B = 900
+    tr.capture_step(B, launch_segments=B * 20)
+    p0, t0 = tr.master.clone(), tr.table_master.clone()
+    tr.graph_rays_o.copy_(torch.tensor([5.0, 5.0, 5.0], device="cuda").repeat(B, 1))
+    tr.graph_rays_d.copy_(torch.tensor([0.0, 0.0, 1.0], device="cuda").repeat(B, 1))      # pointing away from [-1,1]^3
+    tgt = torch.full((B, 3), 0.5, device="cuda")
+    tr.graph_targets.copy_(tgt)
+    loss = float(tr.step_captured().item())
+    torch.cuda.synchronize()
+    assert int(tr.total.item()) == 0 and abs(loss - 0.25) < 1e-6
+    assert torch.equal(tr.master, p0) and torch.equal(tr.table_master, t0)
+    assert int(tr.live_ws[0].item()) == 0
+    o, d = camera_rays(scenes.pose_spherical(40.0, -30.0, origin_scale=10.0), scenes.lego_focal_length(True), 30, 30)
+    tr.graph_rays_o.copy_(o); tr.graph_rays_d.copy_(d)
+    l1 = float(tr.step_captured().item())
+    for _ in range(20):
+        l2 = float(tr.step_captured().item())
+    assert int(tr.total.item()) > 0 and np.isfinite(l2) and l2 < l1 and not torch.equal(tr.master, p0)
