@@ -509,21 +509,28 @@ __global__ __launch_bounds__(256) void volrender_l2_fused_multi_kernel(const flo
     ar = wave_sum(ar);
     ag = wave_sum(ag);
     ab = wave_sum(ab);
-    const float e0 = ar - target[3 * (long)ray], e1 = ag - target[3 * (long)ray + 1], e2 = ab - target[3 * (long)ray + 2];
-    const __half h0 = __float2half(loss_scale * 2.0f * e0 * inv_n), h1 = __float2half(loss_scale * 2.0f * e1 * inv_n),
-                 h2 = __float2half(loss_scale * 2.0f * e2 * inv_n);
-    const float g0 = __half2float(h0), g1 = __half2float(h1), g2 = __half2float(h2);
-    if (lane == 0) {
-      pixels[3 * (long)ray] = ar;
-      pixels[3 * (long)ray + 1] = ag;
-      pixels[3 * (long)ray + 2] = ab;
-      if (loss_gradients) {
-        loss_gradients[3 * (long)ray] = h0;
-        loss_gradients[3 * (long)ray + 1] = h1;
-        loss_gradients[3 * (long)ray + 2] = h2;
+    float g0, g1, g2;
+    if (target) {
+      const float e0 = ar - target[3 * (long)ray], e1 = ag - target[3 * (long)ray + 1], e2 = ab - target[3 * (long)ray + 2];
+      const __half h0 = __float2half(loss_scale * 2.0f * e0 * inv_n), h1 = __float2half(loss_scale * 2.0f * e1 * inv_n),
+                   h2 = __float2half(loss_scale * 2.0f * e2 * inv_n);
+      g0 = __half2float(h0); g1 = __half2float(h1); g2 = __half2float(h2);
+      if (lane == 0) {
+        pixels[3 * (long)ray] = ar;
+        pixels[3 * (long)ray + 1] = ag;
+        pixels[3 * (long)ray + 2] = ab;
+        if (loss_gradients) {
+          loss_gradients[3 * (long)ray] = h0;
+          loss_gradients[3 * (long)ray + 1] = h1;
+          loss_gradients[3 * (long)ray + 2] = h2;
+        }
       }
+      loss_part = (e0 * e0 + e1 * e1 + e2 * e2) * inv_n;
+    } else {      // rtxn_volrender_bwd: the pixel gradients are given (launch_volrender_backward_cuda's loss_gradients)
+      g0 = __half2float(loss_gradients[3 * (long)ray]);
+      g1 = __half2float(loss_gradients[3 * (long)ray + 1]);
+      g2 = __half2float(loss_gradients[3 * (long)ray + 2]);
     }
-    loss_part = (e0 * e0 + e1 * e1 + e2 * e2) * inv_n;
     const float S = g0 * ar + g1 * ag + g2 * ab;
     // sweep 2: per-sample gradients (the radiance is re-read: cache hits)
     T_carry = 0.0f;
@@ -707,6 +714,10 @@ extern "C" int rtxn_volrender_bwd(const float* loss_values, const void* loss_gra
   if (mode == RTXN_VR_COMPAT)
     volrender_bwd_compat_kernel<<<grid, block, 0, s>>>(lg, rad, t_hit, num_hits, indices, batch_size,
                                                        num_samples_per_hit, out);
+  else if (num_samples_per_hit % 2 == 0 && ((uintptr_t)t_hit & 7) == 0 && ((uintptr_t)radiance_gradients & 15) == 0)
+    // the training compositor with the pixel gradients given instead of formed from a target: 512 samples per step, two per lane
+    volrender_l2_fused_multi_kernel<4><<<grid, block, 0, s>>>(rad, t_hit, num_hits, indices, batch_size, num_samples_per_hit, nullptr, 0.0f,
+                                                              nullptr, const_cast<__half*>(lg), nullptr, out);
   else
     volrender_bwd_nerf_kernel<<<grid, block, 0, s>>>(lg, rad, t_hit, num_hits, indices, batch_size,
                                                      num_samples_per_hit, out);
