@@ -51,7 +51,9 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ s
                                                      float* __restrict__ t_vals, float* __restrict__ samples,
                                                      int batch_size, const int* __restrict__ num_hits,
                                                      const int* __restrict__ indices) {
+  __shared__ __attribute__((aligned(16))) float strips[4][64 * 5];
   const int lane = threadIdx.x & 63;
+  float* strip = strips[threadIdx.x >> 6];
   const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (ray >= batch_size) return;  // reference reads indices[x] before its guard (sampler.cu:32-37); we do not
   const int start_index = indices[ray];
@@ -86,39 +88,29 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ s
       }
     }
     if ((lane >> 5) < nseg) t_vals[(seg0 + (lane >> 5)) * K + i] = tv;
-    // the two segments' origin and direction: wave-uniform addresses, one transaction each
-    float og[2][3], dr[2][3];
-#pragma unroll
-    for (int sg = 0; sg < 2; ++sg) {
-      const long g = (seg0 + (sg < nseg ? sg : 0)) * 3;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        og[sg][c] = start_points[g + c];
-        dr[sg][c] = end_points[g + c] - og[sg][c];
-      }
+    // This lane's own sample (segment j0 + lane / 32, i): three multiply-adds from its segment's start and direction (two
+    // distinct addresses per load instruction), written as 5 floats into the wave's LDS strip -- stride 5 words: conflict-free.
+    // The strip is then read back linearly as float4 and stored: the 2-segment run is 320 contiguous floats = 80 float4, lane
+    // l stores float4 l (1 KiB per store instruction), lanes 0..15 a second one.  (The first version had every lane compute
+    // the four floats of ITS float4 -- a division by 5, selects between the two segments and a shuffle of t per value,
+    // ~100 VALU instructions per step -- and ran at 0.42 of the HBM rate with the stores waiting on the arithmetic.)
+    {
+      const long g = (seg0 + min(lane >> 5, nseg - 1)) * 3;
+      const float ox = start_points[g], oy = start_points[g + 1], oz = start_points[g + 2];
+      float* my = strip + lane * 5;
+      my[0] = fmaf(t, end_points[g] - ox, ox);
+      my[1] = fmaf(t, end_points[g + 1] - oy, oy);
+      my[2] = fmaf(t, end_points[g + 2] - oz, oz);
+      my[3] = theta;
+      my[4] = phi;
     }
-    // The 2-segment run is 320 contiguous floats = 80 float4: lane l stores float4 l (1 KiB per store instruction
-    // instead of 256 B), lanes 0..15 a second one.  Flat float f is component f % 5 of sample f / 5.
+    __builtin_amdgcn_wave_barrier();        // one wave, in-order LDS queue: the reads below see the writes above
     float4* out = reinterpret_cast<float4*>(samples + seg0 * (K * 5));
     const int nq = nseg * (K * 5 / 4);
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int q = lane + 64 * k;
-      float v[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int f = 4 * q + e;
-        const int sm = f / 5, comp = f - sm * 5, sg = (sm >> 5) & 1;
-        float ts;
-        if (TYPE == RTXN_SAMPLING_REGULAR) ts = (float)(sm & (K - 1)) * inc;
-        else if (TYPE == RTXN_SAMPLING_MIDPOINT_WORLD) ts = ((float)(sm & (K - 1)) + 0.5f) * inc;
-        else ts = __shfl(t, sm & 63, 64);
-        const float o3 = comp == 0 ? (sg ? og[1][0] : og[0][0]) : comp == 1 ? (sg ? og[1][1] : og[0][1]) : (sg ? og[1][2] : og[0][2]);
-        const float d3 = comp == 0 ? (sg ? dr[1][0] : dr[0][0]) : comp == 1 ? (sg ? dr[1][1] : dr[0][1]) : (sg ? dr[1][2] : dr[0][2]);
-        v[e] = comp < 3 ? fmaf(ts, d3, o3) : (comp == 3 ? theta : phi);
-      }
-      if (q < nq) out[q] = make_float4(v[0], v[1], v[2], v[3]);
-    }
+    const float4* lin = reinterpret_cast<const float4*>(strip);
+    if (lane < nq) out[lane] = lin[lane];
+    if (lane + 64 < nq) out[lane + 64] = lin[lane + 64];
+    __builtin_amdgcn_wave_barrier();        // the next step rewrites the strip
   }
 }
 
