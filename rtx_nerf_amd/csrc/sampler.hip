@@ -61,6 +61,12 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ s
   const float theta = view_dirs[2 * ray], phi = view_dirs[2 * ray + 1];
   const float inc = 1.0f / K;
   const int i = lane & (K - 1);  // sample within segment
+  static_assert(K == 32, "the random modes' draw numbering below assumes two 32-sample segments per 64-lane step");
+  uint32_t lane_pow = 1, step_pow = 1, pow64 = 1;
+  if (TYPE == RTXN_SAMPLING_STRATIFIED_JITTERING || TYPE == RTXN_SAMPLING_UNIFORM) {
+    lane_pow = minstd_pow((uint32_t)lane + 1u);
+    pow64 = minstd_pow(64u);
+  }
   for (int j0 = 0; j0 < n_hits; j0 += 2) {
     const int nseg = min(2, n_hits - j0);
     const long seg0 = (long)start_index + j0;
@@ -76,8 +82,11 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ s
                   dz = end_points[g + 2] - start_points[g + 2];
       tv = sqrtf(fmaf(dz, dz, fmaf(dx, dx, dy * dy))) * inc;
     } else {
-      uint32_t draw = (uint32_t)(j0 + (lane >> 5)) * K + i + 1;
-      uint32_t x = minstd_pow(draw);  // seed 1
+      // draw number (j0 + lane / 32) * K + i + 1 = 64 (j0 / 2) + lane + 1: 48271^draw = 48271^(lane + 1) (per lane, formed once)
+      // times (48271^64)^(j0 / 2) (per wave, one modular multiply per step) -- the same residues as square-and-multiply per
+      // sample, which took ~22 modular multiplies each
+      const uint32_t x = mulmod(lane_pow, step_pow);  // seed 1
+      step_pow = mulmod(step_pow, pow64);
       if (TYPE == RTXN_SAMPLING_UNIFORM) {
         t = thrust_uniform(x, 0.0f, 1.0f);
         tv = 0.0f;
