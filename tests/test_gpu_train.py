@@ -92,8 +92,11 @@ def test_hashgrid_encode_and_backward(gpu, oracle, levels, feat, log2, base, sca
         assert np.all(got32[lo:] == 0)
         assert np.abs(got32[:lo] - want_g[:lo]).max() < 1e-4 * max(1.0, np.abs(want_g).max())
         if lo < hg.n_params():
-            # fp16 accumulation: each of an entry's few contributions rounded to 11 bits
-            assert np.abs(got16 - want_g[lo:]).max() < 3e-3 * max(1.0, np.abs(want_g[lo:]).max())
+            # fp16 accumulation in whatever order the atomics arrive: a running sum of n contributions carries up to ~n/2
+            # half-ulps of its largest partial sum (n ~ 25 per entry in the smallest table here); measured maxima 2e-3 ...
+            # 3.5e-3 of the largest entry from run to run -- the bound below is that order-dependent worst case, the 2-norm
+            # bound after it is the tight one
+            assert np.abs(got16 - want_g[lo:]).max() < 1e-2 * max(1.0, np.abs(want_g[lo:]).max())
             assert np.linalg.norm(got16 - want_g[lo:]) < 1e-3 * np.linalg.norm(want_g[lo:])
 
 
@@ -302,7 +305,7 @@ def test_sampler_folded_into_encoders_and_scatter(gpu, oracle, stype):
         hg.backward_segments(sp_d, ep_d, P, stype, denc, a32, a16)
         if half:
             hg.backward_mixed(samples, denc, b32, b16)
-            assert float((a16.float() - b16.float()).abs().max()) <= 4e-3 * float(b16.float().abs().max())
+            assert float((a16.float() - b16.float()).abs().max()) <= 1e-2 * float(b16.float().abs().max())   # two fp16 atomic orders
         else:
             hg.backward(samples, denc, b32)
         assert float((a32 - b32).abs().max()) <= 1e-5 * float(b32.abs().max()) and float(b32.abs().max()) > 0
@@ -413,7 +416,8 @@ def test_live_segment_backward_equals_the_full_backward(gpu):
     np.testing.assert_array_equal(a[:, cols], b[:, cols])
     assert np.all(b[:, ~cols] == 7.0) and np.all(a[:, ~cols] == 0.0)
     assert float((dt_full - dt_live).abs().max()) <= 1e-5 * float(dt_full.abs().max()) and float(dt_full.abs().max()) > 0
-    assert float((dh_full.float() - dh_live.float()).abs().max()) <= 4e-3 * float(dh_full.float().abs().max())
+    assert float((dh_full.float() - dh_live.float()).abs().max()) <= 1e-2 * float(dh_full.float().abs().max())   # two fp16 atomic orders
+    assert float((dh_full.float() - dh_live.float()).norm()) <= 2e-3 * float(dh_full.float().norm())
     # nothing live: count 0, gradients untouched
     api.live_segments(torch.zeros_like(dout_d), P, cap, ws)
     assert int(ws[0].item()) == 0

@@ -99,7 +99,8 @@ def test_config3_training_step_matches_oracle_chain(gpu, oracle):
     dt = O.hg_backward(ocfg, samples, denc_g)
     got_dt = tr.table_grad().cpu().numpy()
     # hashed levels are accumulated in fp16 (packed atomics): 11-bit contributions
-    assert np.abs(got_dt - dt).max() < (3e-3 if tr.hash_fp16 else 1e-3) * max(1e-6, np.abs(dt).max())
+    assert np.abs(got_dt - dt).max() < (1e-2 if tr.hash_fp16 else 1e-3) * max(1e-6, np.abs(dt).max())   # fp16 atomics: order-dependent
+    assert np.linalg.norm(got_dt - dt) < (2e-3 if tr.hash_fp16 else 1e-3) * np.linalg.norm(dt)
     # Adam from the GPU's gradients reproduces the GPU's new parameters
     m, v = np.zeros_like(master0), np.zeros_like(master0)
     O.adam_step(master0, got_dp, m, v, 1, lr=1e-2, loss_scale=ls)
