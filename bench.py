@@ -21,9 +21,11 @@ of every stage (--serial times the one-stream form).
 
 At N = 1 the same JSON line also carries two more records measured in the same process after the headline loop
 (BASELINE.json configs[2] and configs[4] at full size; --no-extras skips them):
-  "train_config3": one optimisation step of 4096 rays, hash grid (L=16, F=2, T=2^19) + 4x64 MLP, 128^3 grid, with the
-                   per-stage HIP-event split and the hash gather / scatter kernels against the HBM roofline;
-  "config5":       the 1008x756 forward-facing frame, 256^3 sparse grid, 8x256 MLP, with mlp_fwd256_kernel against the
+  "train_config3": one optimisation step of 4096 rays, hash grid (L=16, F=2, T=2^19) + 4x64 MLP, 128^3 grid: timed as one
+                   hipGraph per step (Trainer.capture_step: device-side segment count, traversal one batch ahead) with the
+                   host-segment-count form beside it (ms_per_step_host_count), the per-stage HIP-event split and the hash
+                   gather / scatter kernels against the HBM roofline;
+  "config5":       the 1008x756 forward-facing frame, 256^3 sparse grid, 8x256 MLP, with mlp_fwd256x16_kernel against the
                    MFMA roofline.
 The headline (metric/value/roofline/cpu_baseline) stays configs[1].
 
