@@ -25,6 +25,8 @@ ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--encoding", default="hash")
 ap.add_argument("--empty-odd", action="store_true", help="every odd ray of the global batch (= all of rank 1's share in a 2-rank run) "
                 "points away from the grid: that rank has NO samples and must still take part in every collective and Adam step")
+ap.add_argument("--captured", action="store_true", help="Trainer.capture_step / step_captured: gradients and optimizer as two hipGraphs "
+                "with the all-reduces between them (the gradients of step 0 are not saved: the captured Adam clears them)")
 a = ap.parse_args()
 rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 rehearse = os.environ.get("RTXN_REHEARSE_ON_ONE_GPU") == "1"
@@ -49,6 +51,14 @@ for it in range(a.steps):
     if a.empty_odd:
         odd = (torch.arange(mine.numel(), device="cuda") * world + rank) % 2 == 1   # position in the GLOBAL batch
         dm[odd] = -dm[odd]
+    if a.captured:
+        if it == 0:
+            tr.capture_step(mine.numel())
+        tr.graph_rays_o.copy_(o[mine]); tr.graph_rays_d.copy_(dm); tr.graph_targets.copy_(tgt[mine])
+        tr.step_captured()
+        if it == 0:
+            g0 = np.zeros(tr.dparams.numel() + (tr.dtable.numel() if a.encoding == "hash" else 0), np.float32)
+        continue
     tr.step(o[mine].contiguous(), dm, tgt[mine].contiguous())
     if it == 0:   # gradients of the first step (summed over ranks -> mean), before Adam's normalisation amplifies noise
         g0 = torch.cat([tr.dparams, tr.table_grad() if a.encoding == "hash" else tr.dparams[:0]]).cpu().numpy() / world
