@@ -120,7 +120,7 @@ typedef struct rtxn_trace_params {
                                      * empty-space hierarchy (needs occupancy_coarse, R % 16 == 0) */
   int* num_stored;           /* int[ray_count] or NULL: segments actually WRITTEN for the ray (< num_hits when
                               * intersection_arr_size / segment_capacity cut it off): the count downstream stages may read */
-  int sub_rays;              /* RTXN_TRACE_DDA only; 0 or 1: one thread walks a ray.  2, 4, 8 or 16: that many adjacent lanes walk
+  int sub_rays;              /* RTXN_TRACE_DDA only; 0 or 1: one thread walks a ray.  2, 4, ... 64 (a power of two): that many adjacent lanes walk
                               * consecutive pieces of the ray's parameter range (same segments, same order, bit for bit) -- for
                               * small batches, where the launch takes as long as the longest ray's walk */
   int* sub_hits;             /* int[ray_count * sub_rays] scratch, required when sub_rays > 1: written by the counting pass,

@@ -87,14 +87,19 @@ def trace_grid(look_at=None, focal_length=1.0, aspect_ratio=1.0, width=0, height
 def auto_sub_rays(n_rays):
     """Lanes per ray (rtxn_trace_params.sub_rays) for a launch of n_rays: measured on MI355X (tools/trace_bench.py), the
     smaller the launch the more the longest ray's walk dominates it -- 640 k rays: 2 (0.20 -> 0.15 ms), 80 k: 8 (0.18 ->
-    0.07 ms), a 4096-ray training batch: 16."""
+    0.07 ms), 16 k rays: 16, a 4096-ray training batch: 32."""
+    import os
+    if os.environ.get("RTXN_SUB_RAYS"):          # experiments (tools/trace_bench.py, tools/probe)
+        return int(os.environ["RTXN_SUB_RAYS"])
     if n_rays >= 300_000:
         return 2
     if n_rays >= 120_000:
         return 4
     if n_rays >= 30_000:
         return 8
-    return 16
+    if n_rays >= 12_000:
+        return 16
+    return 32          # a 4096-ray training batch: count + scan + write 81 -> 67 us; 64 lanes per ray: no further gain
 
 
 def build_occupancy_mip(occupancy, grid_res):

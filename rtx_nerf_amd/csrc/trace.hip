@@ -511,8 +511,8 @@ extern "C" int rtxn_trace_grid(const rtxn_trace_params* p, rtxn_stream_t stream)
   RTXN_REQUIRE(p->num_hits != nullptr, "rtxn_trace_grid: num_hits is NULL");
   hipStream_t s = rtxn::as_stream(stream);
   const int Q = p->mode == RTXN_TRACE_DDA && p->sub_rays > 1 ? p->sub_rays : 1;
-  RTXN_REQUIRE(p->sub_rays >= 0 && (Q == 1 || Q == 2 || Q == 4 || Q == 8 || Q == 16) && (p->sub_rays <= 1 || p->mode == RTXN_TRACE_DDA),
-               "rtxn_trace_grid: sub_rays = %d must be 0, 1, 2, 4, 8 or 16 (RTXN_TRACE_DDA only)", p->sub_rays);
+  RTXN_REQUIRE(p->sub_rays >= 0 && Q >= 1 && Q <= 64 && (Q & (Q - 1)) == 0 && (p->sub_rays <= 1 || p->mode == RTXN_TRACE_DDA),
+               "rtxn_trace_grid: sub_rays = %d must be 0 or a power of two up to 64 (RTXN_TRACE_DDA only)", p->sub_rays);
   RTXN_REQUIRE(Q == 1 || p->sub_hits != nullptr, "rtxn_trace_grid: sub_rays = %d needs the sub_hits scratch", p->sub_rays);
   dim3 grid((unsigned)(((size_t)p->ray_count * Q + 255) / 256)), block(256);
   const TraceLds tl = trace_lds(*p);

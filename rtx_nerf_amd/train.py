@@ -123,8 +123,9 @@ class Trainer:
         self.truncated_steps = 0
         self.total = torch.zeros(1, dtype=torch.int32, device=d)
         # a batch is a small launch: several lanes walk each ray (bit-identical segments, shorter critical path)
-        self.sub_rays = api.auto_sub_rays(B)
-        self.sub_hits = torch.zeros(B * self.sub_rays, dtype=torch.int32, device=d)
+        self.sub_rays = api.auto_sub_rays(B)              # for a full batch_rays launch; smaller launches take more lanes per ray
+        self.sub_hits = torch.zeros(max(api.auto_sub_rays(n) * n for n in {min(B, t) for t in (11_999, 29_999, 119_999, 299_999, B)}),
+                                    dtype=torch.int32, device=d)           # the largest lanes x rays of any launch of <= B rays
         self.scan_ws = torch.empty((api._lib.lib().rtxn_scan_workspace_bytes(B) + 3) // 4, dtype=torch.int32, device=d)
         self.start = torch.empty((M, 3), device=d)
         self.end = torch.empty((M, 3), device=d)
@@ -147,7 +148,7 @@ class Trainer:
     def _segments(self, rays_o, rays_d, n):
         kw = dict(grid_res=self.R, rays_o=rays_o, rays_d=rays_d, width=n, height=1, ray_begin=0, ray_count=n,
                   occupancy=self.occ, occupancy_coarse=self.coarse, occupancy_bricks=self.bricks, occupancy_super=self.super_mip, mode=api.TRACE_DDA,
-                  viewing_direction=self.view_dirs, num_hits=self.num_hits, sub_rays=self.sub_rays, sub_hits=self.sub_hits)
+                  viewing_direction=self.view_dirs, num_hits=self.num_hits, sub_rays=api.auto_sub_rays(n), sub_hits=self.sub_hits)
         with _Stage(self, "trace_count"):
             api.trace_grid(None, **kw)
         with _Stage(self, "scan"):
@@ -575,7 +576,7 @@ class Trainer:
         st, n, cap = self._g_sets[k], self._g_n, self._g_cap
         kw = dict(grid_res=self.R, rays_o=self.graph_rays_o, rays_d=self.graph_rays_d, width=n, height=1, ray_begin=0, ray_count=n,
                   occupancy=self.occ, occupancy_coarse=self.coarse, occupancy_bricks=self.bricks, occupancy_super=self.super_mip,
-                  mode=api.TRACE_DDA, viewing_direction=st["view_dirs"], num_hits=st["num_hits"], sub_rays=self.sub_rays,
+                  mode=api.TRACE_DDA, viewing_direction=st["view_dirs"], num_hits=st["num_hits"], sub_rays=api.auto_sub_rays(n),
                   sub_hits=st["sub_hits"])
         st["targets"].copy_(self.graph_targets)
         api.trace_grid(None, **kw)

@@ -145,7 +145,7 @@ def test_trace_occupancy_and_hierarchical_skip(gpu, oracle, R, use_coarse):
             _assert_trace_equal(got, want)
 
 
-@pytest.mark.parametrize("sub_rays", [0, 2, 8, 16])
+@pytest.mark.parametrize("sub_rays", [0, 2, 8, 16, 32, 64])
 def test_trace_window_and_packed_two_pass(gpu, oracle, sub_rays):
     """Ray window (the multi-GPU shard) + count -> scan -> write into the packed CSR layout; with sub_rays = Q the ray
     is walked by Q lanes in consecutive pieces and must give the same segments, in the same order, bit for bit."""

@@ -52,7 +52,7 @@ for it in range(a.iters):
     t0 = torch.full((n * S,), -2.0, device="cuda")
     t1 = torch.full((n * S,), -2.0, device="cuda")
     # sub-ray walk (DDA only): Q lanes per ray, counting pass first (it fills sub_hits), then the write pass
-    Q = int(rng.choice([1, 1, 2, 4, 8, 16])) if mode == 1 else 1
+    Q = int(rng.choice([1, 1, 2, 4, 8, 16, 32, 64])) if mode == 1 else 1
     sub = torch.zeros(n * Q, dtype=torch.int32, device="cuda") if Q > 1 else None
     la_d = torch.from_numpy(la.reshape(16)).cuda()
     common = dict(grid_res=R, occupancy=occ, occupancy_coarse=coarse, occupancy_bricks=bricks, occupancy_super=sup, mode=mode,
