@@ -823,6 +823,23 @@ __device__ __forceinline__ void encode_layer0_input(const float (&xq)[CT][5], co
   }
 }
 
+// Diagnostic build only (-DRTXN_STAMPS, tools/probe/stamps.py; never in the shipped library): block 0 records s_memtime at
+// the stage boundaries of its tiles 2..5, every wave its own, into LDS and copies them out when it is done.  The values go
+// to a buffer nothing else reads.  Stamp k of a tile: 0 top, 1 encoded, 2 + 2l past the barrier of stage l, 3 + 2l stage l done.
+#ifdef RTXN_STAMPS
+constexpr int kStampTiles = 4, kStampSlots = 24;
+__device__ unsigned g_stamps[8 * kStampTiles * kStampSlots];
+#define RTXN_STAMP(k)                                                                                     \
+  do {                                                                                                    \
+    if (blockIdx.x == 0 && tile_it >= 2 && tile_it < 2 + kStampTiles) {                                   \
+      const unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime();                                         \
+      if (lane == 0) stamp_lds[(wave_u * kStampTiles + (tile_it - 2)) * kStampSlots + (k)] = t_;          \
+    }                                                                                                     \
+  } while (0)
+#else
+#define RTXN_STAMP(k)
+#endif
+
 // OUT_MODE 0: half[n][16]; 1: float4 radiance (+ t_vals); 3: compact half4.  (The per-segment compositor epilogue,
 // OUT_MODE 2, exists only in the 32x32 kernel.)
 template <int W, int PD, int PF, int DD, int DF, int IN_MODE, int OUT_MODE>
@@ -838,6 +855,10 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd16_kernel(FwdArgs a) {
   constexpr int RES_BYTES = L0_BYTES + OUT_BYTES;       // [layer 0 | output layer x 4 rotations | 3 x HID_BYTES]
   constexpr bool ROT = OUT_MODE != 0;                   // 4-output epilogue: column tile v's outputs land in lane group v
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+#ifdef RTXN_STAMPS
+  __shared__ unsigned stamp_lds[8 * kStampTiles * kStampSlots];
+  int tile_it = 0;
+#endif
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -876,29 +897,59 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd16_kernel(FwdArgs a) {
     valid = sidx < a.n;
     return sidx;
   };
-  auto load_inputs = [&](int tile) {
+  // The next tile's inputs are FETCHED one tile ahead (behind the barrier of stage 1) and only turned into samples at the top
+  // of their own tile.  Forming the samples where the loads are issued -- as this kernel did until the in-kernel stamps
+  // (tools/probe/stamps.py) showed a 5,000-cycle "barrier" at stage 1 -- makes hipcc wait for the loads right there: both
+  // wave groups stood still for an HBM round trip once per tile, 10 % of the tile's 46,600 cycles.
+  // (The carried values are kept in the vector types the loads produce: as a float array they were copied element by
+  // element right behind the loads -- register tuples versus loop phis -- and the copies waited for the data all the same.)
+  typedef float f3v __attribute__((ext_vector_type(3)));
+  typedef float f2v __attribute__((ext_vector_type(2)));
+  f3v raw_s[CT / 2], raw_e[CT / 2];         // segments: start, end, view of the wave's two
+  f2v raw_v[CT / 2];
+  float raw_x[IN_MODE == 1 ? 1 : CT][5];    // samples: x[5] of the lane's four
+  auto fetch_inputs = [&](int tile) {
+    if (IN_MODE == 1) {
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-      bool valid_in;
-      const long samp_in = sample_of(tile, ct, valid_in);
-      if (IN_MODE == 1) {
+      for (int sgi = 0; sgi < CT / 2; ++sgi) {
+        bool valid_in;
+        const long samp_in = sample_of(tile, 2 * sgi, valid_in);
         const long sg = valid_in ? (samp_in >> 5) : 0;
-        const float t = (float)(16 * (ct & 1) + c) * (1.0f / 32);
+        __builtin_memcpy(&raw_s[sgi], a.start + 3 * sg, 12);
+        __builtin_memcpy(&raw_e[sgi], a.end + 3 * sg, 12);
+        __builtin_memcpy(&raw_v[sgi], a.seg_view + 2 * sg, 8);
+      }
+    } else {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const float og = a.start[3 * sg + k];
-          xq[ct][k] = fmaf(t, a.end[3 * sg + k] - og, og) * pos_scale;   // REGULAR sample, sampler.cu:52-66; exact scaling
-        }
-        xq[ct][3] = a.seg_view[2 * sg] * dir_scale;
-        xq[ct][4] = a.seg_view[2 * sg + 1] * dir_scale;
-      } else {
+      for (int ct = 0; ct < CT; ++ct) {
+        bool valid_in;
+        const long samp_in = sample_of(tile, ct, valid_in);
         const long sidx = valid_in ? samp_in : 0;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) xq[ct][k] = a.input[5 * sidx + k] * (k < PD ? pos_scale : dir_scale);
+        for (int k = 0; k < 5; ++k) raw_x[ct][k] = a.input[5 * sidx + k];
       }
     }
   };
-  load_inputs((int)blockIdx.x);
+  auto form_inputs = [&]() {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      if (IN_MODE == 1) {
+        const int sgi = ct >> 1;
+        const float t = (float)(16 * (ct & 1) + c) * (1.0f / 32);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float og = raw_s[sgi][k];
+          xq[ct][k] = fmaf(t, raw_e[sgi][k] - og, og) * pos_scale;   // REGULAR sample, sampler.cu:52-66; exact scaling
+        }
+        xq[ct][3] = raw_v[sgi][0] * dir_scale;
+        xq[ct][4] = raw_v[sgi][1] * dir_scale;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) xq[ct][k] = raw_x[ct][k] * (k < PD ? pos_scale : dir_scale);
+      }
+    }
+  };
+  fetch_inputs((int)blockIdx.x);
 
   if (grp == 1) {
     if (n_hid > 0) {
@@ -912,6 +963,8 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd16_kernel(FwdArgs a) {
   }
   for (int tile = (int)blockIdx.x; tile < n_tiles; tile += tile_step) {
     const bool more = tile + tile_step < n_tiles;       // this block has another tile after this one
+    RTXN_STAMP(0);
+    form_inputs();
     if (IN_MODE == 1 && OUT_MODE == 1 && a.t_vals) {
       // REGULAR t_vals (sampler.cu:65: post-increment) of the wave's 64 samples, one per lane: lane l is sample l of the two
       // segments.  The lane index goes through an empty asm so that the per-lane address is formed here, not hoisted out of
@@ -949,11 +1002,12 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd16_kernel(FwdArgs a) {
       sj.lds = smem + RES_BYTES + (unsigned)__builtin_amdgcn_readfirstlane(((inst + lk - 1) % 3) * HID_BYTES);
       sj.nfrags = __builtin_amdgcn_readfirstlane(fetch ? HID_BYTES / 1024 : 0);
       if (hidden) ++qs;
-      if (l == 1 && more) load_inputs(tile + tile_step);
+      if (l == 1 && more) fetch_inputs(tile + tile_step);
       return cur;
     };
     auto finish = [&](half8 (&in)[NB][CT], half8 (&other)[NB][CT]) {
       const uint8_t* w = begin_stage(n_layers - 1);
+      RTXN_STAMP(2 + 2 * (n_layers - 1));
       if constexpr (!ROT) {
         rtxn::pipe_layer16<0, KS, NB, CT, true>(w, sj, in, other, acc2, wave_u, lane);
         // output rows 4g .. 4g+3 of sample (ct, c) are this lane's four accumulator registers
@@ -1018,25 +1072,43 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd16_kernel(FwdArgs a) {
     };
     {
       encode_layer0_input<ES, PD, PF, DD, DF, KS0, NB, CT, SHARE>(xq, dirs, bf);   // VALU only: before the stage barrier, not behind it
+      RTXN_STAMP(1);
       const uint8_t* w = begin_stage(0);
+      RTXN_STAMP(2);
       rtxn::pipe_layer16<RT, KS0, NB, CT, false>(w, sj, bf, bg, acc2, wave_u, lane);
+      RTXN_STAMP(3);
     }
     int l = 1;
     for (; l + 1 < n_layers - 1; l += 2) {
       const uint8_t* w = begin_stage(l);
+      RTXN_STAMP(2 + 2 * l);
       rtxn::pipe_layer16<RT, KS, NB, CT, true>(w, sj, bg, bf, acc2, wave_u, lane);
+      RTXN_STAMP(3 + 2 * l);
       w = begin_stage(l + 1);
+      RTXN_STAMP(4 + 2 * l);
       rtxn::pipe_layer16<RT, KS, NB, CT, true>(w, sj, bf, bg, acc2, wave_u, lane);
+      RTXN_STAMP(5 + 2 * l);
     }
     if (l < n_layers - 1) {
       const uint8_t* w = begin_stage(l);
+      RTXN_STAMP(2 + 2 * l);
       rtxn::pipe_layer16<RT, KS, NB, CT, true>(w, sj, bg, bf, acc2, wave_u, lane);
+      RTXN_STAMP(3 + 2 * l);
       finish(bf, bg);
     } else {
       finish(bg, bf);
     }
+    RTXN_STAMP(3 + 2 * (n_layers - 1));
+#ifdef RTXN_STAMPS
+    ++tile_it;
+#endif
   }
   if (grp == 0) rtxn::staged_barrier();
+#ifdef RTXN_STAMPS
+  if (blockIdx.x == 0)
+    for (int i = lane; i < kStampTiles * kStampSlots; i += 64)
+      g_stamps[wave_u * kStampTiles * kStampSlots + i] = stamp_lds[wave_u * kStampTiles * kStampSlots + i];
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -1878,3 +1950,10 @@ extern "C" int rtxn_mlp_forward_segments_composite(const rtxn_mlp* m, const floa
   a.step_scale = step_scale;
   return launch_fwd(m, a, 1, 2, max_segments, rtxn::as_stream(stream));
 }
+
+#ifdef RTXN_STAMPS
+// diagnostic builds only: the stamps of the last launch of mlp_fwd16_kernel (8 waves x 4 tiles x 24 slots)
+extern "C" int rtxn_debug_read_stamps(unsigned* dst) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), sizeof(unsigned) * 8 * kStampTiles * kStampSlots) == hipSuccess ? 0 : 1;
+}
+#endif

@@ -145,6 +145,14 @@ __device__ __forceinline__ void lds_wait() {
   asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N));
   __builtin_amdgcn_sched_barrier(0);
 }
+// The same wait as a real instruction (gfx9 encoding: vmcnt and expcnt fields all ones).  Between two asm statements that
+// share a register (ds_read -> the MFMA statement) hipcc's hazard recogniser assumes a forwarding hazard and pads with s_nop
+// unless an instruction it can see sits between them; an asm s_waitcnt does not count, this one does.
+template <int N>
+__device__ __forceinline__ void lds_wait_insn() {
+  __builtin_amdgcn_s_waitcnt(0xC07F | (N << 8));
+  __builtin_amdgcn_sched_barrier(0);
+}
 
 // pack2 unit P (0 .. 8*CT-1) of a finished accumulator tile -> dword (P%4) of B fragment dst[k0 + (P%8)/4][P/8]
 template <int NB, int CT, int P>
@@ -338,6 +346,82 @@ __device__ __forceinline__ void convert_slice16(const floatx4 (&acc)[CT], half8 
   convert_units16<NB, CT, RTI, p0, p1>(acc, dst);
 }
 
+// One k-step of the 16x16x32 pipeline with the issue order fixed by hand (RTXN_ILV16, default on): the CT MFMAs and the
+// ReLU/convert units [P0, P1) of the finished tile RTI (accumulators `fin`) as single-instruction asm volatile statements,
+// the units' 2 (P1 - P0) instructions (cvt, max, cvt, max, ...) dealt over the CT gaps behind the MFMAs in order.  An 8-pass
+// MFMA holds the SIMD's vector issue for 8 of its 16 cycles (MI355X_MICROARCH.md, issue-cost row), so one 4-cycle VALU
+// instruction per gap is nearly free, while the four hipcc placed behind the step's FIRST MFMA (the units are asm, the
+// MFMAs were builtins it could move) made that gap 8 + 17 cycles: 73 instead of 64 cycles per step in the wave's own stream.
+// ZERO: first k-step of a row tile, C = 0.  Hazards, by construction as before: a unit reads a tile whose last MFMA is at
+// least CT MFMAs behind it; a chain accumulator meets its next MFMA CT - 1 MFMAs later; nothing here reads `dst`.
+#ifndef RTXN_ILV16
+#define RTXN_ILV16 1
+#endif
+// Two MFMAs and the NUP units behind them as ONE asm statement: between separate statements hipcc's hazard recogniser pads
+// a cvt -> max pair it cannot see through with s_nop (4 issue cycles).  NUP = 1: M0 cvt M1 max; 2: M0 cvt max M1 cvt max.
+#define RTXN_M16(ACC, B, C) "v_mfma_f32_16x16x32_f16 %[" ACC "], %[a], %[" B "], " C "\n\t"
+#define RTXN_CVT16(U) "v_cvt_pk_f16_f32 %[r" U "], %[x" U "], %[y" U "]\n\t"
+#define RTXN_MAX16(U) "v_pk_max_i16 %[r" U "], %[r" U "], 0\n\t"
+#define RTXN_UNIT16(U) RTXN_CVT16(U) RTXN_MAX16(U)
+#define RTXN_IN16 [a] "v"(a), [b0] "v"(b0), [b1] "v"(b1)
+#define RTXN_UOUT(U, I) [r##U] "=&v"(r[I])
+#define RTXN_UIN(U, I) [x##U] "v"(x[I]), [y##U] "v"(y[I])
+#define RTXN_PAIR16_CASES(M0, M1, ACC0, ACC1)                                                                                          \
+  if constexpr (NUP == 0) asm volatile(M0 M1 : ACC0, ACC1 : RTXN_IN16);                                                                  \
+  else if constexpr (NUP == 1) asm volatile(M0 RTXN_CVT16("0") M1 RTXN_MAX16("0") : ACC0, ACC1, RTXN_UOUT(0, 0) : RTXN_IN16, RTXN_UIN(0, 0)); \
+  else if constexpr (NUP == 2)                                                                                                    \
+    asm volatile(M0 RTXN_UNIT16("0") M1 RTXN_UNIT16("1") : ACC0, ACC1, RTXN_UOUT(0, 0), RTXN_UOUT(1, 1) : RTXN_IN16, RTXN_UIN(0, 0), RTXN_UIN(1, 1)); \
+  else                                                                                                                            \
+    asm volatile(M0 RTXN_UNIT16("0") RTXN_UNIT16("1") M1 RTXN_UNIT16("2") RTXN_UNIT16("3")                                         \
+                 : ACC0, ACC1, RTXN_UOUT(0, 0), RTXN_UOUT(1, 1), RTXN_UOUT(2, 2), RTXN_UOUT(3, 3)                                         \
+                 : RTXN_IN16, RTXN_UIN(0, 0), RTXN_UIN(1, 1), RTXN_UIN(2, 2), RTXN_UIN(3, 3));
+template <bool ZERO, int NUP>
+__device__ __forceinline__ void pair16(floatx4& acc0, floatx4& acc1, const half8& a, const half8& b0, const half8& b1,
+                                       int (&r)[NUP > 0 ? NUP : 1], const float (&x)[NUP > 0 ? NUP : 1], const float (&y)[NUP > 0 ? NUP : 1]) {
+  static_assert(NUP == 0 || NUP == 1 || NUP == 2 || NUP == 4, "unit pattern not written");
+  if constexpr (ZERO) {
+    RTXN_PAIR16_CASES(RTXN_M16("c0", "b0", "0"), RTXN_M16("c1", "b1", "0"), [c0] "=&v"(acc0), [c1] "=&v"(acc1))
+  } else {
+    RTXN_PAIR16_CASES(RTXN_M16("c0", "b0", "%[c0]"), RTXN_M16("c1", "b1", "%[c1]"), [c0] "+v"(acc0), [c1] "+v"(acc1))
+  }
+}
+// units [P0, P0 + NU) of the finished tile RTI go behind the step's CT MFMAs, pair by pair
+template <int NB, int CT, int RTI, int P0, int NU, bool ZERO, int PAIR>
+struct PairRun16 {
+  static constexpr int NPAIR = CT / 2;
+  static constexpr int u0 = (NU * PAIR + NPAIR - 1) / NPAIR, u1 = (NU * (PAIR + 1) + NPAIR - 1) / NPAIR, NUP = u1 - u0;   // earlier pairs take the odd one
+  __device__ static __forceinline__ void run(const half8& a, const half8 (&b)[CT], floatx4 (&acc)[CT], const floatx4 (&fin)[CT],
+                                             half8 (&dst)[NB][CT]) {
+    int r[NUP > 0 ? NUP : 1];
+    float x[NUP > 0 ? NUP : 1], y[NUP > 0 ? NUP : 1];
+#pragma unroll
+    for (int i = 0; i < NUP; ++i) {
+      const int P = P0 + u0 + i;
+      x[i] = fin[P / 2][2 * (P % 2)];
+      y[i] = fin[P / 2][2 * (P % 2) + 1];
+    }
+    pair16<ZERO, NUP>(acc[2 * PAIR], acc[2 * PAIR + 1], a, b[2 * PAIR], b[2 * PAIR + 1], r, x, y);
+#pragma unroll
+    for (int i = 0; i < NUP; ++i) {
+      const int P = P0 + u0 + i, ct = P / 2, e = P % 2;
+      int4v t = __builtin_bit_cast(int4v, dst[RTI >> 1][ct]);
+      t[2 * (RTI & 1) + e] = r[i];
+      dst[RTI >> 1][ct] = __builtin_bit_cast(half8, t);
+    }
+    if constexpr (PAIR + 1 < NPAIR) PairRun16<NB, CT, RTI, P0, NU, ZERO, PAIR + 1>::run(a, b, acc, fin, dst);
+  }
+};
+template <int NB, int CT, int RTI, int P0, int P1, bool ZERO>
+__device__ __forceinline__ void mfma_convert_step16(const half8& a, const half8 (&b)[CT], floatx4 (&acc)[CT], const floatx4 (&fin)[CT],
+                                                    half8 (&dst)[NB][CT]) {
+  static_assert(CT % 2 == 0, "MFMAs go in pairs");
+  PairRun16<NB, CT, RTI, P0, (P1 > P0 ? P1 - P0 : 0), ZERO, 0>::run(a, b, acc, fin, dst);
+}
+template <int CT, int U, int KK>
+struct UnitRange16 {
+  static constexpr int p0 = KK * U < 2 * CT ? KK * U : 2 * CT, p1 = (KK + 1) * U < 2 * CT ? (KK + 1) * U : 2 * CT;
+};
+
 // RT 16-row tiles (RT == 0: the output layer's single tile, left raw in acc[0]); KS 32-wide k-steps.
 // PEND: acc[1] holds the previous layer's last row tile (an odd tile: dwords 2, 3 of bf[KS-1]).
 template <int RT, int KS, int NB, int CT, bool PEND, int I>
@@ -352,6 +436,18 @@ struct PipeStep16 {
                                              floatx4 (&acc)[2][CT], const StageJob& sj, int wave_u, int lane) {
     constexpr int rt = I / KS, kk = I % KS, cur = rt & 1;
     constexpr int outstanding = (N - 1 - I) < (D - 1) ? (N - 1 - I) : (D - 1);
+#if RTXN_ILV16
+    lds_wait_insn<outstanding>();
+    if constexpr (rt > 0) {
+      using R = UnitRange16<CT, U, kk>;
+      mfma_convert_step16<NB, CT, rt - 1, R::p0, R::p1, kk == 0>(ring[I % D], bf[kk], acc[cur], acc[cur ^ 1], nbf);
+    } else if constexpr (PEND && kk < WIN) {
+      using R = UnitRange16<CT, UP, kk>;
+      mfma_convert_step16<NB, CT, 2 * KS - 1, R::p0, R::p1, kk == 0>(ring[I % D], bf[kk], acc[cur], acc[1], bf);
+    } else {
+      mfma_convert_step16<NB, CT, 0, 0, 0, kk == 0>(ring[I % D], bf[kk], acc[cur], acc[cur], nbf);
+    }
+#else
     lds_wait<outstanding>();
     const half8 a = ring[I % D];
     if (kk == 0) {
@@ -364,6 +460,7 @@ struct PipeStep16 {
     for (int ct = 0; ct < CT; ++ct) acc[cur][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bf[kk][ct], acc[cur][ct], 0, 0, 0);
     if constexpr (rt > 0) convert_slice16<NB, CT, rt - 1, U, kk>(acc[cur ^ 1], nbf);
     else if constexpr (PEND && kk < WIN) convert_slice16<NB, CT, 2 * KS - 1, UP, kk>(acc[1], bf);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (I + D < N) lds_read_frag<(I + D) * 1024>(ring[I % D], addr);
     if constexpr (I < CHUNKS) {
@@ -414,6 +511,19 @@ struct PipeStep16c {
                                              floatx4 (&acc)[2][CT], const StageJob& sj, int wave_u, int lane) {
     constexpr int r = I / KS, kk = I % KS, cur = r & 1;
     constexpr int outstanding = (N - 1 - I) < (D - 1) ? (N - 1 - I) : (D - 1);
+#if RTXN_ILV16
+    lds_wait_insn<outstanding>();
+    if constexpr (r > 0 && kk >= 1) {
+      using R = UnitRange16<CT, U, kk - 1>;
+      mfma_convert_step16<NB, CT, RT0 + r - 1, R::p0, R::p1, false>(ring[I % D], in[kk], acc[cur], acc[cur ^ 1], out);
+    } else if constexpr (r == 0 && PEND && kk < WIN) {
+      using R = UnitRange16<CT, UP, kk>;
+      if constexpr (RT0 > 0) mfma_convert_step16<NB, CT, RT0 - 1, R::p0, R::p1, kk == 0>(ring[I % D], in[kk], acc[cur], acc[1], out);
+      else mfma_convert_step16<NB, CT, 2 * NB - 1, R::p0, R::p1, kk == 0>(ring[I % D], in[kk], acc[cur], acc[1], in);
+    } else {
+      mfma_convert_step16<NB, CT, 0, 0, 0, kk == 0>(ring[I % D], in[kk], acc[cur], acc[cur], out);
+    }
+#else
     lds_wait<outstanding>();
     const half8 a = ring[I % D];
     if (kk == 0) {
@@ -430,6 +540,7 @@ struct PipeStep16c {
       if constexpr (RT0 > 0) convert_slice16<NB, CT, RT0 - 1, UP, kk>(acc[1], out);
       else convert_slice16<NB, CT, 2 * NB - 1, UP, kk>(acc[1], in);
     }
+#endif
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (I + D < N) lds_read_frag<(I + D) * 1024>(ring[I % D], addr);
     if constexpr (I < CHUNKS) {

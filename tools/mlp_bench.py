@@ -19,6 +19,8 @@ ap.add_argument("--neurons", type=int, default=128)
 ap.add_argument("--layers", type=int, default=8)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--composite", action="store_true", help="time the fused per-segment composite epilogue variant")
+ap.add_argument("--weights", choices=["xavier", "zero", "small"], default="xavier", help="power experiment: all-zero weights (no operand toggling "
+                "in the matrix core: what the kernel does when the clock is not held down) or tiny ones; timing only")
 ap.add_argument("--samples", action="store_true", help="time rtxn_mlp_forward_radiance on a materialised float[N][5] batch (the bench.py default path)")
 args = ap.parse_args()
 
@@ -33,7 +35,12 @@ seg_ray = (torch.arange(P, device="cuda", dtype=torch.int32) // 5).clamp_(max=n_
 sv = vd[seg_ray.long()].contiguous()
 total = torch.tensor([P], dtype=torch.int32, device="cuda")
 net = api.Network(n_neurons=args.neurons, n_hidden_layers=args.layers)
-net.set_params(torch.from_numpy(scenes.xavier_params_fp16(args.neurons, args.layers, net.encoded_width())).cuda())
+w_np = scenes.xavier_params_fp16(args.neurons, args.layers, net.encoded_width())
+if args.weights == "zero":
+    w_np = np.zeros_like(w_np)
+elif args.weights == "small":
+    w_np = (w_np.astype(np.float32) * 1e-3).astype(np.float16)
+net.set_params(torch.from_numpy(w_np).cuda())
 if args.composite:
     seg_first = (torch.arange(P, device="cuda") % 5 == 0).to(torch.uint8)
     seg_out = torch.empty((P, 4), device="cuda")
