@@ -1363,25 +1363,47 @@ __global__ __launch_bounds__(kThreads256, 2) void mlp_fwd256x16_kernel(FwdArgs a
     valid = sidx < a.n;
     return sidx;
   };
-  auto load_inputs = [&](int tile) {
+  // fetched one tile ahead as the loads deliver them, formed into samples at the top of their own tile (mlp_fwd16_kernel
+  // explains why: forming them where the loads are issued makes the wave wait for HBM there)
+  typedef float f3v __attribute__((ext_vector_type(3)));
+  typedef float f2v __attribute__((ext_vector_type(2)));
+  f3v raw_s, raw_e;                         // segment input: the wave's one segment
+  f2v raw_v;
+  float raw_x[IN_MODE == 1 ? 1 : CT][5];    // sample input: x[5] of the lane's two
+  auto fetch_inputs = [&](int tile) {
+    if (IN_MODE == 1) {
+      bool valid_in;
+      const long samp_in = sample_of(tile, 0, valid_in);
+      const long sg = valid_in ? (samp_in >> 5) : 0;
+      __builtin_memcpy(&raw_s, a.start + 3 * sg, 12);
+      __builtin_memcpy(&raw_e, a.end + 3 * sg, 12);
+      __builtin_memcpy(&raw_v, a.seg_view + 2 * sg, 8);
+    } else {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        bool valid_in;
+        const long samp_in = sample_of(tile, ct, valid_in);
+        const long sidx = valid_in ? samp_in : 0;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) raw_x[ct][k] = a.input[5 * sidx + k];
+      }
+    }
+  };
+  auto form_inputs = [&]() {
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
-      bool valid_in;
-      const long samp_in = sample_of(tile, ct, valid_in);
       if (IN_MODE == 1) {
-        const long sg = valid_in ? (samp_in >> 5) : 0;
         const float t = (float)(16 * ct + c) * (1.0f / 32);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-          const float og = a.start[3 * sg + k];
-          xq[ct][k] = fmaf(t, a.end[3 * sg + k] - og, og) * pos_scale;   // REGULAR sample, sampler.cu:52-66; exact scaling
+          const float og = raw_s[k];
+          xq[ct][k] = fmaf(t, raw_e[k] - og, og) * pos_scale;   // REGULAR sample, sampler.cu:52-66; exact scaling
         }
-        xq[ct][3] = a.seg_view[2 * sg] * dir_scale;
-        xq[ct][4] = a.seg_view[2 * sg + 1] * dir_scale;
+        xq[ct][3] = raw_v[0] * dir_scale;
+        xq[ct][4] = raw_v[1] * dir_scale;
       } else {
-        const long sidx = valid_in ? samp_in : 0;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) xq[ct][k] = a.input[5 * sidx + k] * (k < PD ? pos_scale : dir_scale);
+        for (int k = 0; k < 5; ++k) xq[ct][k] = raw_x[ct][k] * (k < PD ? pos_scale : dir_scale);
       }
     }
   };
@@ -1404,7 +1426,7 @@ __global__ __launch_bounds__(kThreads256, 2) void mlp_fwd256x16_kernel(FwdArgs a
   int chunk_in_tile = 0, prefetch_tile = -1;
   auto next_chunk = [&]() -> const uint8_t* {
     rtxn::staged_barrier();  // chunk gq landed; everyone is done with chunk gq-1
-    if (chunk_in_tile++ == 1 && prefetch_tile >= 0) load_inputs(prefetch_tile);   // behind a barrier: never waited on early
+    if (chunk_in_tile++ == 1 && prefetch_tile >= 0) fetch_inputs(prefetch_tile);   // behind a barrier; consumed at the next tile's top
     int size = 0;
     const unsigned off = gq + 2 < g_end ? chunk_src(gq + 2, size) : 0u;
     sj.g = a.packed + (unsigned)__builtin_amdgcn_readfirstlane((int)off);
@@ -1415,9 +1437,10 @@ __global__ __launch_bounds__(kThreads256, 2) void mlp_fwd256x16_kernel(FwdArgs a
     return p;
   };
 
-  load_inputs((int)blockIdx.x);
+  fetch_inputs((int)blockIdx.x);
 
   for (int tile = (int)blockIdx.x; tile < n_tiles; tile += tile_step) {
+    form_inputs();
     if (IN_MODE == 1 && OUT_MODE == 1 && a.t_vals) {
       int lane_t = lane;
       asm volatile("" : "+v"(lane_t));
