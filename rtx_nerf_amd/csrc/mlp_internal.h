@@ -488,6 +488,11 @@ __device__ __forceinline__ void pipe_layer16(const uint8_t* lds_buf, const Stage
   if constexpr (D > 2 && N > 2) lds_read_frag<2048>(ring[2 % D], addr);
   if constexpr (D > 3 && N > 3) lds_read_frag<3072>(ring[3 % D], addr);
   PipeStep16<RT, KS, NB, CT, PEND, 0>::run(addr, bf, nbf, ring, acc, sj, wave_u, lane);
+#if RTXN_ILV16
+  // RT == 0: the caller reads acc[0] with ordinary code right behind this, and hipcc cannot see the asm MFMAs that wrote it:
+  // the MFMA-result -> VALU-read wait states (8 passes + margin) are spent here, once per tile
+  if constexpr (RT == 0) asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+#endif
 }
 
 // The same 16x16x32 pipeline over one CHUNK of a streamed layer (the 256-wide kernel: a layer is 128 KiB of fragments and goes
