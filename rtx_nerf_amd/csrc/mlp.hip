@@ -611,7 +611,7 @@ __global__ __launch_bounds__(64 * RTXN_NW, CT == 2 ? 2 : 1) void mlp_fwd_kernel(
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float z = acc[ct][e];
-          y[e] = a.out_act == RTXN_ACT_SIGMOID ? 1.0f / (1.0f + __expf(-z)) : z;
+          y[e] = a.out_act == RTXN_ACT_SIGMOID ? rtxn::sigmoidf_fast(z) : z;
         }
         bool valid;
         const long samp = sample_of(tile, ct, valid);
@@ -1020,7 +1020,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd16_kernel(FwdArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const float z = acc2[0][ct][e];
-              o[e] = (_Float16)(a.out_act == RTXN_ACT_SIGMOID ? 1.0f / (1.0f + __expf(-z)) : z);
+              o[e] = (_Float16)(a.out_act == RTXN_ACT_SIGMOID ? rtxn::sigmoidf_fast(z) : z);
             }
             *reinterpret_cast<half4v*>(a.out_half + samp * 16 + 4 * g) = o;
           }
@@ -1045,7 +1045,9 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd16_kernel(FwdArgs a) {
             const half8 af = *reinterpret_cast<const half8*>(w + ((ct * KS + kk) * 64 + lane) * 16);
             z4[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, in[kk][ct], z4[ct], 0, 0, 0);
           }
-          __builtin_amdgcn_sched_barrier(0);   // one k-step's four fragments in flight at a time (all 16 hoisted = 64 VGPRs: spills)
+          // two k-steps' fragments in flight at a time (one: four exposed LDS latencies in an epilogue that is on the block's
+          // critical path; all 16 hoisted = 64 VGPRs on top of the layer's peak)
+          if (kk & 1) __builtin_amdgcn_sched_barrier(0);
         }
         // lane (c, g): sample 16 g + c of the wave's 64 -- consecutive lanes, consecutive samples
         rtxn::floatx4 z = g == 0 ? z4[0] : (g == 1 ? z4[1] : (g == 2 ? z4[2] : z4[3]));
@@ -1064,7 +1066,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd16_kernel(FwdArgs a) {
         if (valid) {
           half4v o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (_Float16)(a.out_act == RTXN_ACT_SIGMOID ? 1.0f / (1.0f + __expf(-z[e])) : z[e]);
+          for (int e = 0; e < 4; ++e) o[e] = (_Float16)(a.out_act == RTXN_ACT_SIGMOID ? rtxn::sigmoidf_fast(z[e]) : z[e]);
           if (OUT_MODE == 3) *reinterpret_cast<half4v*>(a.out_half + samp * 4) = o;
           else a.radiance[samp] = make_float4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
         }
@@ -1288,7 +1290,7 @@ __global__ __launch_bounds__(kThreads256, 2) void mlp_fwd256_kernel(FwdArgs a) {
     const floatx16& acc = acc2[0][0];
     float y[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) y[e] = a.out_act == RTXN_ACT_SIGMOID ? 1.0f / (1.0f + __expf(-acc[e])) : acc[e];
+    for (int e = 0; e < 8; ++e) y[e] = a.out_act == RTXN_ACT_SIGMOID ? rtxn::sigmoidf_fast(acc[e]) : acc[e];
     if (OUT_MODE == 2) {
       const float4 c = seg_composite((float)(_Float16)y[0], (float)(_Float16)y[1], (float)(_Float16)y[2],
                                      (float)(_Float16)y[3], col, d0, dr, a.vr_mode);
@@ -1506,7 +1508,7 @@ __global__ __launch_bounds__(kThreads256, 2) void mlp_fwd256x16_kernel(FwdArgs a
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const float z = z4[ct][e];
-              o[e] = (_Float16)(a.out_act == RTXN_ACT_SIGMOID ? 1.0f / (1.0f + __expf(-z)) : z);
+              o[e] = (_Float16)(a.out_act == RTXN_ACT_SIGMOID ? rtxn::sigmoidf_fast(z) : z);
             }
             *reinterpret_cast<half4v*>(a.out_half + samp * 16 + 4 * g) = o;
           }
@@ -1529,7 +1531,7 @@ __global__ __launch_bounds__(kThreads256, 2) void mlp_fwd256x16_kernel(FwdArgs a
         if (valid) {
           half4v o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (_Float16)(a.out_act == RTXN_ACT_SIGMOID ? 1.0f / (1.0f + __expf(-z[e])) : z[e]);
+          for (int e = 0; e < 4; ++e) o[e] = (_Float16)(a.out_act == RTXN_ACT_SIGMOID ? rtxn::sigmoidf_fast(z[e]) : z[e]);
           if (OUT_MODE == 3) *reinterpret_cast<half4v*>(a.out_half + samp * 4) = o;
           else a.radiance[samp] = make_float4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
         }

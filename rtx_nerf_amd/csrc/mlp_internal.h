@@ -31,6 +31,11 @@ struct rtxn_mlp {
 
 namespace rtxn {
 
+// The output activation of every MLP kernel: 1 / (1 + exp(-z)) with the hardware exponential and reciprocal (v_exp_f32,
+// v_rcp_f32: 1 ulp each).  A plain `1.0f / x` is an IEEE division, ten instructions per value in an epilogue that sits on the
+// block's critical path; the result is rounded to fp16 right behind it.
+__device__ __forceinline__ float sigmoidf_fast(float z) { return __builtin_amdgcn_rcpf(1.0f + __expf(-z)); }
+
 // Stage BYTES of lane-linear A fragments from global memory into LDS with LDS-DMA
 // (global_load_lds, 16 B per lane).  All 256 threads of the block call it.
 template <int BYTES, int THREADS = 256>

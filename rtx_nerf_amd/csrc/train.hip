@@ -613,7 +613,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_train_fwd_kernel(TrainArgs a)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float z = acc[ct][e];
-      y[e] = a.out_act == RTXN_ACT_SIGMOID ? 1.0f / (1.0f + __expf(-z)) : z;
+      y[e] = a.out_act == RTXN_ACT_SIGMOID ? rtxn::sigmoidf_fast(z) : z;
     }
     half4v lo, hi;
 #pragma unroll
