@@ -1598,9 +1598,8 @@ Variant make_variant() {
   memset(v.fn16, 0, sizeof(v.fn16));
   v.k0_16 = 0;
   v.lds16 = 0;
-  // same 512-sample tiles per block as the 32x32 kernel.  Not built for the 128-wide model with fewer than 8 direction slots
-  // (DF = 4): its compact segment variant needs two VGPRs more than the 256 of two waves per SIMD and would spill.
-  if constexpr (RTXN_NW == 8 && CT == 2 && PF % 2 == 0 && DF % 2 == 0 && (W == 64 || DD * DF / 2 >= 8)) {
+  // same 512-sample tiles per block as the 32x32 kernel
+  if constexpr (RTXN_NW == 8 && CT == 2 && PF % 2 == 0 && DF % 2 == 0) {
     using ES16 = EncSpec16<PD, PF, DD, DF>;
     v.fn16[0][0] = mlp_fwd16_kernel<W, PD, PF, DD, DF, 0, 0>;
     v.fn16[0][1] = mlp_fwd16_kernel<W, PD, PF, DD, DF, 0, 1>;
