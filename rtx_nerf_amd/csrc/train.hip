@@ -256,15 +256,29 @@ __global__ __launch_bounds__(kThreads) void hashgrid_encode_f2_kernel(HgLevels l
       fr[a] = p - fl;
     }
     const bool shared = hashed && (g[0] & 1u) == 0;
-    unsigned e[8];
+    // All of a level's gathers are issued before the first one is used: written corner by corner (load, select, load) hipcc
+    // waited for every load where it stood -- eight serial L2 round trips per level and thread (107 -> 86 us on the configs[2]
+    // batch, bit-identical).  Keeping the NEXT level's gathers in flight as well (software-pipelined levels, counted waits)
+    // measured no better (91 us): past this point the kernel is bound by the gather rate, not by the round trips.
+    unsigned e[8], i_lo[4], i_hi[4];
+    uint2 pr[4];
 #pragma unroll
     for (int yz = 0; yz < 4; ++yz) {
       const unsigned py = g[1] + (unsigned)(yz & 1), pz = g[2] + (unsigned)(yz >> 1);
-      const unsigned i_lo = hg_index_nodiv(g[0], py, pz, res, size, hashed);
-      const uint2 pr = *reinterpret_cast<const uint2*>(base + ((i_lo & ~1u) << 2));
-      e[2 * yz] = (i_lo & 1u) ? pr.y : pr.x;
-      e[2 * yz + 1] = (i_lo & 1u) ? pr.x : pr.y;
-      if (!shared) e[2 * yz + 1] = *reinterpret_cast<const unsigned*>(base + (hg_index_nodiv(g[0] + 1u, py, pz, res, size, hashed) << 2));
+      i_lo[yz] = hg_index_nodiv(g[0], py, pz, res, size, hashed);
+      i_hi[yz] = hg_index_nodiv(g[0] + 1u, py, pz, res, size, hashed);
+    }
+#pragma unroll
+    for (int yz = 0; yz < 4; ++yz) pr[yz] = *reinterpret_cast<const uint2*>(base + ((i_lo[yz] & ~1u) << 2));
+    unsigned hi[4] = {0u, 0u, 0u, 0u};
+    if (!shared) {
+#pragma unroll
+      for (int yz = 0; yz < 4; ++yz) hi[yz] = *reinterpret_cast<const unsigned*>(base + (i_hi[yz] << 2));
+    }
+#pragma unroll
+    for (int yz = 0; yz < 4; ++yz) {
+      e[2 * yz] = (i_lo[yz] & 1u) ? pr[yz].y : pr[yz].x;
+      e[2 * yz + 1] = shared ? ((i_lo[yz] & 1u) ? pr[yz].x : pr[yz].y) : hi[yz];
     }
     float acc0 = 0.0f, acc1 = 0.0f;
 #pragma unroll
