@@ -351,12 +351,13 @@ __device__ __forceinline__ void convert_slice16(const floatx4 (&acc)[CT], half8 
   convert_units16<NB, CT, RTI, p0, p1>(acc, dst);
 }
 
-// One k-step of the 16x16x32 pipeline with the issue order fixed by hand (RTXN_ILV16, default on): the CT MFMAs and the
-// ReLU/convert units [P0, P1) of the finished tile RTI (accumulators `fin`) as single-instruction asm volatile statements,
-// the units' 2 (P1 - P0) instructions (cvt, max, cvt, max, ...) dealt over the CT gaps behind the MFMAs in order.  An 8-pass
-// MFMA holds the SIMD's vector issue for 8 of its 16 cycles (MI355X_MICROARCH.md, issue-cost row), so one 4-cycle VALU
-// instruction per gap is nearly free, while the four hipcc placed behind the step's FIRST MFMA (the units are asm, the
-// MFMAs were builtins it could move) made that gap 8 + 17 cycles: 73 instead of 64 cycles per step in the wave's own stream.
+// One k-step of the 16x16x32 pipeline with NOTHING left to the compiler (RTXN_ILV16, default on): the CT MFMAs, accumulating
+// in place, and the ReLU/convert units [P0, P1) of the finished tile RTI (accumulators `fin`) as asm, the units interleaved
+// with the MFMAs (M cvt M max ...).  Why: builtin MFMAs that hipcc may move, merge or re-allocate around asm units it cannot
+// see into produced wrong, timing-dependent values three times in this kernel family; as one asm statement per
+// MFMA pair the step is what the source says.  Speed: the same as the builtin form -- tools/probe/mfma_cadence.hip: a VALU
+// instruction next to the MFMAs of its own wave costs ~4 cycles wherever it stands (units behind the first MFMA 81 cycles per
+// step, interleaved 80, behind the last 98); it is the partner wave of the SIMD that hides it.
 // ZERO: first k-step of a row tile, C = 0.  Hazards, by construction as before: a unit reads a tile whose last MFMA is at
 // least CT MFMAs behind it; a chain accumulator meets its next MFMA CT - 1 MFMAs later; nothing here reads `dst`.
 #ifndef RTXN_ILV16
