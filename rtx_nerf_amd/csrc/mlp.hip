@@ -478,41 +478,64 @@ __global__ __launch_bounds__(64 * RTXN_NW, CT == 2 ? 2 : 1) void mlp_fwd_kernel(
     valid = sidx < a.n;
     return sidx;
   };
-  auto load_inputs = [&](long tile) {
+  // fetched raw one tile ahead, formed into samples at the top of their own tile (mlp_fwd16_kernel explains why: forming them
+  // where the loads are issued makes the wave wait for HBM there, once per tile)
+  typedef float f3v __attribute__((ext_vector_type(3)));
+  typedef float f2v __attribute__((ext_vector_type(2)));
+  f3v raw_s[CT], raw_e[CT];                 // segment input: start, end, view (and first-of-ray flag) of the wave's CT segments
+  f2v raw_v[CT];
+  unsigned char raw_first[CT];
+  float raw_x[IN_MODE == 1 ? 1 : CT][5];    // sample input
+  auto fetch_inputs = [&](long tile) {
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
       bool valid_in;
       const long samp_in = sample_of(tile, ct, valid_in);
       if (IN_MODE == 1) {
         const long sg = valid_in ? (samp_in >> 5) : 0;
+        __builtin_memcpy(&raw_s[ct], a.start + 3 * sg, 12);
+        __builtin_memcpy(&raw_e[ct], a.end + 3 * sg, 12);
+        __builtin_memcpy(&raw_v[ct], a.seg_view + 2 * sg, 8);
+        raw_first[ct] = 0;
+        if (OUT_MODE == 2 && a.vr_mode == RTXN_VR_COMPAT) raw_first[ct] = a.seg_first[sg];
+      } else {
+        const long sidx = valid_in ? samp_in : 0;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) raw_x[ct][c] = a.input[5 * sidx + c];
+      }
+    }
+  };
+  auto form_inputs = [&]() {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      if (IN_MODE == 1) {
         const bool mid = OUT_MODE == 2 && a.vr_mode == RTXN_VR_NERF;   // NERF composite samples sub-interval midpoints
         const float t = ((float)col + (mid ? 0.5f : 0.0f)) * (1.0f / 32);
         float dd[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          const float og = a.start[3 * sg + c];
-          dd[c] = a.end[3 * sg + c] - og;
+          const float og = raw_s[ct][c];
+          dd[c] = raw_e[ct][c] - og;
           xin[ct][c] = fmaf(t, dd[c], og);   // REGULAR sample, sampler.cu:52-66
         }
         const float len2 = fmaf(dd[2], dd[2], fmaf(dd[0], dd[0], dd[1] * dd[1]));   // as the MIDPOINT_WORLD sampler
-        xin[ct][3] = a.seg_view[2 * sg];
-        xin[ct][4] = a.seg_view[2 * sg + 1];
+        xin[ct][3] = raw_v[ct][0];
+        xin[ct][4] = raw_v[ct][1];
         if (OUT_MODE == 2) {
           if (a.vr_mode == RTXN_VR_COMPAT) {
             dr_n[ct] = 1.0f / 32;
-            d0_n[ct] = a.seg_first[sg] ? 1.0f / 32 : 31.0f / 32;   // t_prev is not reset per segment (vol_render.cu:56)
+            d0_n[ct] = raw_first[ct] ? 1.0f / 32 : 31.0f / 32;   // t_prev is not reset per segment (vol_render.cu:56)
           } else {
             d0_n[ct] = dr_n[ct] = sqrtf(len2) * (1.0f / 32) * a.step_scale;
           }
         }
       } else {
-        const long sidx = valid_in ? samp_in : 0;
 #pragma unroll
-        for (int c = 0; c < 5; ++c) xin[ct][c] = a.input[5 * sidx + c];
+        for (int c = 0; c < 5; ++c) xin[ct][c] = raw_x[ct][c];
       }
     }
   };
-  load_inputs(blockIdx.x);
+  fetch_inputs(blockIdx.x);
 
   if (SKEW && grp == 1) {
     // group B's bubble: its share of the first streamed stage, then the barrier that puts it one stage behind
@@ -530,6 +553,7 @@ __global__ __launch_bounds__(64 * RTXN_NW, CT == 2 ? 2 : 1) void mlp_fwd_kernel(
     half8 bf[NB][CT];
     float d0[CT], dr[CT];
     const float phase = 0.25f * (float)h;
+    form_inputs();
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
       d0[ct] = d0_n[ct];
@@ -597,7 +621,7 @@ __global__ __launch_bounds__(64 * RTXN_NW, CT == 2 ? 2 : 1) void mlp_fwd_kernel(
       }
       // next tile's inputs, one tile ahead: issued behind the first barrier after layer 0 (which still reads this tile's),
       // so that no staged_barrier ever waits on them before they have had a whole layer to land
-      if (l == 1 && tile + gridDim.x < n_tiles) load_inputs(tile + gridDim.x);
+      if (l == 1 && tile + gridDim.x < n_tiles) fetch_inputs(tile + gridDim.x);
       return cur;
     };
     auto finish = [&](half8 (&in)[NB][CT], half8 (&other)[NB][CT]) {
