@@ -51,6 +51,9 @@ namespace {
 //   RTXN_PIPE   depth of the A-fragment register ring                        -- mlp_internal.h
 //   RTXN_SHARE_DIR 1: segment input computes a column tile's direction features once per lane-half (DirShare)
 //   RTXN_L0_PLAIN  encode all of layer 0's input up front instead of inside layer 0 (A/B timing)
+//   RTXN_ILV16  1: a k-step of the 16x16x32 pipelines is one asm statement per MFMA pair, convert units inside (0: builtin
+//               MFMAs + asm units, the form that came out wrong beside extra asm at the stage boundary)      -- mlp_internal.h
+//   RTXN_STAMPS diagnostic build: per-stage s_memtime stamps of block 0 (tools/probe/stamps.py); never in the shipped library
 // Every variant these knobs select computes the same values (tools/ablate.sh builds them side by side).  The round-1
 // timing ablations that broke the results (no encoding / no barriers / no weight staging) are gone from this file; their
 // measurements are recorded in DESIGN.md 3.4.
