@@ -1798,6 +1798,7 @@ extern "C" int rtxn_mlp_create(const rtxn_mlp_config* cfg, rtxn_mlp** out) {
   m->packed_train_bytes = (size_t)((E / 16) * RT + (L - 1) * KS * RT + KS) * 1024;
   m->packed_t_bytes = (size_t)(RT + (L - 1) * RT * KS + ((E + 31) / 32) * KS) * 1024;
   m->packed = m->packed_train = m->packed_t = nullptr;
+  m->inference_ready = 0;
   *out = m;
   return RTXN_OK;
 }
@@ -1857,7 +1858,9 @@ extern "C" int rtxn_mlp_set_params_training(rtxn_mlp* m, const void* params_fp16
 
 static int set_params_impl(rtxn_mlp* m, const void* params_fp16, rtxn_stream_t stream, bool inference) {
   RTXN_DEVICE_OR_FAIL();
-  if (m->packed_bytes && !m->packed) RTXN_HIP(hipMalloc(&m->packed, m->packed_bytes));
+  // training-only update: the inference packings are neither allocated nor refreshed, and say so (check_ready)
+  m->inference_ready = 0;
+  if (inference && m->packed_bytes && !m->packed) RTXN_HIP(hipMalloc(&m->packed, m->packed_bytes));
   if (!m->packed_train) RTXN_HIP(hipMalloc(&m->packed_train, m->packed_train_bytes));
   if (!m->packed_t) RTXN_HIP(hipMalloc(&m->packed_t, m->packed_t_bytes));
   void* dst[3] = {m->packed, m->packed_train, m->packed_t};
@@ -1882,6 +1885,7 @@ static int set_params_impl(rtxn_mlp* m, const void* params_fp16, rtxn_stream_t s
                                                                m->cfg.n_hidden_layers, d);
     RTXN_LAUNCH_CHECK("pack16_kernel");
   }
+  if (inference) m->inference_ready = 1;
   return RTXN_OK;
 }
 
@@ -1891,7 +1895,12 @@ static int check_ready(const rtxn_mlp* m, const char* who) {
     rtxn::set_error("%s: this model takes pre-encoded input (RTXN_ENC_EXTERNAL); use rtxn_mlp_train_forward", who);
     return RTXN_ERR_UNSUPPORTED;
   }
-  if (!m->packed) { rtxn::set_error("%s: rtxn_mlp_set_params has not been called", who); return RTXN_ERR_INVALID; }
+  if (!m->packed || (m->mfma16 && !m->packed16)) { rtxn::set_error("%s: rtxn_mlp_set_params has not been called", who); return RTXN_ERR_INVALID; }
+  if (!m->inference_ready) {
+    rtxn::set_error("%s: the parameters were last set with rtxn_mlp_set_params_training, which leaves the fused inference kernels' "
+                    "weights stale; call rtxn_mlp_set_params before rendering", who);
+    return RTXN_ERR_INVALID;
+  }
   return RTXN_OK;
 }
 

@@ -27,6 +27,8 @@ struct rtxn_mlp {
   int mfma16;         // inference runs mlp_fwd16_kernel (v_mfma_f32_16x16x32_f16) where the variant has one
   void* packed16;     // its A fragments (pack16_kernel)
   size_t packed16_bytes;
+  int inference_ready; // the fused inference kernels' packings (packed / packed16) hold the CURRENT parameters: set by
+                       // rtxn_mlp_set_params, cleared by rtxn_mlp_set_params_training (which re-packs the training layouts only)
 };
 
 namespace rtxn {

@@ -161,12 +161,19 @@ __device__ __forceinline__ unsigned hg_index(unsigned x, unsigned y, unsigned z,
 }
 
 // hg_index without the integer division: a hashed level's size is the table cap, a power of two (mask); a densely stored
-// level's index is below twice its size (x, y, z <= res), so one conditional subtract is the modulo.  `hashed` is uniform
-// per launch row (one level), so the choice is a scalar branch.
+// level's index is below twice its size for a position inside the domain (x, y, z <= res), so one conditional subtract is the
+// modulo.  A position OUTSIDE [-1, 1]^3 (or an Inf / NaN) reaching the public encode / backward entry points gives cell
+// coordinates beyond res: the second compare then falls back to the real `% size`, so the index stays inside the level
+// whatever the input is -- the same wrap hg_index (and tcnn's grid_index) performs; never taken for in-domain samples.
+// `hashed` is uniform per launch row (one level), so the choice is a scalar branch.
 __device__ __forceinline__ unsigned hg_index_nodiv(unsigned x, unsigned y, unsigned z, unsigned res, unsigned size, bool hashed) {
   if (hashed) return ((x * 1u) ^ (y * 2654435761u) ^ (z * 805459861u)) & (size - 1u);
-  const unsigned i = x + y * res + z * res * res;
-  return i >= size ? i - size : i;
+  unsigned i = x + y * res + z * res * res;
+  if (i >= size) {
+    i -= size;
+    if (__builtin_expect(i >= size, 0)) i %= size;
+  }
+  return i;
 }
 
 // grid.y = level (0..L-1: hash levels; L: direction frequencies + padding)

@@ -520,6 +520,7 @@ class Trainer:
                 dst.copy_(src)
         self.net.set_params_training(self.params)
         self._g_step.fill_(self.step_count)
+        self._g_step_host = self.step_count     # host mirror of the device counter (see _sync_device_step)
         clear_grads()
         torch.cuda.synchronize()
         for st in sets:
@@ -620,6 +621,14 @@ class Trainer:
                 api.adam_step_captured(self.table_master, self.table, self.dtable, self.table_m, self.table_v, lr_tab, eps=1e-15,
                                        loss_scale=ls, zero_grads=True)
 
+    def _sync_device_step(self):
+        """The captured Adam looks its bias-corrected rate up with a DEVICE step counter that only replays advance.  An eager
+        step() between two captured ones, or load_checkpoint(), moves step_count on the host alone: bring the device counter
+        back in line before the next replay (host mirror compared, no synchronisation)."""
+        if self._g_step_host != self.step_count:
+            self._g_step.fill_(self.step_count)
+            self._g_step_host = self.step_count
+
     def _check_truncation(self, k):
         th = self._g_sets[k]["total_host"]
         need = int(th[0])                  # written by an earlier replay (a stale read only delays the report)
@@ -648,12 +657,15 @@ class Trainer:
         segment count on the host: a batch without any sample still runs Adam (on a zero gradient), and a truncated batch
         is noticed a call later (truncated_steps)."""
         if getattr(self, "_graphs", None) is None:
-            raise RuntimeError("step_captured: call capture_step() first")
+            raise RuntimeError("step_captured: call capture_step() first (also after update_occupancy() on a trainer that "
+                               "was created without an occupancy grid: its graphs were dropped)")
         if not getattr(self, "_grads_clean", False):
             self._clear_grads()                       # an eager step() ran in between: its gradients are still in the buffers
+        self._sync_device_step()
         if not self._g_prefetch:
             self._check_truncation(0)
             self.step_count += 1
+            self._g_step_host += 1
             self._graphs["step"][0].replay()
             if self._g_world > 1:
                 self._finish_dp()
@@ -666,6 +678,7 @@ class Trainer:
             return None
         self._check_truncation(self._g_pending)
         self.step_count += 1
+        self._g_step_host += 1
         self._graphs["step"][k].replay()                # traverse into set k || train on set 1-k (the pending one)
         self._g_pending = k
         if self._g_world > 1:
@@ -676,11 +689,15 @@ class Trainer:
         """prefetch only: train on the batch the last step_captured() call submitted; returns its loss (None if there is none)."""
         if not getattr(self, "_g_prefetch", False) or self._g_pending is None:
             return None
+        if getattr(self, "_graphs", None) is None:
+            raise RuntimeError("flush_captured: the captured graphs were dropped (update_occupancy on a dense trainer); capture_step() again")
         if not getattr(self, "_grads_clean", False):
             self._clear_grads()
+        self._sync_device_step()
         k = self._g_pending
         self._check_truncation(k)
         self.step_count += 1
+        self._g_step_host += 1
         self._graphs["flush"][k].replay()
         self._g_pending = None
         if self._g_world > 1:
@@ -710,11 +727,30 @@ class Trainer:
             self.net.train_forward_outputs(self.encT, m, self.out, self.radiance)
             sigma[s0:s0 + m] = self.radiance[:m, 3]
         thick = sigma * (self.density_scale * 2.0 / R)
-        self.occ = api.occupancy_from_density(thick, threshold, R)
-        self.coarse = api.build_occupancy_mip(self.occ, R) if R % 4 == 0 else None
-        self.bricks = api.build_occupancy_bricks(self.occ, R) if R % 4 == 0 else None
-        self.super_mip = api.build_occupancy_mip(self.coarse, R // 4) if R % 16 == 0 else None
+        self._set_occupancy(api.occupancy_from_density(thick, threshold, R))
         return float((thick > threshold).float().mean().item())
+
+    def _set_occupancy(self, occ):
+        """Install a new occupancy bitfield.  The four traversal inputs (fine bits, 4^3 mip, bricks, 16^3 mip) keep their
+        ADDRESSES once they exist: capture_step() bakes those device pointers into the traversal nodes of its graphs, so the
+        refresh copies into the buffers the graphs read instead of re-binding the attributes (a dropped tensor's memory
+        goes back to the caching allocator and may be reused under a replay).  A trainer that started dense (occupancy=None)
+        has no buffer for the graphs to read, so its captured graphs are dropped and capture_step() must be called again."""
+        R = self.R
+        new = {"occ": occ,
+               "coarse": api.build_occupancy_mip(occ, R) if R % 4 == 0 else None}
+        new["bricks"] = api.build_occupancy_bricks(occ, R) if R % 4 == 0 else None
+        new["super_mip"] = api.build_occupancy_mip(new["coarse"], R // 4) if R % 16 == 0 else None
+        rebound = False
+        for name, t in new.items():
+            cur = getattr(self, name)
+            if cur is not None and t is not None and cur.shape == t.shape and cur.dtype == t.dtype:
+                cur.copy_(t)
+            else:
+                setattr(self, name, t)
+                rebound = rebound or (cur is not None or t is not None)
+        if rebound and getattr(self, "_graphs", None) is not None:
+            self._graphs = None            # pointers changed under the captured traversal: step_captured() asks for a re-capture
 
 
 def camera_rays(look_at, focal, width, height, device="cuda", origin_scale=0.1):

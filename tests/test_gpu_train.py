@@ -467,3 +467,64 @@ def test_live_segment_backward_of_the_saved_activation_path(gpu, W, L):
     a, b = de_full.cpu().numpy()[:, :S], de_live.cpu().numpy()[:, :S]
     np.testing.assert_array_equal(a[:, cols], b[:, cols])
     assert np.all(b[:, ~cols] == 7.0)
+
+
+def test_hashgrid_out_of_domain_positions_stay_inside_the_table(gpu, oracle):
+    """hg_index_nodiv replaced `% size` by one conditional subtract on the densely stored levels, which only covers
+    positions inside [-1, 1]^3.  Out-of-domain and non-finite positions handed to the public encode / backward entry points
+    must wrap like hg_index (the oracle's and tcnn's `% size`) and never leave the level: finite out-of-range inputs equal the
+    oracle bit for bit; Inf / NaN / huge inputs only have to stay in bounds (guard entries around the table untouched,
+    outputs finite)."""
+    torch = gpu
+    from rtx_nerf_amd import api
+    O = oracle
+    hg = api.HashGrid(6, 2, 12, 4, 1.6, n_dir_freqs=4)
+    cfg = O.hg_cfg(6, 2, 12, 4, 1.6)
+    n_par = hg.n_params()
+    assert 0 < hg.hashed_offset() < n_par                   # both kinds of level are exercised
+    rng = np.random.default_rng(5)
+    table = (rng.uniform(-1, 1, n_par)).astype(np.float16)
+    x = rng.uniform(-1, 1, (512, 5)).astype(np.float32)
+    x[:128, :3] = rng.uniform(-9, 9, (128, 3))              # finite, far outside the domain, both signs
+    x[128:160, 0] = 1.0 + 2.0 ** -20                        # just past the upper face
+    got = hg.encode(_dev(torch, table), _dev(torch, x)).cpu().numpy()[:, :512].T
+    want = O.encode_hg(cfg, 4, table, x)
+    np.testing.assert_array_equal(np.ascontiguousarray(got[:, :12]).view(np.uint16), np.ascontiguousarray(want[:, :12]).view(np.uint16))
+    # non-finite / huge: memory safety only.  The table sits between two guard blocks in one allocation.
+    bad = x.copy()
+    bad[0:8, 0] = np.inf; bad[8:16, 1] = -np.inf; bad[16:24, 2] = np.nan; bad[24:32, :3] = 3.0e38; bad[32:40, :3] = -3.0e38
+    G = 4096
+    buf = torch.zeros(n_par + 2 * G, dtype=torch.float16, device="cuda")
+    buf[G:G + n_par] = _dev(torch, table)
+    enc = hg.encode(buf[G:G + n_par], _dev(torch, bad))
+    assert torch.isfinite(enc.float()).all()
+    dtab = torch.zeros(n_par + 2 * G, dtype=torch.float32, device="cuda")
+    dtab_h = torch.zeros(n_par - hg.hashed_offset() + 2 * G, dtype=torch.float16, device="cuda")
+    denc = torch.ones_like(enc)
+    hg.backward(_dev(torch, bad), denc, dtab[G:G + n_par])
+    hg.backward_mixed(_dev(torch, bad), denc, dtab[G:G + n_par], dtab_h[G:G + n_par - hg.hashed_offset()])
+    torch.cuda.synchronize()
+    for t, n in ((dtab, n_par), (dtab_h, n_par - hg.hashed_offset())):
+        assert float(t[:G].abs().sum()) == 0.0 and float(t[G + n:].abs().sum()) == 0.0
+
+
+def test_inference_refuses_stale_weights_after_a_training_only_update(gpu):
+    """rtxn_mlp_set_params_training re-packs the training layouts only.  The fused inference kernels must then
+    refuse to run (error status, not a fault on a NULL packing and not a silent render with the old weights) until
+    rtxn_mlp_set_params is called again."""
+    torch = gpu
+    from rtx_nerf_amd import api, _lib
+    net = api.Network(n_neurons=64, n_hidden_layers=2)
+    p = net.initialize_params(3).half().cuda()
+    x = torch.rand(256, 5, device="cuda") * 2 - 1
+    net.set_params_training(p)                       # never set for inference at all
+    with pytest.raises(_lib.RtxnError, match="rtxn_mlp_set_params"):
+        net.forward(x)
+    net.set_params(p)
+    y0 = net.forward(x).clone()
+    net.set_params_training((p * 0.5).contiguous())  # a training step's update
+    with pytest.raises(_lib.RtxnError, match="stale"):
+        net.forward(x)
+    net.set_params((p * 0.5).contiguous())
+    y1 = net.forward(x)
+    assert not torch.equal(y0, y1)

@@ -329,3 +329,59 @@ def test_captured_step_on_a_batch_that_misses_the_grid(gpu):
     for _ in range(20):
         l2 = float(tr.step_captured().item())
     assert int(tr.total.item()) > 0 and np.isfinite(l2) and l2 < l1 and not torch.equal(tr.master, p0)
+
+
+def test_captured_step_sees_an_occupancy_refresh(gpu):
+    """capture_step() bakes the device pointers of the occupancy hierarchy into the traversal nodes; a refresh must
+    write into THOSE buffers (Trainer._set_occupancy) -- re-binding the attributes left the graphs traversing freed memory.
+    capture, empty the grid (threshold 1e9), replay: no ray may hit anything; fill it (threshold -1), replay: every ray that
+    enters the cube hits."""
+    torch = gpu
+    from rtx_nerf_amd import scenes
+    from rtx_nerf_amd.train import camera_rays
+    tr = _small_trainer(torch, "hash", "nerf", 64, 4)
+    B = 900
+    o, d = camera_rays(scenes.pose_spherical(40.0, -30.0, origin_scale=10.0), scenes.lego_focal_length(True), 30, 30)
+    tr.capture_step(B, launch_segments=B * 30)
+    tr.graph_rays_o.copy_(o); tr.graph_rays_d.copy_(d); tr.graph_targets.fill_(0.5)
+    tr.step_captured()
+    torch.cuda.synchronize()
+    before = int(tr.total.item())
+    ptrs = [t.data_ptr() for t in (tr.occ, tr.coarse, tr.bricks, tr.super_mip)]
+    assert before > 0
+    assert tr.update_occupancy(threshold=1e9) == 0.0
+    assert ptrs == [t.data_ptr() for t in (tr.occ, tr.coarse, tr.bricks, tr.super_mip)] and tr._graphs is not None
+    tr.step_captured()
+    torch.cuda.synchronize()
+    assert int(tr.total.item()) == 0
+    assert tr.update_occupancy(threshold=-1.0) == 1.0
+    tr.step_captured()
+    torch.cuda.synchronize()
+    assert int(tr.total.item()) > before
+
+
+def test_captured_adam_follows_the_host_step_count(gpu):
+    """the captured Adam reads its bias-corrected rate through a DEVICE step counter that only replays advance.  An
+    eager step() in between (supported) and load_checkpoint() move step_count on the host only; the next replay must use
+    the rate of step_count + 1 all the same: eager-only and mixed eager/captured runs end at the same parameters."""
+    import numpy as np
+    torch = gpu
+    from rtx_nerf_amd import scenes
+    from rtx_nerf_amd.train import camera_rays
+    a = _small_trainer(torch, "freq", "nerf", 64, 2)
+    b = _small_trainer(torch, "freq", "nerf", 64, 2)
+    B = 900
+    o, d = camera_rays(scenes.pose_spherical(40.0, -30.0, origin_scale=10.0), scenes.lego_focal_length(True), 30, 30)
+    t = torch.full((B, 3), 0.5, device="cuda")
+    b.capture_step(B, launch_segments=B * 30)
+    b.graph_rays_o.copy_(o); b.graph_rays_d.copy_(d); b.graph_targets.copy_(t)
+    for kind in ("eager", "eager", "eager", "captured", "eager", "captured"):   # the rate changes fastest in the first steps
+        a.step(o, d, t)
+        if kind == "eager":
+            b.step(o, d, t)
+        else:
+            b.step_captured()
+    torch.cuda.synchronize()
+    assert a.step_count == b.step_count == 6 and int(b._g_step.item()) == 6
+    pa, pb = a.master.cpu().numpy(), b.master.cpu().numpy()
+    assert np.linalg.norm(pa - pb) <= 2e-3 * np.linalg.norm(pa), np.linalg.norm(pa - pb) / np.linalg.norm(pa)
