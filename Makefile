@@ -12,7 +12,7 @@ all: rtx_nerf_amd/librtxn.so oracle examples/render_host
 # weight-gradient accumulators in AGPRs by hand (asm "+a"); left to its heuristic, hipcc put the destination of EVERY MFMA of
 # that kernel in AGPRs and copied each chain accumulator back for the fp16 conversion (816 v_accvgpr_read per tile).
 build/train.o: EXTRA := -mllvm -amdgpu-mfma-vgpr-form
-build/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/mlp_internal.h include/rtxn.h
+build/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/mlp_internal.h $(CSRC)/hashgrid_internal.h include/rtxn.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) $(EXTRA) -c $< -o $@
 

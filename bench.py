@@ -78,23 +78,21 @@ def pmc_traffic(samples_per_launch):
 
 
 def time_shade(pipe, poses_d, ray_begin, n_local, steps):
-    """The fused sampler+encode+MLP launch exactly as a frame makes it, bracketed by HIP events on the launch stream;
-    returns (mean kernel ms, mean samples per launch)."""
+    """The fused sampler+encode+MLP launch exactly as a frame makes it (RenderPipeline.shade_again: the same C entry point over
+    the segments a frame just left in slot 0), bracketed by HIP events on the launch stream; returns (mean kernel ms, mean
+    samples per launch)."""
     from rtx_nerf_amd import api
     ms, smp = [], []
     for i in range(steps):
         pipe.look_at.copy_(poses_d[i % len(poses_d)], non_blocking=True)
-        nh, idx = pipe.num_hits[:n_local], pipe.indices[:n_local]
-        pipe._trace(ray_begin, n_local, write=False)
-        api.scan_hits(nh, idx, pipe.total, pipe.scan_ws)
-        pipe._trace(ray_begin, n_local, write=True)
+        pipe.render(ray_begin=ray_begin, ray_count=n_local)          # leaves this pose's packed segments in slot 0
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        pipe._shade(pipe._slots[0])
+        pipe.shade_again(0)
         e1.record()
         torch.cuda.synchronize()
         ms.append(e0.elapsed_time(e1))
-        smp.append(int(pipe.total.item()) * api.NUM_SAMPLES_PER_SEGMENT)
+        smp.append(min(int(pipe.total.item()), pipe.max_segments) * api.NUM_SAMPLES_PER_SEGMENT)
     return (float(np.mean(ms)), float(np.mean(smp))) if ms else (None, 0.0)
 
 
@@ -229,8 +227,8 @@ def extra_config5(steps, warmup, kernel_steps):
                     "8x256 ReLU MLP + Composite-Frequency encoding, 32 samples/segment, 4 forward-facing poses, seeded random fp16 weights",
         "ms_per_step": round(1e3 * dt / steps, 4), "mrays_s": round(W * H * steps / dt / 1e6, 4), "steps": steps, "warmup": warmup,
         "rays_per_step": W * H, "segments_per_frame_max": worst, "mean_samples_per_ray": round(smp / (W * H), 2), "dtype": "f16",
-        "roofline": {"kernel": ("mlp_fwd256x16_kernel" if net.mfma_shape() == 16 else "mlp_fwd256_kernel") + "<3,10,2,12,segments,half4>",
-                     "mfma": "v_mfma_f32_16x16x32_f16" if net.mfma_shape() == 16 else "v_mfma_f32_32x32x16_f16", "bound": "mfma", "achieved": round(ach, 2),
+        "roofline": {"kernel": "mlp_fwd256x16_kernel<3,10,2,12,segments,half4>",
+                     "mfma": "v_mfma_f32_16x16x32_f16", "bound": "mfma", "achieved": round(ach, 2),
                      "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_DENSE_PEAK_TFLOPS, 4),
                      "traffic": None, "flop_per_sample": flops, "samples_per_launch": smp, "kernel_ms": round(ms, 4)},
     }
@@ -256,7 +254,6 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the train_config3 / config5 records (N = 1 only)")
     ap.add_argument("--extra-steps", type=int, default=30, help="timed steps of each extra record")
-    ap.add_argument("--fused", action="store_true", help="per-segment compositing in the MLP epilogue (measured slower: frame is MFMA-bound)")
     ap.add_argument("--kernel-steps", type=int, default=5, help="extra frames with HIP events around the MLP kernel")
     ap.add_argument("--no-compact", action="store_true", help="fp32 float4 radiance + t_vals between the MLP kernel and the compositor "
                     "(the reference's convertHalfToFloat layout) instead of the network's half outputs")
@@ -317,7 +314,7 @@ def main():
     sh = RowShard(W, H, 0, args.emulate_shard_of) if (args.emulate_shard_of > 1 and world == 1) else RowShard(W, H, rank, world)
     n_local, ray_begin = sh.n_local, sh.ray_begin
     pipe = render.RenderPipeline(net, R, W, H, focal, occupancy=occ, max_rays=n_local, max_segments=1024,
-                                 window=sh.window, fused=args.fused, compact=False if (args.no_compact or args.fused) else None)
+                                 window=sh.window, compact=False if args.no_compact else None)
     worst = pipe.calibrate(poses, ray_begin=ray_begin, ray_count=n_local)
     poses_d = [torch.from_numpy(p.reshape(16)).cuda() for p in poses]
 
@@ -429,11 +426,9 @@ def main():
         if ms:
             ach = flops * smp / (ms * 1e-3) / 1e12
             out["roofline"] = {
-                "kernel": ((f"mlp_fwd256x16_kernel<3,10,2,12,segments," if args.neurons == 256 else f"mlp_fwd16_kernel<{args.neurons},3,10,2,12,segments,")
-                           if net.mfma_shape() == 16 and not args.fused
-                           else f"mlp_fwd{'256' if args.neurons == 256 else ''}_kernel<{args.neurons},3,10,2,12,segments,")
-                          + f"{'segment-composite' if args.fused else ('half4' if pipe.compact else 'radiance')}>",
-                "mfma": "v_mfma_f32_16x16x32_f16" if net.mfma_shape() == 16 and not args.fused else "v_mfma_f32_32x32x16_f16",
+                "kernel": (f"mlp_fwd256x16_kernel<3,10,2,12,segments," if args.neurons == 256 else f"mlp_fwd16_kernel<{args.neurons},3,10,2,12,segments,")
+                          + f"{'half4' if pipe.compact else 'radiance'}>",
+                "mfma": "v_mfma_f32_16x16x32_f16",
                 "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": pmc_traffic(smp),
                 "flop_per_sample": flops, "samples_per_launch": smp, "kernel_ms": round(ms, 4),

@@ -221,6 +221,7 @@ typedef struct rtxn_mlp_config {
 } rtxn_mlp_config;
 
 typedef struct rtxn_mlp rtxn_mlp;
+typedef struct rtxn_hashgrid rtxn_hashgrid;   /* multiresolution hash grid: rtxn_hashgrid_create, below */
 
 int rtxn_mlp_create(const rtxn_mlp_config* cfg, rtxn_mlp** out);
 int rtxn_mlp_destroy(rtxn_mlp* m);
@@ -231,9 +232,8 @@ int rtxn_mlp_destroy(rtxn_mlp* m);
  * co-resides only if it fits the CU's left-over registers/LDS (this library's traversal, scan and compositor kernels do);
  * a collective library's kernels may not.  n_cus > 0 keeps that many CUs free of MLP blocks (default 0). */
 int rtxn_mlp_set_reserved_cus(rtxn_mlp* m, int n_cus);
-/* Which fused inference kernel the model runs: 16 = mlp_fwd16_kernel (v_mfma_f32_16x16x32_f16, the default for the 64- and
- * 128-wide models), 32 = the 32x32x16 kernels (the 256-wide model; the per-segment compositor epilogue; or any model
- * created while the environment has RTXN_MFMA_SHAPE=32, the A/B switch); 0 = no fused inference kernel (RTXN_ENC_EXTERNAL). */
+/* MFMA shape of the model's fused inference kernel: 16 = v_mfma_f32_16x16x32_f16 (every Composite-Frequency model);
+ * 0 = no fused inference kernel (RTXN_ENC_EXTERNAL: use rtxn_hashmlp_forward_segments or the rtxn_mlp_train_* entry points). */
 int rtxn_mlp_mfma_shape(const rtxn_mlp* m);
 long rtxn_mlp_n_params(const rtxn_mlp* m);
 int rtxn_mlp_padded_output_width(const rtxn_mlp* m); /* 16 (main.cu:715) */
@@ -273,22 +273,117 @@ int rtxn_mlp_forward_segments_compact(const rtxn_mlp* m, const float* start_poin
                                       void* radiance_half4, rtxn_stream_t stream);
 int rtxn_volrender_fwd_compact(const void* radiance_half4, const int* num_hits, const int* indices, int batch_size,
                                int num_samples_per_hit, float* pixels, rtxn_stream_t stream);
+/* The same hand-over for RTXN_VR_NERF (midpoint samples, exclusive transmittance): every sample of a segment has the same
+ * world-space step |end - start| / K (x density scale), so the compositor takes ONE float per segment (segment_step[P], written
+ * by rtxn_hashmlp_forward_segments) instead of launch_volrender_cuda's ray_hit[P*K].  Pixels bit-identical to
+ * rtxn_volrender_fwd(RTXN_VR_NERF) on the widened radiance and the expanded steps. */
+int rtxn_volrender_fwd_compact_nerf(const void* radiance_half4, const float* segment_step, const int* num_hits,
+                                    const int* indices, int batch_size, int num_samples_per_hit, float* pixels,
+                                    rtxn_stream_t stream);
 
-/* Fused compositor, first half: as rtxn_mlp_forward_segments, but instead of per-sample radiance the kernel
- * composites each segment's 32 samples in its epilogue and writes ONE record per segment,
- * seg_out[s] = (C_r, C_g, C_b, X) with C = sum_i w_i c_i and X = sum_i delta_i sigma_i over the segment
- * (16 B/segment instead of 20 B/sample).  mode RTXN_VR_COMPAT: the reference arithmetic (delta = 1/32, and 31/32
- * at the first sample of every later segment of a ray -- seg_first from rtxn_trace_grid says which; inclusive
- * transmittance); RTXN_VR_NERF: samples at sub-interval midpoints, delta = |end-start|/32 * step_scale, exclusive
- * transmittance.  Second half: rtxn_composite_segments. */
-int rtxn_mlp_forward_segments_composite(const rtxn_mlp* m, const float* start_points, const float* end_points,
-                                        const float* seg_view, const uint8_t* seg_first, const int* total_segments,
-                                        long max_segments, float* seg_out, int mode, float step_scale,
-                                        rtxn_stream_t stream);
-/* pixels[r] = sum over the ray's segments of exp(-sum of earlier X) * C  (replaces launch_volrender_cuda when the
- * first half ran; num_hits/indices as there). */
-int rtxn_composite_segments(const float* seg_out, const int* num_hits, const int* indices, int batch_size, float* pixels,
-                            rtxn_stream_t stream);
+/* ---- hash-grid inference -------------------------------------------------------------------------------------------
+ * launchSampler + HashGrid(position) (+) Frequency(direction) encoding + network->forward + the half outputs' glue
+ * (main.cu:703-728 with the hash-grid model north_star names) as ONE kernel over packed segments: the hash-grid counterpart of
+ * rtxn_mlp_forward_segments_compact.  `m` is the pre-encoded (RTXN_ENC_EXTERNAL) model a training loop trains with
+ * rtxn_hashgrid_encode_segments + rtxn_mlp_train_forward_outputs; this entry point computes the SAME values as that staged
+ * pair in one pass, without the half[E][S] encoding in memory.  sample_type RTXN_SAMPLING_REGULAR | RTXN_SAMPLING_MIDPOINT_WORLD.
+ * radiance_half4: half[max_segments*32][4]; segment_step (may be NULL): float[max_segments], for MIDPOINT_WORLD the
+ * world-space step |end - start| / 32 x t_scale of each segment -- what rtxn_volrender_fwd_compact_nerf consumes.
+ * *total_segments: device int (rtxn_scan_hits' total), clamped to max_segments.
+ * rtxn_hashmlp_supported: 1 if the fused kernel is built for this model / grid pair (64 wide, 1..8 hidden layers, 2 features
+ * per level, an even number of levels, encoded width <= 64), else 0 (the entry point then returns RTXN_ERR_UNSUPPORTED). */
+int rtxn_hashmlp_supported(const rtxn_mlp* m, const rtxn_hashgrid* g, int n_dir_freqs);
+int rtxn_hashmlp_forward_segments(const rtxn_mlp* m, const rtxn_hashgrid* g, int n_dir_freqs, const void* table_fp16,
+                                  const float* start_points, const float* end_points, const float* seg_view,
+                                  const int* total_segments, long max_segments, int sample_type, float t_scale,
+                                  void* radiance_half4, float* segment_step, rtxn_stream_t stream);
+
+/* ---- one frame behind one call ------------------------------------------------------------------------------------
+ * The per-image host sequence of the reference -- fill Params and optixLaunch (main.cu:473-508), copy every traversal
+ * buffer to the host and re-pack it (:510-543, :646-673), thrust compaction (:631-637), launchSampler (:704),
+ * network->forward (:721), convertHalfToFloat (:723-728), launch_volrender_cuda (:737) -- as ONE entry point that
+ * enqueues   trace(count) -> scan -> trace(write packed CSR) -> sampler+encode+MLP (one kernel) -> composite
+ * for a window of the width x height launch, with the segment count, the capacity clamp and the overflow flag all in
+ * device memory: nothing synchronises the host, so rtxn_render_frame is hipGraph-capturable.
+ *
+ * rtxn_render owns no device memory of its own: the caller hands rtxn_render_create one workspace of
+ * rtxn_render_workspace_bytes(cfg) bytes (256-byte aligned) in which the per-frame buffers of `n_slots` frames in flight
+ * and the occupancy hierarchy (4^3 mip, bricks, 16^3 mip: rtxn_build_occupancy_*) are laid out.  Streams and events of the
+ * pipelined form are created by rtxn_render_create and released by rtxn_render_destroy.
+ *
+ * Radiance model: `mlp` alone = a Composite-Frequency model (the fused inference kernels; rtxn_mlp_set_params must have run);
+ * `mlp` + `grid` + `table_fp16` = multiresolution hash grid + Frequency(n_dir_freqs) directions feeding a pre-encoded
+ * (RTXN_ENC_EXTERNAL) 64-wide model through rtxn_hashmlp_forward_segments (rtxn_mlp_set_params[_training] must have run;
+ * the table is read at frame time, so a training loop may keep updating it in place). */
+enum rtxn_render_flags {
+  RTXN_RENDER_FLOAT4 = 1    /* hand the compositor the reference's float4 radiance + float t_vals (convertHalfToFloat layout,
+                             * 20 B/sample) instead of the network's own half4 outputs (8 B/sample); same pixels bit for bit */
+};
+typedef struct rtxn_render_config {
+  const rtxn_mlp* mlp;
+  const rtxn_hashgrid* grid;      /* NULL: frequency model */
+  const void* table_fp16;         /* hash grid only (device) */
+  int n_dir_freqs;                /* hash grid only */
+  uint32_t width, height;         /* the launch (params.h:41) */
+  float focal_length, aspect_ratio;
+  uint32_t max_rays;              /* largest ray window a frame call will ask for (0 = width*height) */
+  uint32_t window_chunk, window_stride;  /* ray interleave of this shard, as rtxn_trace_params */
+  int grid_res;
+  const uint32_t* occupancy;      /* R^3 bits (device) or NULL = dense; read at rtxn_render_create / rtxn_render_set_occupancy
+                                   * (hierarchy build) and by every frame */
+  int trace_mode;                 /* enum rtxn_trace_mode */
+  int sub_rays;                   /* RTXN_TRACE_DDA: lanes per ray (rtxn_trace_params.sub_rays); 0 = 1 */
+  int vr_mode;                    /* enum rtxn_volrender_mode */
+  int sample_type;                /* RTXN_SAMPLING_REGULAR (frequency model: the only one) | RTXN_SAMPLING_MIDPOINT_WORLD */
+  float step_scale;               /* RTXN_VR_NERF: density scale on the world-space step */
+  long max_segments;              /* capacity of the packed segment buffers; a frame that needs more is truncated on the
+                                   * device (never out of bounds) and reported by rtxn_render_status */
+  int n_slots;                    /* frames in flight for rtxn_render_frame_async: 1..4 */
+  int flags;                      /* enum rtxn_render_flags */
+} rtxn_render_config;
+typedef struct rtxn_render rtxn_render;
+
+typedef struct rtxn_render_stats {
+  long frames;              /* frames enqueued so far */
+  long frames_checked;      /* of those, frames whose segment count has reached the host */
+  long overflow_frames;     /* checked frames that needed more than max_segments (delivered truncated) */
+  long max_segments_needed; /* largest segment count seen */
+  long last_segments;       /* segment count of the most recently checked frame */
+  long max_segments;        /* the capacity */
+} rtxn_render_stats;
+
+size_t rtxn_render_workspace_bytes(const rtxn_render_config* cfg);
+int rtxn_render_create(const rtxn_render_config* cfg, void* workspace, size_t workspace_bytes, rtxn_render** out);
+int rtxn_render_destroy(rtxn_render* r);
+/* Rebuild the occupancy hierarchy after the bits behind cfg->occupancy changed (or point the renderer at another bitfield
+ * of the same resolution). */
+int rtxn_render_set_occupancy(rtxn_render* r, const uint32_t* occupancy, rtxn_stream_t stream);
+/* Counting pass + scan for one pose: *segments (HOST) = packed segments the window needs.  Synchronises `stream`; for sizing
+ * max_segments outside any timed region (the reference sizes by 3R slots per ray, main.cu:486). */
+int rtxn_render_count_segments(rtxn_render* r, const float* look_at, uint32_t ray_begin, uint32_t ray_count, long* segments,
+                               rtxn_stream_t stream);
+/* One frame (or one shard of it: rays [ray_begin, ray_begin + ray_count) of the launch under the configured interleave) on
+ * ONE stream, using buffer slot `slot`.  look_at: 16 floats on the DEVICE, copied into the slot first.  pixels:
+ * float[ray_count][3].  Nothing synchronises; capturable. */
+int rtxn_render_frame(rtxn_render* r, int slot, const float* look_at, uint32_t ray_begin, uint32_t ray_count, float* pixels,
+                      rtxn_stream_t stream);
+/* The same frame software-pipelined against its neighbours: traversal on an internal stream, the MLP kernel on `stream`,
+ * the compositor on a second internal stream, rotating through the n_slots buffer slots, so that under the MLP kernel of
+ * frame i the chip also traverses frame i+1 and composites frame i-1.  *composite_stream (may be NULL) receives the stream
+ * the pixels are complete on: enqueue follow-up work on the pixels there (a gather, a copy), or call rtxn_render_drain. */
+int rtxn_render_frame_async(rtxn_render* r, const float* look_at, uint32_t ray_begin, uint32_t ray_count, float* pixels,
+                            rtxn_stream_t stream, rtxn_stream_t* composite_stream);
+/* Make `stream` wait for everything rtxn_render_frame_async has enqueued on the internal streams. */
+int rtxn_render_drain(rtxn_render* r, rtxn_stream_t stream);
+/* Overflow report without polling the device: every frame copies its segment count to pinned host memory (4 bytes, async);
+ * this looks at the counts that have arrived (wait != 0: synchronises the device first, so every enqueued frame is seen). */
+int rtxn_render_status(rtxn_render* r, int wait, rtxn_render_stats* out);
+/* Device buffers of a slot for inspection (tests, profiling tools); any out pointer may be NULL.  num_stored = segments
+ * actually written per ray; t_vals: RTXN_RENDER_FLOAT4 only, segment_step: compact RTXN_VR_NERF only (else NULL). */
+int rtxn_render_slot_buffers(rtxn_render* r, int slot, const int** num_hits, const int** num_stored, const int** indices,
+                             const int** total_segments, const float** start_points, const float** end_points,
+                             const float** seg_view, const void** radiance, const float** t_vals, const float** segment_step,
+                             const float** viewing_direction);
 
 /* ---- training path (tiny-cuda-nn surface of main.cu:721-787) ------------------------ */
 /* Per-sample training tensors are FEATURE-MAJOR fp16: X[feature][S_pad] with
@@ -307,7 +402,6 @@ typedef struct rtxn_hashgrid_config {
   int base_resolution;
   float per_level_scale;
 } rtxn_hashgrid_config;
-typedef struct rtxn_hashgrid rtxn_hashgrid;
 int rtxn_hashgrid_create(const rtxn_hashgrid_config* cfg, rtxn_hashgrid** out);
 int rtxn_hashgrid_destroy(rtxn_hashgrid* g);
 long rtxn_hashgrid_n_params(const rtxn_hashgrid* g);                 /* fp16 table entries */

@@ -94,6 +94,22 @@ class TrainBatch(C.Structure):
                 ("dparams", C.c_void_p), ("dtable", C.c_void_p), ("dtable_hashed_half", C.c_void_p), ("live_ws", C.c_void_p)]
 
 
+class RenderConfig(C.Structure):
+    """struct rtxn_render_config (include/rtxn.h)."""
+    _fields_ = [("mlp", C.c_void_p), ("grid", C.c_void_p), ("table_fp16", C.c_void_p), ("n_dir_freqs", C.c_int),
+                ("width", C.c_uint32), ("height", C.c_uint32), ("focal_length", C.c_float), ("aspect_ratio", C.c_float),
+                ("max_rays", C.c_uint32), ("window_chunk", C.c_uint32), ("window_stride", C.c_uint32), ("grid_res", C.c_int),
+                ("occupancy", C.c_void_p), ("trace_mode", C.c_int), ("sub_rays", C.c_int), ("vr_mode", C.c_int),
+                ("sample_type", C.c_int), ("step_scale", C.c_float), ("max_segments", C.c_long), ("n_slots", C.c_int),
+                ("flags", C.c_int)]
+
+
+class RenderStats(C.Structure):
+    """struct rtxn_render_stats (include/rtxn.h)."""
+    _fields_ = [(n, C.c_long) for n in ("frames", "frames_checked", "overflow_frames", "max_segments_needed", "last_segments",
+                                        "max_segments")]
+
+
 # every symbol include/rtxn.h declares: name -> (restype, argtypes)
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_long, C.c_float
 SYMBOLS = {
@@ -124,8 +140,19 @@ SYMBOLS = {
     "rtxn_mlp_forward_segments": (_I, [_P, _P, _P, _P, _P, _L, _P, _P, _P]),
     "rtxn_mlp_forward_segments_compact": (_I, [_P, _P, _P, _P, _P, _L, _P, _P]),
     "rtxn_volrender_fwd_compact": (_I, [_P, _P, _P, _I, _I, _P, _P]),
-    "rtxn_mlp_forward_segments_composite": (_I, [_P, _P, _P, _P, _P, _P, _L, _P, _I, _F, _P]),
-    "rtxn_composite_segments": (_I, [_P, _P, _P, _I, _P, _P]),
+    "rtxn_volrender_fwd_compact_nerf": (_I, [_P, _P, _P, _P, _I, _I, _P, _P]),
+    "rtxn_hashmlp_supported": (_I, [_P, _P, _I]),
+    "rtxn_hashmlp_forward_segments": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _L, _I, _F, _P, _P, _P]),
+    "rtxn_render_workspace_bytes": (C.c_size_t, [C.POINTER(RenderConfig)]),
+    "rtxn_render_create": (_I, [C.POINTER(RenderConfig), _P, C.c_size_t, C.POINTER(_P)]),
+    "rtxn_render_destroy": (_I, [_P]),
+    "rtxn_render_set_occupancy": (_I, [_P, _P, _P]),
+    "rtxn_render_count_segments": (_I, [_P, _P, C.c_uint32, C.c_uint32, C.POINTER(C.c_long), _P]),
+    "rtxn_render_frame": (_I, [_P, _I, _P, C.c_uint32, C.c_uint32, _P, _P]),
+    "rtxn_render_frame_async": (_I, [_P, _P, C.c_uint32, C.c_uint32, _P, _P, C.POINTER(_P)]),
+    "rtxn_render_drain": (_I, [_P, _P]),
+    "rtxn_render_status": (_I, [_P, _I, C.POINTER(RenderStats)]),
+    "rtxn_render_slot_buffers": (_I, [_P, _I] + [C.POINTER(_P)] * 11),
     "rtxn_padded_samples": (_L, [_L]),
     "rtxn_encode_frequency": (_I, [_P, _P, _P, _L, _P]),
     "rtxn_hashgrid_create": (_I, [C.POINTER(HashGridConfig), C.POINTER(_P)]),

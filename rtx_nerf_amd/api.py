@@ -225,7 +225,7 @@ class Network:
         return int(_lib.lib().rtxn_mlp_encoded_width(self._h))
 
     def mfma_shape(self):
-        """16: mlp_fwd16_kernel (v_mfma_f32_16x16x32_f16); 32: the 32x32x16 kernels; 0: no fused inference kernel."""
+        """16: the fused inference kernels (v_mfma_f32_16x16x32_f16); 0: no fused inference kernel (pre-encoded input)."""
         return int(_lib.lib().rtxn_mlp_mfma_shape(self._h))
 
     def flops_per_sample(self):
@@ -306,25 +306,31 @@ def volrender_compact(radiance_half4, num_hits, indices, batch_size, num_samples
           "rtxn_volrender_fwd_compact")
 
 
-def _net_forward_segments_composite(self, start_points, end_points, seg_view, seg_first, total_segments, max_segments,
-                                    seg_out, mode=VR_COMPAT, step_scale=1.0):
-    """sampler + forward + glue + the per-segment half of the compositor in one launch (16 B/segment out)."""
-    check(_lib.lib().rtxn_mlp_forward_segments_composite(
-        self._h, _ptr(start_points, torch.float32, "start_points"), _ptr(end_points, torch.float32, "end_points"),
-        _ptr(seg_view, torch.float32, "seg_view"), _ptr(seg_first, torch.uint8, "seg_first"),
-        _ptr(total_segments, torch.int32, "total_segments"), max_segments, _ptr(seg_out, torch.float32, "seg_out"), mode,
-        step_scale, _stream()), "rtxn_mlp_forward_segments_composite")
-    return seg_out
+def volrender_compact_nerf(radiance_half4, segment_step, num_hits, indices, batch_size, num_samples_per_hit, pixels):
+    """RTXN_VR_NERF compositing of half[N, 4] radiance with ONE step length per segment (float[P])."""
+    check(_lib.lib().rtxn_volrender_fwd_compact_nerf(_ptr(radiance_half4, torch.float16, "radiance_half4"),
+                                                     _ptr(segment_step, torch.float32, "segment_step"),
+                                                     _ptr(num_hits, torch.int32, "num_hits"), _ptr(indices, torch.int32, "indices"),
+                                                     batch_size, num_samples_per_hit, _ptr(pixels, torch.float32, "pixels"), _stream()),
+          "rtxn_volrender_fwd_compact_nerf")
 
 
-Network.forward_segments_composite = _net_forward_segments_composite
+def hashmlp_supported(net, grid):
+    """True if the fused hash-encode + MLP inference kernel is built for this model / grid pair."""
+    return bool(_lib.lib().rtxn_hashmlp_supported(net._h, grid._h, grid.n_dir_freqs))
 
 
-def composite_segments(seg_out, num_hits, indices, batch_size, pixels):
-    """second half of the fused compositor (replaces launch_volrender_cuda after forward_segments_composite)."""
-    check(_lib.lib().rtxn_composite_segments(_ptr(seg_out, torch.float32, "seg_out"), _ptr(num_hits, torch.int32, "num_hits"),
-                                             _ptr(indices, torch.int32, "indices"), batch_size,
-                                             _ptr(pixels, torch.float32, "pixels"), _stream()), "rtxn_composite_segments")
+def hashmlp_forward_segments(net, grid, table_fp16, start_points, end_points, seg_view, total_segments, max_segments, radiance_half4,
+                             sample_type=SAMPLING_REGULAR, t_scale=1.0, segment_step=None):
+    """launchSampler + HashGrid/Frequency encoding + network->forward + glue as one kernel over packed segments (the hash-grid
+    counterpart of Network.forward_segments_compact): half[N, 4] radiance, optionally the per-segment world step."""
+    check(_lib.lib().rtxn_hashmlp_forward_segments(
+        net._h, grid._h, grid.n_dir_freqs, _ptr(table_fp16, torch.float16, "table"), _ptr(start_points, torch.float32, "start_points"),
+        _ptr(end_points, torch.float32, "end_points"), _ptr(seg_view, torch.float32, "seg_view"),
+        _ptr(total_segments, torch.int32, "total_segments"), int(max_segments), int(sample_type), float(t_scale),
+        _ptr(radiance_half4, torch.float16, "radiance_half4"), _ptr(segment_step, torch.float32, "segment_step"), _stream()),
+        "rtxn_hashmlp_forward_segments")
+    return radiance_half4
 
 
 # --------------------------------------------------------------------------- training path

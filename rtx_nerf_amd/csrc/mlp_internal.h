@@ -13,25 +13,29 @@ struct rtxn_mlp {
   rtxn_mlp_config cfg;
   int enc_width;    // encoded features before padding
   int enc_padded;   // multiple of 16, padding features are 1.0 (= first-layer in_width of the params)
-  int k0;           // inference kernel: first-layer K as staged (multiple of 16 covering all encode slots)
+  int k0;           // inference kernel: first-layer K as staged (multiple of 32 covering all encode dwords)
   long n_params;
   int variant;      // index into the inference kernel table, -1 if this model has no fused inference kernel
   int reserved_cus; // CUs the persistent inference grid leaves free (rtxn_mlp_set_reserved_cus)
   // device buffers owned by the model, (re)built by rtxn_mlp_set_params
-  void* packed;       // inference: A fragments, layer 0 in the sin/cos-pair slot order
+  void* packed;       // inference (v_mfma_f32_16x16x32_f16): A fragments, layer 0 in the lane-group frequency-block order (pack16_kernel)
   size_t packed_bytes;
   void* packed_train; // training forward: A fragments, every layer in the accumulator-permuted k order
   size_t packed_train_bytes;
   void* packed_t;     // training backward: A fragments of the TRANSPOSED layers (dA = W^T dZ)
   size_t packed_t_bytes;
-  int mfma16;         // inference runs mlp_fwd16_kernel (v_mfma_f32_16x16x32_f16) where the variant has one
-  void* packed16;     // its A fragments (pack16_kernel)
-  size_t packed16_bytes;
   int inference_ready; // the fused inference kernels' packings (packed / packed16) hold the CURRENT parameters: set by
                        // rtxn_mlp_set_params, cleared by rtxn_mlp_set_params_training (which re-packs the training layouts only)
 };
 
 namespace rtxn {
+
+// hashmlp.hip: network->forward on pre-encoded input, outputs only, on the 16x16x32 all-asm pipeline with every weight resident
+// in LDS (64-wide models).  total_segments != NULL: the live sample count is read on the device (32 x *total_segments,
+// clamped to `capacity` segments) and n_samples is the capacity the grid is sized for.
+bool enc_forward16_supported(const rtxn_mlp* m);
+int launch_enc_forward16(const rtxn_mlp* m, const void* encT, long n_samples, long Sp, const int* total_segments, int capacity,
+                         void* output_half, float* radiance, hipStream_t stream);
 
 // The output activation of every MLP kernel: 1 / (1 + exp(-z)) with the hardware exponential and reciprocal (v_exp_f32,
 // v_rcp_f32: 1 ulp each).  A plain `1.0f / x` is an IEEE division, ten instructions per value in an epilogue that sits on the
@@ -257,58 +261,6 @@ __device__ __forceinline__ void pipe_layer(const uint8_t* lds_buf, const StageJo
   if constexpr (D > 2 && N > 2) lds_read_frag<2048>(ring[2 % D], addr);
   if constexpr (D > 3 && N > 3) lds_read_frag<3072>(ring[3 % D], addr);
   PipeStep<RT, KS, NB, CT, PEND, 0>::run(addr, bf, nbf, ring, acc, sj, wave_u, lane);
-}
-
-// The same pipeline for the 256-wide kernel: one 32-sample column tile per wave (CT = 1), 8 waves, weights streamed in
-// chunks of two row tiles (2 x KS fragments).  Row tile r of the chunk is global row tile RT0 + r of the layer and
-// feeds out[2*(RT0+r)], out[2*(RT0+r)+1].  acc[1] always arrives holding the previous chunk's second row tile: it belongs
-// to out[] of this layer (RT0 > 0) or, for the first chunk of a layer, to the last two fragments of in[] (PEND says
-// whether there is one at all).  With a single accumulator chain per wave a slice may not read the tile finished by the
-// MFMA issued just before it, so slices start one k-step late.
-template <int KS, int NB, int NR, int RT0, bool PEND, int I>
-struct PipeStep256 {
-  static constexpr int D = RTXN_PIPE, N = NR * KS, WAVES = 8;       // NR = 1: the output layer's single row tile
-  static constexpr int SPAN = KS - 4 > 1 ? KS - 4 : 1;              // k-steps 1..SPAN carry the 8 units of a finished tile
-  static constexpr int U = (8 + SPAN - 1) / SPAN;
-  static constexpr int CHUNKS = 4;                                  // 32 KiB / (8 waves x 1 KiB)
-  __device__ static __forceinline__ void run(unsigned addr, half8 (&in)[NB][1], half8 (&out)[NB][1], half8 (&ring)[D],
-                                             floatx16 (&acc)[2][1], const StageJob& sj, int wave_u, int lane) {
-    constexpr int r = I / KS, kk = I % KS;
-    constexpr int outstanding = (N - 1 - I) < (D - 1) ? (N - 1 - I) : (D - 1);
-    lds_wait<outstanding>();
-    const half8 a = ring[I % D];
-    if (kk == 0) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[r][0][e] = 0.0f;
-    }
-    acc[r][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, in[kk][0], acc[r][0], 0, 0, 0);
-    if constexpr (kk >= 1 && kk <= SPAN) {
-      if constexpr (r == 1) convert_slice<NB, 1, U, kk - 1>(acc[0], out, 2 * RT0);
-      else if constexpr (PEND && RT0 > 0) convert_slice<NB, 1, U, kk - 1>(acc[1], out, 2 * (RT0 - 1));
-      else if constexpr (PEND) convert_slice<NB, 1, U, kk - 1>(acc[1], in, NB - 2);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (I + D < N) lds_read_frag<(I + D) * 1024>(ring[I % D], addr);
-    if constexpr (I < CHUNKS) {
-      stage_chunk<I, WAVES>(sj, wave_u, lane);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if constexpr (I + 1 < N) PipeStep256<KS, NB, NR, RT0, PEND, I + 1>::run(addr, in, out, ring, acc, sj, wave_u, lane);
-  }
-};
-
-template <int KS, int NB, int NR, int RT0, bool PEND>
-__device__ __forceinline__ void pipe_chunk256(const uint8_t* lds_buf, const StageJob& sj, half8 (&in)[NB][1], half8 (&out)[NB][1],
-                                              floatx16 (&acc)[2][1], int wave_u, int lane) {
-  constexpr int D = RTXN_PIPE;
-  static_assert(!PEND || RT0 > 0 || KS == NB, "a tile pending across a layer boundary lands in in[NB-2], in[NB-1]");
-  half8 ring[D];
-  const unsigned addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) uint8_t*)lds_buf + lane * 16;
-  lds_read_frag<0>(ring[0], addr);
-  if constexpr (D > 1) lds_read_frag<1024>(ring[1 % D], addr);
-  if constexpr (D > 2) lds_read_frag<2048>(ring[2 % D], addr);
-  if constexpr (D > 3) lds_read_frag<3072>(ring[3 % D], addr);
-  PipeStep256<KS, NB, NR, RT0, PEND, 0>::run(addr, in, out, ring, acc, sj, wave_u, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

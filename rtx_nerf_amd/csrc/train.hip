@@ -24,6 +24,7 @@
 //   hashgrid_backward_kernel  scatter-add of denc into the table gradient (fp32 atomics)
 //   l2_loss_kernel, adam_kernel
 #include "mlp_internal.h"
+#include "hashgrid_internal.h"
 
 #include <algorithm>
 #include <cmath>
@@ -32,12 +33,6 @@
 #include <mutex>
 #include <vector>
 
-struct rtxn_hashgrid {
-  rtxn_hashgrid_config cfg;
-  long n_params;
-  float scale[32];
-  unsigned res[32], size[32], offset[32];
-};
 
 namespace {
 
@@ -46,6 +41,11 @@ using rtxn::out_mma;
 using rtxn::pack8;
 using rtxn::perm_feature;
 using rtxn::stage_rt;
+using rtxn::HgLevels;
+using rtxn::hg_index;
+using rtxn::hg_index_nodiv;
+using rtxn::levels_of;
+using rtxn::sin_turns;
 
 constexpr int kThreads = 256;
 constexpr int kTile = 256;
@@ -70,11 +70,6 @@ __device__ __forceinline__ long padded_dev(long S) { return (S + kTile - 1) / kT
 constexpr long kMaxTrainSamples = (1L << 32) / 10 - kTile;
 
 // ------------------------------------------------------------------------- encoders
-__device__ __forceinline__ float sin_turns(float x, int f, int ph) {
-  // sin(pi * 2^f * x + ph*pi/2) with an exact argument reduction
-  return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(ldexpf(x, f - 1)) + 0.25f * (float)ph);
-}
-
 // Where a kernel's samples come from: a materialised float[S][5] batch (the sampler's output, sampler/sampler.cu), or the
 // packed segments themselves -- sample (segment g, i) is then formed here exactly as sample_kernel forms it (REGULAR: t = i/32;
 // MIDPOINT_WORLD: t = (i + 0.5)/32; position = fma(t, end - start, start); (theta, phi) = the segment's), so the 20-byte
@@ -144,36 +139,6 @@ __global__ __launch_bounds__(kThreads) void encode_freq_kernel(SampleSrc src, _F
     for (int f = 0; f < DF; ++f)
       for (int ph = 0; ph < 2; ++ph, ++j) encT[(long)j * Sp + s] = ok ? (_Float16)sin_turns(x[PD + d], f, ph) : (_Float16)0.0f;
   for (; j < E; ++j) encT[(long)j * Sp + s] = ok ? (_Float16)1.0f : (_Float16)0.0f;
-}
-
-struct HgLevels {
-  float scale[16];
-  unsigned res[16], size[16], offset[16];
-  int n_levels, n_features;
-};
-
-__device__ __forceinline__ unsigned hg_index(unsigned x, unsigned y, unsigned z, unsigned res, unsigned size) {
-  const unsigned long long dense = (unsigned long long)res * res * res;
-  // the +1 corner of a boundary cell indexes one past the level's extent; like tcnn's grid_index the
-  // result is reduced modulo the level size, so it wraps instead of leaving the level
-  if (dense <= size) return (x + y * res + z * res * res) % size;
-  return ((x * 1u) ^ (y * 2654435761u) ^ (z * 805459861u)) % size;
-}
-
-// hg_index without the integer division: a hashed level's size is the table cap, a power of two (mask); a densely stored
-// level's index is below twice its size for a position inside the domain (x, y, z <= res), so one conditional subtract is the
-// modulo.  A position OUTSIDE [-1, 1]^3 (or an Inf / NaN) reaching the public encode / backward entry points gives cell
-// coordinates beyond res: the second compare then falls back to the real `% size`, so the index stays inside the level
-// whatever the input is -- the same wrap hg_index (and tcnn's grid_index) performs; never taken for in-domain samples.
-// `hashed` is uniform per launch row (one level), so the choice is a scalar branch.
-__device__ __forceinline__ unsigned hg_index_nodiv(unsigned x, unsigned y, unsigned z, unsigned res, unsigned size, bool hashed) {
-  if (hashed) return ((x * 1u) ^ (y * 2654435761u) ^ (z * 805459861u)) & (size - 1u);
-  unsigned i = x + y * res + z * res * res;
-  if (i >= size) {
-    i -= size;
-    if (__builtin_expect(i >= size, 0)) i %= size;
-  }
-  return i;
 }
 
 // grid.y = level (0..L-1: hash levels; L: direction frequencies + padding)
@@ -1578,15 +1543,6 @@ int check_train(const rtxn_mlp* m, const char* who) {
   return RTXN_OK;
 }
 
-HgLevels levels_of(const rtxn_hashgrid* g) {
-  HgLevels lv;
-  memset(&lv, 0, sizeof(lv));
-  lv.n_levels = g->cfg.n_levels;
-  lv.n_features = g->cfg.n_features;
-  for (int l = 0; l < g->cfg.n_levels; ++l) { lv.scale[l] = g->scale[l]; lv.res[l] = g->res[l]; lv.size[l] = g->size[l]; lv.offset[l] = g->offset[l]; }
-  return lv;
-}
-
 }  // namespace
 
 // ============================================================================ C ABI
@@ -1672,6 +1628,12 @@ static int train_forward_impl(const rtxn_mlp* m, const void* encT, long n_sample
                               float* radiance, DevCount dc, rtxn_stream_t stream) {
   const int W = m->cfg.n_neurons;
   const long Sp = padded(n_samples);
+  // outputs only, 64 wide: the all-asm 16x16x32 kernel with the weights resident in LDS (hashmlp.hip) -- the same layer stack
+  // the fused hash-grid inference kernel runs.  RTXN_TRAIN_FWD16=0: the 32x32x16 kernel below (A/B).
+  if (!workspace && rtxn::enc_forward16_supported(m)) {
+    static const bool use16 = !(getenv("RTXN_TRAIN_FWD16") && atoi(getenv("RTXN_TRAIN_FWD16")) == 0);
+    if (use16) return rtxn::launch_enc_forward16(m, encT, n_samples, Sp, dc.total_segments, dc.capacity, output_half, radiance, rtxn::as_stream(stream));
+  }
   TrainArgs a;
   memset(&a, 0, sizeof(a));
   a.packed = static_cast<const uint8_t*>(m->packed_train);

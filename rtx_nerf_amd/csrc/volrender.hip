@@ -54,9 +54,10 @@ struct alignas(8) half4 {
   __half x, y, z, w;
 };
 
-// COMPACT: radiance is half[N][4] (the network's own output, 8 B/sample instead of 16) and t_vals are not read at all:
-// REGULAR sampling makes them the function (i + 1) / K of the sample index (sampler.cu:52-66).  Same arithmetic from there
-// on, so the pixels are bit-identical to the float4 + t_vals form at 40 % of its bytes.
+// COMPACT: radiance is half[N][4] (the network's own output, 8 B/sample instead of 16) and per-sample t_vals are not read at
+// all.  RTXN_VR_COMPAT: REGULAR sampling makes them the function (i + 1) / K of the sample index (sampler.cu:52-66);
+// RTXN_VR_NERF: every sample of a segment has the same world-space step, so `ray_hit` is one float per SEGMENT (4 B per K
+// samples).  Same arithmetic from there on, so the pixels are bit-identical to the float4 + t_vals form at 40 % of its bytes.
 template <int MODE, bool COMPACT = false>
 __global__ __launch_bounds__(256) void volrender_fwd_kernel(const float4* __restrict__ radiance,
                                                             const int* __restrict__ num_hits,
@@ -78,7 +79,8 @@ __global__ __launch_bounds__(256) void volrender_fwd_kernel(const float4* __rest
       if (COMPACT) {
         const half4 c16 = reinterpret_cast<const half4*>(radiance)[base + s0 + lane];
         c = make_float4(__half2float(c16.x), __half2float(c16.y), __half2float(c16.z), __half2float(c16.w));
-        t = (float)((int)((s0 + lane) % K) + 1) * (1.0f / (float)K);
+        if (MODE == RTXN_VR_COMPAT) t = (float)((int)((s0 + lane) % K) + 1) * (1.0f / (float)K);
+        else t = ray_hit[(base + s0 + lane) / K];       // compact NERF: one step length per SEGMENT
       } else {
         c = radiance[base + s0 + lane];
         t = ray_hit[base + s0 + lane];
@@ -144,7 +146,8 @@ __global__ __launch_bounds__(256) void volrender_fwd_pair_kernel(const float4* _
   // sample counts of one ray fit 32 bits (<= 3R segments x K); only the ray's base offset is 64-bit.  K is a power of two in
   // every configuration of the reference (32): the index within the segment is then a mask, not a division.
   const int kmask = (K & (K - 1)) == 0 ? K - 1 : 0;
-  auto load = [&](long base, int n, int s0, Pair& p) {
+  const int kshift = kmask ? __builtin_ctz((unsigned)K) : 0;
+  auto load = [&](long base, long seg0, int n, int s0, Pair& p) {
     const int i0 = s0 + 2 * lane;
     p.c0 = p.c1 = make_float4(0.f, 0.f, 0.f, 0.f);
     p.t0 = p.t1 = 0.0f;
@@ -155,10 +158,14 @@ __global__ __launch_bounds__(256) void volrender_fwd_pair_kernel(const float4* _
         const __half2 c = *reinterpret_cast<const __half2*>(&raw.z), d = *reinterpret_cast<const __half2*>(&raw.w);
         p.c0 = make_float4(__low2float(a), __high2float(a), __low2float(b), __high2float(b));
         p.c1 = make_float4(__low2float(c), __high2float(c), __low2float(d), __high2float(d));
-        // REGULAR t_vals (sampler.cu:52-66): (i + 1) / K of the index in the segment; i0 is even and K even: no wrap inside a pair
-        const int k0 = kmask ? (i0 & kmask) : i0 % K;
-        p.t0 = (float)(k0 + 1) * rK;
-        p.t1 = (float)(k0 + 2) * rK;
+        if (MODE == RTXN_VR_COMPAT) {
+          // REGULAR t_vals (sampler.cu:52-66): (i + 1) / K of the index in the segment; i0 is even and K even: no wrap inside a pair
+          const int k0 = kmask ? (i0 & kmask) : i0 % K;
+          p.t0 = (float)(k0 + 1) * rK;
+          p.t1 = (float)(k0 + 2) * rK;
+        } else {
+          p.t0 = p.t1 = ray_hit[seg0 + (kmask ? i0 >> kshift : i0 / K)];   // the segment's step length (a pair never straddles two)
+        }
       } else {
         p.c0 = radiance[base + i0];
         p.c1 = radiance[base + i0 + 1];
@@ -170,14 +177,15 @@ __global__ __launch_bounds__(256) void volrender_fwd_pair_kernel(const float4* _
   };
   // The frame has few samples per ray (70 % of the bench frame's rays have none, the rest ~500), so a wave's time is its
   // chain of dependent memory round trips: the first step of ALL its rays is requested before any ray is composited.
-  long base_r[kRaysPerWave];
+  long base_r[kRaysPerWave], seg_r[kRaysPerWave];
   int n_r[kRaysPerWave];
   Pair first[kRaysPerWave];
 #pragma unroll
   for (int r = 0; r < kRaysPerWave; ++r) {
-    base_r[r] = (long)__shfl(idx_l, r, 64) * K;
+    seg_r[r] = (long)__shfl(idx_l, r, 64);
+    base_r[r] = seg_r[r] * K;
     n_r[r] = ray0 + r < batch_size ? __shfl(nh_l, r, 64) * K : 0;     // even
-    if (n_r[r] > 0) load(base_r[r], n_r[r], 0, first[r]);
+    if (n_r[r] > 0) load(base_r[r], seg_r[r], n_r[r], 0, first[r]);
   }
 #pragma unroll
   for (int r = 0; r < kRaysPerWave; ++r) {
@@ -188,7 +196,7 @@ __global__ __launch_bounds__(256) void volrender_fwd_pair_kernel(const float4* _
     float ar = 0.0f, ag = 0.0f, ab = 0.0f;
     Pair cur = first[r], nxt;
     for (int s0 = 0; s0 < n; s0 += 128) {
-      if (s0 + 128 < n) load(base, n, s0 + 128, nxt);          // in flight under this step's scan
+      if (s0 + 128 < n) load(base, seg_r[r], n, s0 + 128, nxt);          // in flight under this step's scan
       const bool act = s0 + 2 * lane < n;
       float x0, x1, w0, w1;
       if (MODE == RTXN_VR_COMPAT) {
@@ -600,51 +608,7 @@ __global__ __launch_bounds__(256) void volrender_l2_fused_multi_kernel(const flo
   }
 }
 
-// Second half of the fused compositor: per ray, pixel = sum_seg exp(-T_before(seg)) * C_seg over the
-// (C_r, C_g, C_b, X) records rtxn_mlp_forward_segments_composite wrote (16 B/segment instead of 640 B).
-__global__ __launch_bounds__(256) void composite_segments_kernel(const float4* __restrict__ seg, const int* __restrict__ num_hits,
-                                                                 const int* __restrict__ indices, int batch_size,
-                                                                 float* __restrict__ pixels) {
-  const int lane = threadIdx.x & 63;
-  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (ray >= batch_size) return;
-  const long base = indices[ray];
-  const int n = num_hits[ray];
-  float T_carry = 0.0f, ar = 0.0f, ag = 0.0f, ab = 0.0f;
-  for (int s0 = 0; s0 < n; s0 += 64) {
-    const bool act = s0 + lane < n;
-    const float4 c = act ? seg[base + s0 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float incl = wave_incl_scan_f(c.w, lane);
-    const float w = act ? expf(-(T_carry + incl - c.w)) : 0.0f;
-    ar = fmaf(w, c.x, ar);
-    ag = fmaf(w, c.y, ag);
-    ab = fmaf(w, c.z, ab);
-    T_carry += lane63(incl);
-  }
-  ar = wave_sum(ar);
-  ag = wave_sum(ag);
-  ab = wave_sum(ab);
-  if (lane == 0) {
-    pixels[3 * (long)ray] = ar;
-    pixels[3 * (long)ray + 1] = ag;
-    pixels[3 * (long)ray + 2] = ab;
-  }
-}
-
 }  // namespace
-
-extern "C" int rtxn_composite_segments(const float* seg_out, const int* num_hits, const int* indices, int batch_size,
-                                       float* pixels, rtxn_stream_t stream) {
-  RTXN_REQUIRE(batch_size >= 0, "rtxn_composite_segments: batch_size = %d < 0", batch_size);
-  RTXN_DEVICE_OR_FAIL();
-  if (batch_size == 0) return RTXN_OK;
-  RTXN_REQUIRE(seg_out && num_hits && indices && pixels, "rtxn_composite_segments: NULL buffer");
-  RTXN_REQUIRE(((uintptr_t)seg_out & 15) == 0, "rtxn_composite_segments: seg_out must be 16-byte aligned");
-  composite_segments_kernel<<<(batch_size + 3) / 4, 256, 0, rtxn::as_stream(stream)>>>(
-      reinterpret_cast<const float4*>(seg_out), num_hits, indices, batch_size, pixels);
-  RTXN_LAUNCH_CHECK("composite_segments_kernel");
-  return RTXN_OK;
-}
 
 extern "C" int rtxn_volrender_fwd(const float* network_inputs, const float* network_outputs, const int* num_hits,
                                   const int* indices, const float* ray_hit, int batch_size,
@@ -689,6 +653,26 @@ extern "C" int rtxn_volrender_fwd_compact(const void* radiance_half4, const int*
     volrender_fwd_kernel<RTXN_VR_COMPAT, true><<<grid, block, 0, rtxn::as_stream(stream)>>>(
         static_cast<const float4*>(radiance_half4), num_hits, indices, nullptr, batch_size, num_samples_per_hit, pixels);
   RTXN_LAUNCH_CHECK("volrender_fwd_kernel<compact>");
+  return RTXN_OK;
+}
+
+extern "C" int rtxn_volrender_fwd_compact_nerf(const void* radiance_half4, const float* segment_step, const int* num_hits,
+                                               const int* indices, int batch_size, int num_samples_per_hit, float* pixels,
+                                               rtxn_stream_t stream) {
+  RTXN_REQUIRE(batch_size >= 0, "rtxn_volrender_fwd_compact_nerf: batch_size = %d < 0", batch_size);
+  RTXN_REQUIRE(num_samples_per_hit > 0, "rtxn_volrender_fwd_compact_nerf: num_samples_per_hit = %d", num_samples_per_hit);
+  RTXN_DEVICE_OR_FAIL();
+  if (batch_size == 0) return RTXN_OK;
+  RTXN_REQUIRE(radiance_half4 && segment_step && num_hits && indices && pixels, "rtxn_volrender_fwd_compact_nerf: NULL buffer");
+  RTXN_REQUIRE(((uintptr_t)radiance_half4 & 7) == 0, "rtxn_volrender_fwd_compact_nerf: radiance must be 8-byte aligned");
+  dim3 grid((batch_size + 3) / 4), block(256);
+  if (num_samples_per_hit % 2 == 0 && ((uintptr_t)radiance_half4 & 15) == 0)
+    volrender_fwd_pair_kernel<RTXN_VR_NERF, true><<<dim3((batch_size + 4 * kRaysPerWave - 1) / (4 * kRaysPerWave)), block, 0, rtxn::as_stream(stream)>>>(
+        static_cast<const float4*>(radiance_half4), num_hits, indices, segment_step, batch_size, num_samples_per_hit, pixels);
+  else
+    volrender_fwd_kernel<RTXN_VR_NERF, true><<<grid, block, 0, rtxn::as_stream(stream)>>>(
+        static_cast<const float4*>(radiance_half4), num_hits, indices, segment_step, batch_size, num_samples_per_hit, pixels);
+  RTXN_LAUNCH_CHECK("volrender_fwd_kernel<compact, nerf>");
   return RTXN_OK;
 }
 

@@ -223,6 +223,33 @@ class Trainer:
                                   api.NUM_SAMPLES_PER_SEGMENT, self.pixels[:n], mode=vr)
         return self.pixels[:n]
 
+    def render_pipeline(self, width, height, focal_length, max_segments=None, **kw):
+        """A render.RenderPipeline over this trainer's LIVE model: the fast inference path (rtxn_render_frame: traversal, the fused
+        frequency / hash-encode + MLP kernel, compact compositor; pipelined and ray-shardable) drawing whatever the parameters are
+        at the time of each frame -- the pipeline holds the trainer's own model handle, hash table and occupancy tensors, and
+        rtxn_mlp_set_params[_training] / Adam update them in place.  Compositor and sampling follow the trainer's mode ("nerf":
+        midpoint samples, world-space steps x density_scale, exclusive transmittance; "compat": the reference's).  The
+        frequency model renders through its fused inference kernel, whose weights a training-only update leaves stale:
+        call sync_inference_weights() before rendering.  update_occupancy() refreshes the pipelines made here."""
+        from . import render
+        nerf = self.mode == "nerf"
+        if self.encoding == "hash":
+            if not api.hashmlp_supported(self.net, self.hg):
+                raise api._lib.RtxnError("render_pipeline: no fused hash-grid inference kernel for this model (built: 64 wide, <= 8 hidden "
+                                         "layers, 2 features per level, an even number of levels); use render_rays()")
+            kw.update(hashgrid=self.hg, table=self.table)
+        pipe = render.RenderPipeline(self.net, self.R, width, height, focal_length, occupancy=self.occ, max_segments=max_segments,
+                                     vr_mode=api.VR_NERF if nerf else api.VR_COMPAT, step_scale=self.density_scale if nerf else 1.0, **kw)
+        import weakref
+        self._pipelines = [r for r in getattr(self, "_pipelines", []) if r() is not None] + [weakref.ref(pipe)]
+        return pipe
+
+    def sync_inference_weights(self):
+        """Frequency models: re-pack the fused inference kernel's weights from the current parameters (rtxn_mlp_set_params); the
+        per-step update only refreshes the training layouts.  (Hash models need nothing: their one 16x16x32 packing is refreshed
+        by every update.)"""
+        self.net.set_params(self.params)
+
     def gradients(self, rays_o, rays_d, targets):
         """Everything of a step up to (not including) the optimizer: traversal ... backward.  Leaves the loss-scaled
         gradient SUMS of this batch in self.dparams (MLP, tcnn layout) and self.dtable / self.dtable_h (hash grid: fp32 for the
@@ -751,6 +778,10 @@ class Trainer:
                 rebound = rebound or (cur is not None or t is not None)
         if rebound and getattr(self, "_graphs", None) is not None:
             self._graphs = None            # pointers changed under the captured traversal: step_captured() asks for a re-capture
+        for ref in getattr(self, "_pipelines", []):
+            pipe = ref()
+            if pipe is not None and pipe.occ is not None:
+                pipe.set_occupancy(self.occ)     # the renderer keeps its own mip / brick hierarchy: rebuild it from the new bits
 
 
 def camera_rays(look_at, focal, width, height, device="cuda", origin_scale=0.1):

@@ -27,10 +27,9 @@ def test_header_symbols_are_exported_and_bound():
     assert lib.rtxn_version() == 100
 
 
-def test_struct_layouts_match_header_order():
-    from rtx_nerf_amd import _lib
+def _header_fields(name):
     src = open(os.path.join(ROOT, "include", "rtxn.h")).read()
-    body = src[src.index("typedef struct rtxn_trace_params {"):src.index("} rtxn_trace_params;")]
+    body = src[src.index(f"typedef struct {name} {{"):src.index(f"}} {name};")]
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     fields = []
     for decl in body.split(";"):
@@ -39,8 +38,45 @@ def test_struct_layouts_match_header_order():
             continue
         for part in decl.split(","):
             fields.append(re.findall(r"([A-Za-z_][A-Za-z0-9_]*)\s*$", part.strip())[0])
-    assert fields == [f[0] for f in _lib.TraceParams._fields_]
+    return fields
+
+
+@pytest.mark.parametrize("c_name,binding", [("rtxn_trace_params", "TraceParams"), ("rtxn_mlp_config", "MlpConfig"),
+                                            ("rtxn_hashgrid_config", "HashGridConfig"), ("rtxn_train_batch", "TrainBatch"),
+                                            ("rtxn_render_config", "RenderConfig"), ("rtxn_render_stats", "RenderStats"),
+                                            ("rtxn_image_dataset", "ImageDataset")])
+def test_struct_layouts_match_header_order(c_name, binding):
+    """Every struct that crosses the ABI: the ctypes binding lists the header's fields in the header's order."""
+    from rtx_nerf_amd import _lib
+    assert _header_fields(c_name) == [f[0] for f in getattr(_lib, binding)._fields_]
     assert C.sizeof(_lib.MlpConfig) == 40
+
+
+def test_render_entry_validates_before_touching_a_device():
+    """rtxn_render_*: argument errors are RTXN_ERR_INVALID / UNSUPPORTED with a message, with or without a GPU."""
+    from rtx_nerf_amd import _lib
+    lib = _lib.lib()
+    cfg = _lib.MlpConfig(3, 10, 2, 12, 64, 2, 4, 1)
+    h = C.c_void_p()
+    assert lib.rtxn_mlp_create(C.byref(cfg), C.byref(h)) == 0
+    rc = _lib.RenderConfig()
+    assert lib.rtxn_render_workspace_bytes(C.byref(rc)) == 0 and b"NULL model" in lib.rtxn_last_error()
+    rc.mlp, rc.width, rc.height, rc.grid_res, rc.trace_mode, rc.max_segments, rc.n_slots = h, 64, 48, 32, 1, 1000, 3
+    rc.focal_length, rc.aspect_ratio = 1.0, 64 / 48
+    need = lib.rtxn_render_workspace_bytes(C.byref(rc))
+    assert need > 3 * (1000 * 32 * 8 + 1000 * 32) and need % 256 == 0
+    rc.flags = 1                                           # float4 + t_vals hand-over: 20 B per sample instead of 8
+    assert lib.rtxn_render_workspace_bytes(C.byref(rc)) > need + 3 * 1000 * 32 * 12 - 4096
+    rc.flags, rc.n_slots = 0, 9
+    assert lib.rtxn_render_workspace_bytes(C.byref(rc)) == 0 and b"n_slots" in lib.rtxn_last_error()
+    rc.n_slots, rc.vr_mode = 3, 1                          # NERF compositing of the frequency model needs t_vals
+    assert lib.rtxn_render_workspace_bytes(C.byref(rc)) == 0 and b"RTXN_RENDER_FLOAT4" in lib.rtxn_last_error()
+    rc.vr_mode = 0
+    out = C.c_void_p()
+    assert lib.rtxn_render_create(C.byref(rc), None, 0, C.byref(out)) in (1, 2)      # no workspace (1) / no device (2)
+    assert lib.rtxn_render_frame(None, 0, None, 0, 0, None, None) == 1
+    assert lib.rtxn_render_destroy(None) == 0
+    assert lib.rtxn_mlp_destroy(h) == 0
 
 
 def test_no_cpu_fallback():

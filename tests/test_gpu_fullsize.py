@@ -1,6 +1,6 @@
 """Size-independent properties at BASELINE.json's full size (800x800 frame, 128^3 grid, 8x128 model):
 the oracle cannot run these sizes in seconds, so the checks are structural -- shard/recombine identity,
-determinism, fused == staged compositor, compositor linearity in colour, CSR bookkeeping, and an oracle spot
+determinism, compositor linearity in colour, CSR bookkeeping, and an oracle spot
 check on a strided ray sample."""
 import numpy as np
 import pytest
@@ -66,25 +66,6 @@ def test_row_shards_recombine_to_the_full_frame(frame, world):
         bufs.append(out)
     img = RowShard(W, H, 0, world).assemble(bufs)
     assert torch.equal(img.reshape(-1, 3), frame["pix"])
-
-
-def test_fused_compositor_matches_at_full_size(frame, monkeypatch):
-    """Per-segment compositing in the MLP epilogue (32x32x16 kernel only) vs the staged compositor over the SAME kernel's
-    per-sample radiance: the compositor arithmetic regrouped per segment, on the full frame."""
-    torch, render, api = frame["torch"], frame["render"], frame["api"]
-    monkeypatch.setenv("RTXN_MFMA_SHAPE", "32")
-    net = api.Network()
-    net.set_params(torch.from_numpy(frame["params"]).cuda())
-    pix = []
-    for fused in (True, False):
-        pipe = render.RenderPipeline(net, frame["R"], frame["W"], frame["H"], frame["f"], occupancy=frame["occ"],
-                                     max_segments=frame["pipe"].max_segments, fused=fused)
-        pipe.set_pose(frame["la"])
-        pix.append(pipe.render().clone())
-        del pipe
-    assert float((pix[0] - pix[1]).abs().max()) < 5e-6
-    # and the default (16x16x32) frame agrees with it to fp16-ulp noise of the network outputs
-    assert float((pix[1] - frame["pix"]).abs().max()) < 2e-3
 
 
 def test_compositor_is_linear_in_colour(frame):

@@ -159,7 +159,7 @@ def test_compact_intermediate_gives_identical_pixels(gpu):
     la = scenes.pose_spherical(70.0, -25.0, origin_scale=10.0)
     focal = scenes.lego_focal_length(True)
     pipes = [render.RenderPipeline(net, R, W, H, focal, occupancy=occ, max_segments=1024, compact=c) for c in (True, False)]
-    assert pipes[0].compact and not pipes[1].compact and pipes[0].radiance.dtype == torch.float16 and pipes[0].t_vals is None
+    assert pipes[0].compact and not pipes[1].compact and pipes[0].radiance.dtype == torch.float16 and pipes[0].t_vals is None and pipes[1].t_vals is not None
     outs = []
     for p in pipes:
         p.calibrate([la])

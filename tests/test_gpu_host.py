@@ -1,7 +1,7 @@
-"""The C++ host over the drop-in headers (examples/render_host.cpp, the stage
-order of the reference's main.cu) must produce the same image as the same
-stages driven through the Python mirror of the interface, and both must agree
-with the oracle."""
+"""The C++ host (examples/render_host.cpp).  `stages`: the drop-in headers in the stage order of the reference's main.cu
+must produce the same image as the same stages driven through the Python mirror of the interface, and both must agree
+with the oracle.  `frame`: BASELINE configs[1] (800x800, 128^3, 8x128) through the frame entry rtxn_render_frame from C++
+-- no host re-pack, no Python -- must be bit-identical to RenderPipeline.render() and within tolerance of the oracle."""
 import os
 import subprocess
 
@@ -21,7 +21,7 @@ def test_cpp_host_matches_python_api_and_oracle(gpu, oracle, tmp_path):
     assert os.path.exists(exe)
     W = H = 40
     out = str(tmp_path / "host.ppm")
-    res = subprocess.run([exe, str(W), str(H), out], capture_output=True, text=True, timeout=300)
+    res = subprocess.run([exe, "stages", str(W), str(H), out], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
     raw = open(out, "rb").read()
     header = f"P6\n{W} {H}\n255\n".encode()
@@ -62,3 +62,45 @@ def test_cpp_host_matches_python_api_and_oracle(gpu, oracle, tmp_path):
     cfg = oracle.mlp_cfg()
     want, _ = oracle.render(la, f, 1.0, W, H, R, None, 0, cfg, p16.numpy(), np.arange(n))
     np.testing.assert_allclose(pix, want, rtol=0, atol=2e-3)
+
+
+def _exe():
+    exe = os.path.join(ROOT, "examples", "render_host")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", ROOT, "examples/render_host"])
+    return exe
+
+
+@pytest.mark.parametrize("W,H,R,occupied", [(800, 800, 128, True), (96, 64, 8, False)])
+def test_cpp_host_frame_entry_is_the_python_pipelines_frame(gpu, oracle, tmp_path, W, H, R, occupied):
+    torch = gpu
+    from rtx_nerf_amd import api, render, scenes
+    la = scenes.pose_spherical(15.0, -30.0, origin_scale=10.0).astype(np.float32).reshape(16)
+    words = scenes.pack_occupancy(scenes.lego_standin_density(R, seed=0)) if occupied else None
+    occ_path = "-"
+    if occupied:
+        occ_path = str(tmp_path / "occ.u32")
+        words.astype("<u4").tofile(occ_path)
+    out, raw = str(tmp_path / "frame.ppm"), str(tmp_path / "frame.f32")
+    f = float(np.float32(1.0) / np.tan(np.float32(0.5) * np.float32(0.6911112)))
+    res = subprocess.run([_exe(), "frame", str(W), str(H), str(R), out, raw, occ_path, "4", ",".join(f"{v:.9g}" for v in la), f"{f:.9g}"],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "ms/frame" in res.stdout
+    got = np.fromfile(raw, np.float32).reshape(W * H, 3)
+    # the same frame through the Python caller of the same entry point
+    net = api.Network()
+    p16 = net.initialize_params(1337).half()
+    net.set_params(p16.cuda())
+    occ = torch.from_numpy(words.view(np.int32).copy()).cuda() if occupied else None
+    pipe = render.RenderPipeline(net, R, W, H, f, occupancy=occ, max_segments=1024, sub_rays=2 if W * H >= 300000 else 8)
+    pipe.calibrate([la])
+    pipe.set_pose(la)
+    want = pipe.render().cpu().numpy()
+    assert np.array_equal(got, want) and got.std() > 1e-3
+    assert f"{int(pipe.total.item())} segments" in res.stdout
+    # and the oracle on a strided ray sample
+    ids = (np.arange(1500, dtype=np.int64) * ((W * H) // 1500) + 7).astype(np.uint32)
+    cfg = oracle.mlp_cfg()
+    ref, _ = oracle.render(la, f, W / H, W, H, R, words, 1, cfg, p16.numpy(), ids)
+    np.testing.assert_allclose(got[ids], ref, rtol=0, atol=1e-3)

@@ -310,12 +310,10 @@ def test_volrender_nerf_mode(gpu, oracle):
 
 
 # ------------------------------------------------------------------ MLP
-@pytest.fixture(params=["16", "32"])
-def mfma_shape(request, monkeypatch):
-    """Both fused inference kernels: mlp_fwd16_kernel (v_mfma_f32_16x16x32_f16, the default) and mlp_fwd_kernel
-    (32x32x16); rtxn_mlp_create reads the switch.  All three widths have both."""
-    monkeypatch.setenv("RTXN_MFMA_SHAPE", request.param)
-    return request.param
+@pytest.fixture
+def mfma_shape():
+    """The fused inference kernels run on v_mfma_f32_16x16x32_f16 (rounds 1-2 also carried 32x32x16 builds; removed)."""
+    return "16"
 
 
 def _mlp_case(oracle, W, nh, n, seed, dir_freqs=12):
@@ -514,53 +512,6 @@ def test_config5_forward_facing_256_grid_8x256(gpu, oracle):
     # the two-level walk and the flat walk agree on this grid too (bit-exact segments)
     tr_c = oracle.trace(look_at=la, focal=f, aspect=W / H, W=W, H=H, R=R, occ=words, mode=1, count_only=True)
     np.testing.assert_array_equal(pipe.num_hits.cpu().numpy(), tr_c["num_hits"])
-
-
-@pytest.mark.parametrize("W", [64, 128, 256])
-def test_fused_compositor_equals_staged_and_oracle(gpu, oracle, W, monkeypatch):
-    """The per-segment compositing epilogue + per-ray combine == per-sample radiance + launch_volrender_cuda
-    (COMPAT), both == the oracle; NERF mode == midpoint sampler + forward + NERF volume render."""
-    monkeypatch.setenv("RTXN_MFMA_SHAPE", "32")   # the epilogue exists in the 32x32x16 kernel only: "same arithmetic" needs both sides on it
-    torch = gpu
-    from rtx_nerf_amd import api, render
-    R, Wd, H = 32, 40, 30
-    nh_layers = 2 if W == 64 else 3
-    cfg = oracle.mlp_cfg(n_neurons=W, n_hidden_layers=nh_layers)
-    params = scenes.xavier_params_fp16(W, nh_layers, 112, seed=W)
-    words = scenes.pack_occupancy(scenes.lego_standin_density(R, seed=4))
-    occ = _occ_dev(torch, words)
-    net = api.Network(n_neurons=W, n_hidden_layers=nh_layers)
-    net.set_params(_dev(torch, params))
-    la = scenes.pose_spherical(60.0, -35.0, origin_scale=10.0)
-    f = scenes.lego_focal_length(True)
-    cap = Wd * H * 60
-    fused = render.RenderPipeline(net, R, Wd, H, f, occupancy=occ, max_segments=cap, fused=True)
-    staged = render.RenderPipeline(net, R, Wd, H, f, occupancy=occ, max_segments=cap, fused=False)
-    for p in (fused, staged):
-        p.set_pose(la)
-    a = fused.render().cpu().numpy()
-    b = staged.render().cpu().numpy()
-    np.testing.assert_allclose(a, b, rtol=0, atol=2e-6)        # same arithmetic, regrouped per segment
-    want, _ = oracle.render(la, f, Wd / H, Wd, H, R, words, 1, cfg, params, np.arange(Wd * H))
-    np.testing.assert_allclose(a, want, rtol=0, atol=2e-3)
-    assert (fused.seg_first.cpu().numpy()[:int(fused.total.item())].sum() == (fused.num_hits.cpu().numpy() > 0).sum())
-    # NERF mode
-    scale = 80.0
-    fn = render.RenderPipeline(net, R, Wd, H, f, occupancy=occ, max_segments=cap, fused=True, vr_mode=api.VR_NERF,
-                               step_scale=scale)
-    fn.set_pose(la)
-    c = fn.render().cpu().numpy()
-    P = int(fn.total.item())
-    n = Wd * H
-    samples = torch.empty((P * 32, 5), device="cuda")
-    tv = torch.empty(P * 32, device="cuda")
-    api.launchSampler(fn.start, fn.end, fn.view_dirs, tv, samples, n, R, fn.num_hits, fn.indices, api.SAMPLING_MIDPOINT_WORLD)
-    tv.mul_(scale)
-    rad = net.forward_radiance(samples)
-    pix = torch.empty((n, 3), device="cuda")
-    api.launch_volrender_cuda(None, rad, fn.num_hits, fn.indices, tv, n, 32, pix, mode=api.VR_NERF)
-    np.testing.assert_allclose(c, pix.cpu().numpy(), rtol=0, atol=3e-6)
-    assert c.std() > 0.01
 
 
 @pytest.mark.parametrize("mode", [0, 1])

@@ -26,11 +26,6 @@ cd "$repo"
 python3 tools/stage_bench.py > "$out/stage_bench.txt" 2>&1
 python3 tools/probe/train_stage_probe.py > "$out/train_stage_probe.txt" 2>&1 || true
 python3 tools/probe/captured_probe.py > "$out/captured_probe.txt" 2>&1 || true
-for sh in 16 32 16 32; do
-  RTXN_MFMA_SHAPE=$sh python3 bench.py --scene llff --grid 256 --neurons 256 --width 1008 --height 756 --steps 15 --warmup 3 --no-cpu --no-extras 2>/dev/null | python3 -c "
-import json,sys;d=json.loads(sys.stdin.read());r=d['roofline'];print('RTXN_MFMA_SHAPE=$sh', d['value'],'Mrays/s',d['ms_per_step'],'ms/frame',r['kernel'],r['kernel_ms'],'ms',r['achieved'],'TFLOP/s',r['frac'])" >> "$out/config5_shape_ab.txt"
-done
-python3 tools/mfma_shape_ab.py > "$out/mfma_shape_ab.txt" 2>&1
 python3 -m pytest tests/test_gpu_parity.py -q -k encoder_error > "$out/encoder_octave_error.txt" 2>&1 || true
 # flatten what gets committed
 cp $(ls $out/kt_pipelined/*/*kernel_stats.csv | head -1) $out/pipelined_bench_n1_kernel_stats.csv

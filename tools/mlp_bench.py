@@ -18,7 +18,7 @@ ap.add_argument("--segments", type=int, default=3_000_000)
 ap.add_argument("--neurons", type=int, default=128)
 ap.add_argument("--layers", type=int, default=8)
 ap.add_argument("--iters", type=int, default=10)
-ap.add_argument("--composite", action="store_true", help="time the fused per-segment composite epilogue variant")
+ap.add_argument("--compact", action="store_true", help="the render pipeline's launch: half4 outputs, no t_vals (rtxn_mlp_forward_segments_compact)")
 ap.add_argument("--weights", choices=["xavier", "zero", "small"], default="xavier", help="power experiment: all-zero weights (no operand toggling "
                 "in the matrix core: what the kernel does when the clock is not held down) or tiny ones; timing only")
 ap.add_argument("--samples", action="store_true", help="time rtxn_mlp_forward_radiance on a materialised float[N][5] batch (the bench.py default path)")
@@ -41,12 +41,11 @@ if args.weights == "zero":
 elif args.weights == "small":
     w_np = (w_np.astype(np.float32) * 1e-3).astype(np.float16)
 net.set_params(torch.from_numpy(w_np).cuda())
-if args.composite:
-    seg_first = (torch.arange(P, device="cuda") % 5 == 0).to(torch.uint8)
-    seg_out = torch.empty((P, 4), device="cuda")
+if args.compact:
+    rad16 = torch.empty((P * 32, 4), dtype=torch.float16, device="cuda")
 
     def run():
-        net.forward_segments_composite(sp, ep, sv, seg_first, total, P, seg_out)
+        net.forward_segments_compact(sp, ep, sv, total, P, rad16)
 elif args.samples:
     t = (torch.arange(32, device="cuda", dtype=torch.float32) / 32)[None, :, None]
     xyz = sp[:, None, :] + t * (ep - sp)[:, None, :]

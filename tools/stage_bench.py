@@ -8,10 +8,12 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 import torch
 
-from rtx_nerf_amd import api, render, scenes
+from rtx_nerf_amd import api, scenes
+from _stages import Stages
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=10)
@@ -25,10 +27,11 @@ occ = torch.from_numpy(scenes.pack_occupancy(scenes.lego_standin_density(R, seed
 net = api.Network(n_neurons=128, n_hidden_layers=8)
 net.set_params(torch.from_numpy(scenes.xavier_params_fp16(128, 8, net.encoded_width(), seed=1337)).cuda())
 pose = scenes.pose_spherical(15.0, -30.0, origin_scale=10.0)
-pipe = render.RenderPipeline(net, R, W, H, scenes.lego_focal_length(True), occupancy=occ, max_segments=1024, compact=False)
-P = pipe.calibrate([pose])
-pipe.set_pose(pose)
-pipe.render()
+pipe = Stages(net, R, W, H, scenes.lego_focal_length(True), occ, compact=False)
+P = pipe.size_for(pose)
+pipe.geometry()
+pipe.shade()
+pipe.composite()
 torch.cuda.synchronize()
 n, S = W * H, P * K
 samples = torch.empty((S, 5), device="cuda")
@@ -56,9 +59,9 @@ def timed(fn):
 
 h = P / n   # mean segments per ray
 stages = [
-    ("trace_kernel<DDA> count pass", lambda: pipe._trace(0, n, write=False), 12 * n),
-    ("trace_kernel<DDA> write pass", lambda: pipe._trace(0, n, write=True), 24 * n + 32 * P),
-    ("scan_hits", lambda: api.scan_hits(pipe.num_hits, pipe.indices, pipe.total, pipe.scan_ws), 8 * n),
+    ("trace_kernel<DDA> count pass", lambda: pipe.trace(0, n, False), 12 * n),
+    ("trace_kernel<DDA> write pass", lambda: pipe.trace(0, n, True), 24 * n + 32 * P),
+    ("scan_hits", lambda: pipe.scan(n), 8 * n),
     ("launchSampler REGULAR", lambda: api.launchSampler(pipe.start, pipe.end, pipe.view_dirs, t_vals, samples, n, R, pipe.num_hits_c,
                                                         pipe.indices, api.SAMPLING_REGULAR), 16 * n + 792 * P),
     ("launchSampler JITTER", lambda: api.launchSampler(pipe.start, pipe.end, pipe.view_dirs, t_vals, samples, n, R, pipe.num_hits_c,

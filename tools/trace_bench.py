@@ -6,10 +6,12 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 import torch
 
-from rtx_nerf_amd import api, render, scenes
+from rtx_nerf_amd import api, scenes
+from _stages import Stages
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--scene", default="lego")
@@ -29,10 +31,8 @@ la = scenes.pose_spherical(15.0, -30.0, origin_scale=10.0) if a.scene == "lego" 
 f = scenes.lego_focal_length(True) if a.scene == "lego" else 1.6
 from rtx_nerf_amd.shard import RowShard
 sh = RowShard(a.width, a.height, 0, a.shard_of)
-pipe = render.RenderPipeline(net, R, a.width, a.height, f, occupancy=occ, max_rays=sh.n_local, max_segments=1024, window=sh.window,
-                             sub_rays=a.sub_rays)
-pipe.calibrate([la], ray_begin=sh.ray_begin, ray_count=sh.n_local)
-pipe.set_pose(la)
+pipe = Stages(net, R, a.width, a.height, f, occ, max_rays=sh.n_local, window=sh.window, sub_rays=a.sub_rays)
+pipe.size_for(la, ray_begin=sh.ray_begin, n=sh.n_local)
 n = sh.n_local
 sup = pipe.super_mip
 for label, bricks, pipe.super_mip in (("3-level", pipe.bricks, sup), ("2-level", pipe.bricks, None), ("3-level", pipe.bricks, sup),
@@ -42,10 +42,10 @@ for label, bricks, pipe.super_mip in (("3-level", pipe.bricks, sup), ("2-level",
     for _ in range(12):
         for write in (False, True):
             if write:
-                api.scan_hits(pipe.num_hits[:n], pipe.indices[:n], pipe.total, pipe.scan_ws)
+                pipe.scan(n)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            pipe._trace(sh.ray_begin, n, write=write)
+            pipe.trace(sh.ray_begin, n, write)
             e1.record()
             torch.cuda.synchronize()
             ms[write].append(e0.elapsed_time(e1))
