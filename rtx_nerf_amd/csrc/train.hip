@@ -674,12 +674,17 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_bwd_kernel(TrainArgs a) {
     const bool live = __syncthreads_or(any_grad);
     if (a.live_tiles && threadIdx.x == 0) a.live_tiles[blockIdx.x] = live ? 1 : 0;
     if (!live && a.live_tiles) {
-      if (a.dencT && !a.live_list) {
+      // d(encoding) of the tile: zeros.  With the live list this still matters: a LISTED segment (non-zero dL/d(radiance)) can
+      // have dZ_out == 0 in every sample -- a saturated sigmoid (y (1 - y) == 0 in fp16) or a product that underflows -- and the
+      // hash scatter walks the same list, so its columns must not be left as they were (uninitialised memory: NaNs there once
+      // poisoned a whole training run, 14 steps in).
+      if (a.dencT) {
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
-          for (int f = 0; f < a.E; f += 8)
+          if (ok_s[ct] || !a.live_list)
+            for (int f = 0; f < a.E; f += 8)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) *row_elem(a.dencT, f + j, a.Sp, lane_off[ct]) = (_Float16)0.0f;
+              for (int j = 0; j < 4; ++j) *row_elem(a.dencT, f + j, a.Sp, lane_off[ct]) = (_Float16)0.0f;
       }
       return;
     }
@@ -973,6 +978,17 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_fused64_kernel(FusedArgs 
         _Float16* base = a.dencT + (long)tile * kTile;
         for (int i = tid; i < a.E * (kTile / 8); i += kThreads)
           *reinterpret_cast<uint4*>(base + (long)(i / (kTile / 8)) * a.Sp + (i % (kTile / 8)) * 8) = make_uint4(0u, 0u, 0u, 0u);
+      } else if (a.dencT) {
+        // Live list: the tile's segments ARE listed (non-zero dL/d(radiance)), yet every dZ_out is zero -- a saturated sigmoid
+        // (y (1 - y) == 0 in fp16) or an underflowing product.  The hash scatter walks the same list, so their d(encoding)
+        // columns must read zero, not what the buffer held before (uninitialised memory: NaNs there once poisoned a whole
+        // training run 14 steps in).  lane (col, h) of column tile ct owns rows f + 4h + 0..3 of every 8.
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+          if (ok_s[ct])
+            for (int f = 0; f < a.E; f += 8)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) *row_elem(a.dencT, f + j, a.Sp, lane_off[ct]) = (_Float16)0.0f;
       }
       continue;
     }

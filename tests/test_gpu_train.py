@@ -219,7 +219,10 @@ def test_recompute_path_matches_oracle_and_three_kernel_path(gpu, oracle, L, E, 
     ws = net.train_workspace(n)
     out_ref = net.train_forward(encT_d, n, ws)
     torch.cuda.synchronize()
-    assert torch.equal(out, out_ref)                                       # the same forward arithmetic, with and without saving
+    # the outputs-only forward runs the 16x16x32 all-asm layer stack (hashmlp.hip), the saving forward the 32x32x16 one: the same
+    # fp16 products summed in another order inside the matrix core -- fp16-ulp differences on a minority of the outputs
+    d = (out.float() - out_ref.float()).abs()
+    assert float(d.max()) <= 2e-3 * max(1.0, float(out_ref.float().abs().max())) and float((d > 0).float().mean()) < 0.25
     np.testing.assert_array_equal(rad.cpu().numpy(), out.cpu().numpy().astype(np.float32)[:, :4])
     rng = np.random.default_rng(11)
     dout = (rng.standard_normal((n, 4)) * 0.05).astype(np.float16)
@@ -528,3 +531,61 @@ def test_inference_refuses_stale_weights_after_a_training_only_update(gpu):
     net.set_params((p * 0.5).contiguous())
     y1 = net.forward(x)
     assert not torch.equal(y0, y1)
+
+
+@pytest.mark.parametrize("recompute", [True, False])
+def test_live_segments_with_a_saturated_output_leave_no_stale_gradient(gpu, recompute):
+    """Round 3: a LISTED segment (non-zero dL/d(radiance)) whose network outputs are saturated -- y == 1.0 or 0.0 in fp16, so
+    dZ_out = dout * y (1 - y) is exactly zero in every sample -- made the backward kernels skip its tile without writing its
+    d(encoding) columns, and the hash scatter, walking the same list, then added whatever the buffer held (NaNs from
+    uninitialised memory poisoned a training run 14 steps in).  A whole tile of such segments: their columns must read zero
+    afterwards, and the scatter must add nothing for them."""
+    torch = gpu
+    from rtx_nerf_amd import api
+    rng = np.random.default_rng(3)
+    P, K = 24, 32
+    S = P * K
+    hg = api.HashGrid(4, 2, 12, 8, 1.6, n_dir_freqs=4)
+    E = hg.encoded_width()
+    net = api.Network(n_neurons=64, n_hidden_layers=2, n_encoded_features=E)
+    assert net.recompute_supported()
+    net.set_params(_dev(torch, scenes.xavier_params_fp16(64, 2, E, seed=4)))
+    sp = rng.uniform(-0.9, 0.9, (P, 3)).astype(np.float32)
+    ep = (sp + rng.uniform(-0.02, 0.02, (P, 3))).astype(np.float32)
+    sv = rng.uniform(0, 3, (P, 2)).astype(np.float32)
+    sp_d, ep_d, sv_d = _dev(torch, sp), _dev(torch, ep), _dev(torch, sv)
+    table = _dev(torch, rng.uniform(-1, 1, hg.n_params()).astype(np.float16))
+    Sp = api.padded_samples(S)
+    encT = torch.zeros((E, Sp), dtype=torch.float16, device="cuda")
+    hg.encode_segments(table, sp_d, ep_d, sv_d, P, api.SAMPLING_REGULAR, encT, torch.zeros(S, device="cuda"), 1.0)
+    ws_act = None if recompute else net.train_workspace(S)
+    out = net.train_forward_outputs(encT, S) if recompute else net.train_forward(encT, S, ws_act)
+    # segments 8..15 (one whole 8-segment tile of the live walk when segments 0..7 are live too): saturated outputs
+    sat = np.zeros(P, bool)
+    sat[8:16] = True
+    out_np = out.cpu().numpy().reshape(P, K, 16)
+    out_np[sat, :, :4] = np.float16(1.0)
+    out_np[sat, ::2, 1] = np.float16(0.0)
+    out = _dev(torch, out_np.reshape(S, 16))
+    dout = (rng.standard_normal((P, K, 4)) * 0.05).astype(np.float16)
+    dout[16:] = 0                                             # segments 16.. carry no gradient: not listed
+    dout_d = _dev(torch, dout.reshape(S, 4))
+    ws = api.live_segments_workspace(P + 5)
+    api.live_segments(dout_d, P, P + 5, ws)
+    assert int(ws[0].item()) == 16
+    dp = torch.zeros(net.n_params(), device="cuda")
+    de = torch.full((E, Sp), float("nan"), dtype=torch.float16, device="cuda")      # what uninitialised memory can hold
+    if recompute:
+        net.train_backward_recompute_live(encT, out, dout_d, S, ws, dp, de)
+    else:
+        net.train_backward_live(encT, out, dout_d, S, ws_act, ws, dp, de)
+    lo = hg.hashed_offset()
+    dt, dh = torch.zeros(hg.n_params(), device="cuda"), torch.zeros(hg.n_params() - lo, dtype=torch.float16, device="cuda")
+    hg.backward_segments(sp_d, ep_d, P, api.SAMPLING_REGULAR, de, dt, dh, live_ws=ws)
+    torch.cuda.synchronize()
+    d = de.cpu().numpy()[:, :S].reshape(E, P, K)
+    assert np.all(d[:, sat] == 0.0)                           # listed, saturated: zeros, not the NaN fill
+    assert np.isfinite(d[:, :8]).all() and np.abs(d[:, :8].astype(np.float32)).max() > 0
+    assert np.isnan(d[:, 16:].astype(np.float32)).all()       # not listed: never touched (and never read)
+    assert torch.isfinite(dp).all() and torch.isfinite(dt).all() and torch.isfinite(dh.float()).all()
+    assert float(dt.abs().max()) > 0
