@@ -96,7 +96,7 @@ def time_shade(pipe, poses_d, ray_begin, n_local, steps):
     return (float(np.mean(ms)), float(np.mean(smp))) if ms else (None, 0.0)
 
 
-def extra_train_config3(steps, warmup):
+def extra_train_config3(steps, warmup, kernel_steps=5):
     """BASELINE.json configs[2] at full size: 4096 rays/batch, hash grid L=16 F=2 T=2^19 (base 16, scale 1.5) +
     Frequency(4) directions + 4x64 MLP, 128^3 Lego stand-in grid, K = 32, corrected ("nerf") compositor, L2 + Adam;
     targets rendered from an analytic teacher field.  One step = one full optimisation step (main.cu:619-805)."""
@@ -190,9 +190,177 @@ def extra_train_config3(steps, warmup):
             tf = mult * mlp_flop * S / (ms * 1e-3) / 1e12
             rec["kernels"][name] = {"ms": round(ms, 4), "flop_per_sample": int(mult * mlp_flop), "achieved": round(tf, 2),
                                     "unit": "TFLOP/s", "frac": round(tf / MFMA_F16_DENSE_PEAK_TFLOPS, 4)}
+    rec_hash = extra_render_hash(tr, step_captured=lambda: (batch_into_graph(), tr.step_captured()), trained_steps=warmup + 2 * steps + max(2, warmup) + 6,
+                                 kernel_steps=kernel_steps)
+    del tr
+    torch.cuda.empty_cache()
+    return rec, rec_hash
+
+
+def extra_render_hash(tr, step_captured, trained_steps, kernel_steps, train_to=1500, frames=12):
+    """train -> render -> PSNR on the fast path (north_star: "the fully-fused MLP + hash-grid encoding"): the configs[2] model is
+    trained on to `train_to` optimisation steps (captured step, wall-clocked), then drawn at 800x800 / 128^3 through
+    rtxn_render_frame with the fused hash-encode + 4x64 kernel (hashmlp_fwd_kernel) on the trainer's live tensors: PSNR of two
+    held-out views against the analytic teacher, pipelined Mrays/s, and the kernel against what bounds it -- the gather rate of
+    the cache hierarchy (16 levels x 8 corners x 4 B = 512 B and 128 gathers per sample from a 25-MB table that lives in L2 /
+    Infinity Cache), with the MFMA fraction beside it."""
+    from rtx_nerf_amd import api, scenes
+    from rtx_nerf_amd.train import camera_rays
+    W = H = 800
+    focal = scenes.lego_focal_length(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    more = max(0, train_to - trained_steps)
+    for _ in range(more):
+        step_captured()
+    tr.flush_captured()
+    torch.cuda.synchronize()
+    train_s = time.perf_counter() - t0
+    held = [scenes.pose_spherical(100.0, -35.0, origin_scale=10.0), scenes.pose_spherical(250.0, -20.0, origin_scale=10.0)]
+    poses = held + [scenes.pose_spherical(360.0 * i / 4 + 15.0, -30.0, origin_scale=10.0) for i in range(2)]
+    pipe = tr.render_pipeline(W, H, focal, max_segments=1024)
+    worst = pipe.calibrate(poses)
+    # teacher frames of the held-out views: the trainer's staged path with the analytic field in place of the network, in chunks
+    psnrs = []
+    B = tr.B
+    for la in held:
+        o, d = camera_rays(la, focal, W, H)
+        gt = torch.cat([tr.render_rays(o[i:i + B].contiguous(), d[i:i + B].contiguous(), radiance_fn=scenes.teacher_field).clone()
+                        for i in range(0, W * H, B)])
+        pipe.set_pose(la)
+        pred = pipe.render().clone()
+        torch.cuda.synchronize()
+        mse = float(((pred - gt) ** 2).mean())
+        psnrs.append(10.0 * np.log10(1.0 / max(mse, 1e-12)))
+    poses_d = [torch.from_numpy(p.reshape(16)).cuda() for p in poses]
+    outs = [torch.empty((W * H, 3), device="cuda") for _ in range(2)]
+    for i in range(3):
+        pipe.render_async(poses_d[i % len(poses_d)], out=outs[i & 1])
+    pipe.drain_async()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(frames):
+        pipe.render_async(poses_d[i % len(poses_d)], out=outs[i & 1])
+    pipe.drain_async()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert not pipe.overflowed(), "render_hash4x64: segment capacity overflow"
+    ms, smp = time_shade(pipe, poses_d, 0, W * H, kernel_steps)
+    L = tr.hg.cfg.n_levels
+    gather_b = L * 8 * 4                                   # fp16 pairs: 4 B per corner
+    flop = 2 * (tr.E * 64 + (tr.net.cfg.n_hidden_layers - 1) * 64 * 64 + 16 * 64)
+    gbs = gather_b * smp / (ms * 1e-3) / 1e9
+    tf = flop * smp / (ms * 1e-3) / 1e12
+    IC_GATHER_PEAK_GBS = 8600.0   # MI355X_MICROARCH.md, "Indexed rows": 38 MB table, uniformly random rows served by the Infinity Cache
+    rec = {
+        "workload": f"{W}x{H} inference render of the TRAINED configs[2] model (hash grid L={L} F=2 T=2^{tr.hg.cfg.log2_hashmap_size} + Frequency(4) dirs + "
+                    f"4x64 MLP, {tr.step_count} optimisation steps on the analytic teacher), 128^3 Lego stand-in grid, 32 midpoint samples/segment, "
+                    "NeRF compositor; rtxn_render_frame_async on the trainer's live tensors",
+        "ms_per_step": round(1e3 * dt / frames, 4), "mrays_s": round(W * H * frames / dt / 1e6, 4), "steps": frames, "rays_per_step": W * H,
+        "segments_per_frame_max": worst, "mean_samples_per_ray": round(smp / (W * H), 2), "dtype": "f16 table + MFMA / f32 accumulate",
+        "psnr_vs_teacher_db": [round(p, 2) for p in psnrs], "held_out_views": 2, "train_steps": tr.step_count,
+        "train_seconds_after_bench": round(train_s, 3), "train_steps_in_those_seconds": more,
+        "roofline": {"kernel": "hashmlp_fwd_kernel<2>", "bound": "cache gather (L2 / Infinity Cache; the 25-MB table does not come from HBM)",
+                     "achieved": round(gbs, 1), "peak": IC_GATHER_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / IC_GATHER_PEAK_GBS, 4),
+                     "peak_source": "MI355X_MICROARCH.md 'Indexed rows: gather into LDS': 38 MB table, uniformly random 1,152-B rows = 8.6 TB/s; "
+                                    "4-byte gathers fetch a 64-B sector each, so the same sector rate moves 1/16 of the bytes when no two lanes share one",
+                     "traffic": None, "kernel_ms": round(ms, 4), "bytes_per_sample": gather_b, "gathers_per_sample": L * 8,
+                     "gathers_per_s": round(L * 8 * smp / (ms * 1e-3) / 1e12, 3), "gathers_unit": "T/s", "samples_per_launch": smp,
+                     "mfma": {"flop_per_sample": flop, "achieved": round(tf, 1), "unit": "TFLOP/s", "frac": round(tf / MFMA_F16_DENSE_PEAK_TFLOPS, 4)}},
+    }
+    del pipe
+    return rec
+
+
+def train_ref_record(batch_rays, grid_res, steps, warmup, dense_grid=True, mode="compat", captured=True):
+    """One optimisation step of the reference's OWN training iteration (main.cu:612-805): the 8x128 ReLU model with
+    Composite-Frequency(10, 12) encoding (main.cu:35-69), REGULAR sampler, the reference's compositor forward and backward
+    (RTXN_VR_COMPAT, vol_render.cu:19-143), L2, Adam 1e-3, loss scale 1 (main.cu:36-46); dense_grid: the reference's 8^3 dense
+    grid (main.cu:394) with 32 samples per crossed cell, batch_rays = BATCH_SIZE_GRANULARITY x 176 (main.cu:185-186: 22,528 or
+    45,056 depending on the tiny-cuda-nn version); otherwise the 128^3 Lego stand-in occupancy (continuity with round 2's
+    4096-ray figure).  MFMA fraction = 3 x 262,144 FLOP x samples / step time / 2.5 PFLOP/s (forward + dgrad + wgrad)."""
+    from rtx_nerf_amd import scenes
+    from rtx_nerf_amd.train import Trainer, camera_rays
+    R, B = grid_res, batch_rays
+    if dense_grid:
+        occ, occ_frac = None, 1.0
+    else:
+        dense = scenes.lego_standin_density(R, seed=0)
+        occ = torch.from_numpy(scenes.pack_occupancy(dense).view(np.int32).copy()).cuda()
+        occ_frac = float(dense.mean())
+    focal = scenes.lego_focal_length(True)
+    side = 256
+    ro, rd = [], []
+    for i in range(8):
+        o, d = camera_rays(scenes.pose_spherical(45.0 * i + 15.0, -30.0, origin_scale=10.0), focal, side, side)
+        ro.append(o); rd.append(d)
+    ro, rd = torch.cat(ro), torch.cat(rd)
+    g = torch.Generator(device="cuda").manual_seed(42)
+    tg = torch.rand((ro.shape[0], 3), device="cuda", generator=g)
+    # capacity from a counting pass over a few batches (the reference sizes 3R slots per ray, main.cu:486)
+    probe = Trainer(R, occ, encoding="freq", n_neurons=64, n_hidden_layers=1, n_dir_freqs=12, batch_rays=B, max_segments=1024, mode=mode)
+    need = 0
+    for _ in range(4):
+        idx = torch.randint(0, ro.shape[0], (B,), device="cuda", generator=g)
+        o, d = ro[idx].contiguous(), rd[idx].contiguous()
+        kw = dict(grid_res=R, rays_o=o, rays_d=d, width=B, height=1, ray_begin=0, ray_count=B, occupancy=probe.occ, occupancy_coarse=probe.coarse,
+                  occupancy_bricks=probe.bricks, occupancy_super=probe.super_mip, mode=1, viewing_direction=probe.view_dirs, num_hits=probe.num_hits,
+                  sub_rays=0)
+        from rtx_nerf_amd import api
+        api.trace_grid(None, **kw)
+        need = max(need, int(probe.num_hits[:B].sum().item()))
+    del probe
+    torch.cuda.empty_cache()
+    cap = int(need * 1.15) + 1024
+    tr = Trainer(R, occ, encoding="freq", n_neurons=128, n_hidden_layers=8, n_dir_freqs=12, batch_rays=B, max_segments=cap, lr=1e-3,
+                 loss_scale=1.0 if mode == "compat" else 128.0, density_scale=1.0 if mode == "compat" else 300.0, mode=mode)
+
+    def batch():
+        idx = torch.randint(0, ro.shape[0], (B,), device="cuda", generator=g)
+        return ro[idx].contiguous(), rd[idx].contiguous(), tg[idx].contiguous()
+
+    for _ in range(warmup):
+        loss = tr.step(*batch())
+    torch.cuda.synchronize()
+    samples = 0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = tr.step(*batch())
+        samples += min(int(tr.total.item()), tr.max_segments) * 32
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    S = samples / steps
+    stages = tr.time_stages(*batch(), steps=3)
+    ms = 1e3 * dt / steps
+    flop = 3 * 262144
+    tf = flop * S / (ms * 1e-3) / 1e12
+    rec = {
+        "workload": f"{B} rays/batch, 8x128 ReLU MLP + Composite-Frequency(10, 12), REGULAR sampler, "
+                    f"{'the reference compositor fwd/bwd (RTXN_VR_COMPAT)' if mode == 'compat' else 'NeRF compositor'}, L2, Adam 1e-3; "
+                    f"{R}^3 grid ({'dense, as main.cu:394' if dense_grid else f'Lego stand-in, {100 * occ_frac:.1f}% cells'}), K=32; random targets",
+        "ms_per_step": round(ms, 4), "mrays_s": round(B * steps / dt / 1e6, 4), "steps": steps, "warmup": warmup, "samples_per_step": int(S),
+        "segment_capacity": cap, "truncated_steps": tr.truncated_steps, "loss_last": float(loss.item()), "step_form": "eager (segment count on the host, as main.cu:632)",
+        "stage_ms": {k: round(v, 4) for k, v in stages.items()},
+        "roofline": {"kernels": "mlp_train_fwd_kernel<128> + mlp_bwd_kernel<128> + wgrad_lds_kernel", "bound": "mfma", "achieved": round(tf, 1),
+                     "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_F16_DENSE_PEAK_TFLOPS, 4),
+                     "flop_per_sample": flop, "samples_per_launch": int(S), "traffic": None,
+                     "note": "whole step; the MLP kernels materialise activations and dZ (2 B x 128 per sample and layer, written once and read "
+                             "twice): their HBM floor is 8 layers x 128 x 2 B x 5 passes = 10 KB per sample"},
+    }
+    mlp_ms = sum(stages.get(k, 0.0) for k in ("mlp_fwd", "mlp_bwd+wgrad"))
+    if mlp_ms > 0:
+        rec["roofline"]["mlp_kernels_ms"] = round(mlp_ms, 4)
+        rec["roofline"]["mlp_kernels_frac"] = round(flop * S / (mlp_ms * 1e-3) / 1e12 / MFMA_F16_DENSE_PEAK_TFLOPS, 4)
+        rec["roofline"]["mlp_kernels_hbm_floor_gbs"] = round(10240 * S / (mlp_ms * 1e-3) / 1e9, 1)
     del tr
     torch.cuda.empty_cache()
     return rec
+
+
+def extra_train_ref8x128(steps, warmup):
+    return {"b22528_dense8": train_ref_record(128 * 176, 8, steps, warmup),
+            "b45056_dense8": train_ref_record(256 * 176, 8, max(4, steps // 2), warmup),
+            "b4096_lego128_nerf": train_ref_record(4096, 128, 3 * steps, warmup, dense_grid=False, mode="nerf")}
 
 
 def extra_config5(steps, warmup, kernel_steps):
@@ -480,7 +648,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras and not args.emulate_shard_of:
         del pipe
         torch.cuda.empty_cache()
-        out["train_config3"] = extra_train_config3(args.extra_steps, 5)
+        out["train_config3"], out["render_hash4x64"] = extra_train_config3(args.extra_steps, 5, args.kernel_steps)
+        out["train_ref8x128"] = extra_train_ref8x128(max(6, args.extra_steps // 3), 3)
         out["config5"] = extra_config5(max(8, args.extra_steps // 2), 3, args.kernel_steps)
     if rank == 0:
         print(json.dumps(out), flush=True)
