@@ -358,9 +358,12 @@ def train_ref_record(batch_rays, grid_res, steps, warmup, dense_grid=True, mode=
 
 
 def extra_train_ref8x128(steps, warmup):
+    # (the 4096-ray variant first: measured in the same process AFTER the two large ones -- 70-GB workspaces allocated and
+    # released -- its steps took twice as long)
+    small = train_ref_record(4096, 128, 3 * steps, warmup, dense_grid=False, mode="nerf")
     return {"b22528_dense8": train_ref_record(128 * 176, 8, steps, warmup),
             "b45056_dense8": train_ref_record(256 * 176, 8, max(4, steps // 2), warmup),
-            "b4096_lego128_nerf": train_ref_record(4096, 128, 3 * steps, warmup, dense_grid=False, mode="nerf")}
+            "b4096_lego128_nerf": small}
 
 
 def extra_config5(steps, warmup, kernel_steps):

@@ -564,6 +564,14 @@ int rtxn_mlp_train_backward_recompute_live(const rtxn_mlp* m, const void* encT, 
 int rtxn_mlp_train_backward_live(const rtxn_mlp* m, const void* encT, const void* output_half, const void* dout_half4,
                                  long n_samples, void* workspace, const void* live_ws, float* dparams, void* dencT,
                                  rtxn_stream_t stream);
+/* The saving half of network->forward over the live segments only: a step that has run rtxn_mlp_train_forward_outputs over
+ * the whole batch (outputs, no activations), the compositor and rtxn_live_segments then saves the activations of just the
+ * segments the backward will visit -- into the same workspace, at the same places rtxn_mlp_train_forward would have put them,
+ * so rtxn_mlp_train_backward_live reads them unchanged.  (In NeRF training 70-90 % of a batch lies behind the first surface
+ * and carries no gradient: the full saving forward is the largest kernel of the 8x128 step, and most of what it writes is
+ * never read.) */
+int rtxn_mlp_train_forward_live(const rtxn_mlp* m, const void* encT, long n_samples, void* workspace, const void* live_ws,
+                                rtxn_stream_t stream);
 int rtxn_hashgrid_backward_segments_live(const rtxn_hashgrid* g, const float* start_points, const float* end_points,
                                          long n_segments, int sample_type, const void* dencT, const void* live_ws,
                                          float* dtable, void* dtable_hashed_half, rtxn_stream_t stream);

@@ -185,6 +185,7 @@ SYMBOLS = {
     "rtxn_live_segments": (_I, [_P, _L, _L, _P, _P]),
     "rtxn_mlp_train_backward_recompute_live": (_I, [_P, _P, _P, _P, _L, _P, _P, _P, _P]),
     "rtxn_mlp_train_backward_live": (_I, [_P, _P, _P, _P, _L, _P, _P, _P, _P, _P]),
+    "rtxn_mlp_train_forward_live": (_I, [_P, _P, _L, _P, _P, _P]),
     "rtxn_hashgrid_backward_segments_live": (_I, [_P, _P, _P, _L, _I, _P, _P, _P, _P, _P]),
     "rtxn_load_images_json": (_I, [C.c_char_p, C.c_char_p, _I, C.POINTER(ImageDataset)]),
     "rtxn_free_image_dataset": (None, [C.POINTER(ImageDataset)]),

@@ -509,6 +509,13 @@ def _net_train_backward_live(self, encT, output, dout, n, workspace, live_ws, dp
                                                  _ptr(dencT, torch.float16, "dencT"), _stream()), "rtxn_mlp_train_backward_live")
 
 
+def _net_train_forward_live(self, encT, n, workspace, live_ws):
+    """network->forward's SAVED ACTIVATIONS for the live segments only (the outputs come from train_forward_outputs)."""
+    check(_lib.lib().rtxn_mlp_train_forward_live(self._h, _ptr(encT, torch.float16, "encT"), n, _ptr(workspace, torch.float16, "workspace"),
+                                                 _ptr(live_ws, None, "live_ws"), _stream()), "rtxn_mlp_train_forward_live")
+
+
+Network.train_forward_live = _net_train_forward_live
 Network.train_backward_recompute_live = _net_train_backward_recompute_live
 Network.train_backward_live = _net_train_backward_live
 Network.train_workspace = _net_train_workspace

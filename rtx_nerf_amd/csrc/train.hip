@@ -442,7 +442,7 @@ struct TrainArgs {
   _Float16* dzL;            // [16][Sp]
   _Float16* dencT;          // [E][Sp] or NULL
   uint8_t* live_tiles;      // [Sp / 256]: backward: 1 where the tile carries a non-zero loss gradient (weight-gradient kernels skip the others)
-  const int* live_list;     // backward: segments that carry a loss gradient (rtxn_live_segments), or NULL.  The chain then visits
+  const int* live_list;     // segments that carry a loss gradient (rtxn_live_segments), or NULL.  Backward: the chain then visits
   const int* live_count;    // only those, and dz / dzL are written COMPACT (slot * 32 + sample) for the weight-gradient kernels
 };
 
@@ -465,7 +465,12 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_train_fwd_kernel(TrainArgs a)
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
   a.S = live_samples(a.dc, a.S);
-  if ((long)blockIdx.x * kTile >= a.S) return;
+  // Live list (SAVE only): the saving pass of a step whose outputs were already computed for every sample by the outputs-only
+  // kernel -- it visits only the segments that carry a loss gradient (a column tile is one segment, a block tile any eight),
+  // and leaves their activations where the full pass would have (the backward kernels and the weight-gradient GEMM read them
+  // there); slots past the list neither store nor count.
+  const int live_n = a.live_list ? *a.live_count : 0;
+  if (a.live_list ? (int)blockIdx.x * 8 >= live_n : (long)blockIdx.x * kTile >= a.S) return;
   const long tile0 = (long)blockIdx.x * kTile + wave * 64;
   const int KS0 = a.E / 16;
   const int L = a.n_hidden;
@@ -473,11 +478,19 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_train_fwd_kernel(TrainArgs a)
 
   // per-lane byte offset of this lane's sample within a feature row, lane-half row shift (4h rows) folded in
   unsigned lane_off[2];
-  bool ok_s[2];
+  bool ok_s[2], store_s[2];
+  long samp[2];
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct) {
-    const long s = tile0 + ct * 32 + col;
+    long s = tile0 + ct * 32 + col;
     ok_s[ct] = s < a.S;
+    store_s[ct] = true;                                   // padding columns of the last tile are written as zeros
+    if (a.live_list) {
+      const int slot = (int)blockIdx.x * 8 + wave * 2 + ct;
+      ok_s[ct] = store_s[ct] = slot < live_n;
+      s = (long)(ok_s[ct] ? a.live_list[slot] : 0) * 32 + col;     // slots past the list read segment 0 and store nothing
+    }
+    samp[ct] = s;
     lane_off[ct] = (unsigned)((s + 4L * h * a.Sp) * 2);
   }
   // ---- layer 0: B fragments straight from encT (8 two-byte loads per k-step per column tile) ----
@@ -522,7 +535,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_train_fwd_kernel(TrainArgs a)
       for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-          *row_elem(dst, perm_feature(kk, 0, j), a.Sp, lane_off[ct]) = ok_s[ct] ? v[kk][ct][j] : (_Float16)0.0f;
+          if (store_s[ct]) *row_elem(dst, perm_feature(kk, 0, j), a.Sp, lane_off[ct]) = ok_s[ct] ? v[kk][ct][j] : (_Float16)0.0f;
     // sign masks for the backward chain (read by mlp_bwd_kernel<64> only, see there): values are post-ReLU (>= 0), so
     // "> 0" is "the half is not +0"
     if constexpr (W == 64)
@@ -541,7 +554,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_train_fwd_kernel(TrainArgs a)
         }
         mk |= (unsigned long long)bits << (8 * kk);
       }
-      a.masks[((long)l * a.Sp + tile0 + ct * 32 + col) * 2 + h] = mk;
+      if (store_s[ct]) a.masks[((long)l * a.Sp + samp[ct]) * 2 + h] = mk;
     }
   };
   save_acts(0, bf);
@@ -585,6 +598,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_train_fwd_kernel(TrainArgs a)
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) bf[kk][ct] = bg[kk][ct];
   }
+  if (a.live_list) return;                                // the live pass saves activations only: the outputs exist already
   // ---- output layer ----
   __syncthreads();
   stage_rt(a.packed + off, smem, KS * 1024, tid);
@@ -1617,6 +1631,11 @@ extern "C" int rtxn_encode_frequency_segments(const rtxn_mlp* m, const float* st
   return encode_frequency_impl(m, src, encT, t_vals, t_scale, n_segments * 32, DevCount{nullptr, 0}, stream);
 }
 
+// live-segment workspace (rtxn_live_segments): [int count | 12 B pad | int list[capacity] | uint8 flags[capacity]]
+static size_t live_ws_bytes(long capacity) { return (size_t)(16 + 4 * capacity + ((capacity + 15) / 16) * 16); }
+static const int* live_count_of(const void* ws) { return static_cast<const int*>(ws); }
+static const int* live_list_of(const void* ws) { return reinterpret_cast<const int*>(static_cast<const uint8_t*>(ws) + 16); }
+
 // hipFuncSetAttribute once per (device, kernel): not repeated in front of every launch (and never inside a stream capture
 // after the first, un-captured, call)
 static hipError_t set_lds_once(const void* fn, int bytes) {
@@ -1641,7 +1660,8 @@ static hipError_t set_lds_once(const void* fn, int bytes) {
 
 // workspace == NULL: outputs only (the forward half of the recompute path)
 static int train_forward_impl(const rtxn_mlp* m, const void* encT, long n_samples, void* workspace, void* output_half,
-                              float* radiance, DevCount dc, rtxn_stream_t stream) {
+                              float* radiance, DevCount dc, rtxn_stream_t stream, const int* live_list = nullptr,
+                              const int* live_count = nullptr) {
   const int W = m->cfg.n_neurons;
   const long Sp = padded(n_samples);
   // outputs only, 64 wide: the all-asm 16x16x32 kernel with the weights resident in LDS (hashmlp.hip) -- the same layer stack
@@ -1666,6 +1686,8 @@ static int train_forward_impl(const rtxn_mlp* m, const void* encT, long n_sample
   }
   a.out_half = static_cast<_Float16*>(output_half);
   a.radiance = reinterpret_cast<float4*>(radiance);
+  a.live_list = live_list;
+  a.live_count = live_count;
   const int RT = W / 32, KS = W / 16, KS0 = a.E / 16;
   const size_t lds = (size_t)(KS0 > KS ? KS0 : KS) * RT * 1024;
   hipStream_t s = rtxn::as_stream(stream);
@@ -1691,6 +1713,19 @@ extern "C" int rtxn_mlp_train_forward(const rtxn_mlp* m, const void* encT, long 
   if (n_samples == 0) return RTXN_OK;
   RTXN_REQUIRE(encT && workspace && output_half, "rtxn_mlp_train_forward: NULL buffer");
   return train_forward_impl(m, encT, n_samples, workspace, output_half, radiance, DevCount{nullptr, 0}, stream);
+}
+
+extern "C" int rtxn_mlp_train_forward_live(const rtxn_mlp* m, const void* encT, long n_samples, void* workspace, const void* live_ws,
+                                           rtxn_stream_t stream) {
+  int rc = check_train(m, "rtxn_mlp_train_forward_live");
+  if (rc != RTXN_OK) return rc;
+  RTXN_REQUIRE(n_samples >= 0 && n_samples <= kMaxTrainSamples && n_samples % 32 == 0,
+               "rtxn_mlp_train_forward_live: n_samples = %ld must be whole segments in [0, %ld]", n_samples, kMaxTrainSamples);
+  RTXN_DEVICE_OR_FAIL();
+  if (n_samples == 0) return RTXN_OK;
+  RTXN_REQUIRE(encT && workspace && live_ws, "rtxn_mlp_train_forward_live: NULL buffer");
+  return train_forward_impl(m, encT, n_samples, workspace, nullptr, nullptr, DevCount{nullptr, 0}, stream, live_list_of(live_ws),
+                            live_count_of(live_ws));
 }
 
 static int train_backward_impl(const rtxn_mlp* m, const void* encT, const void* output_half, const void* dout_half4,
@@ -2103,10 +2138,6 @@ extern "C" int rtxn_adam_step_captured(long n, float* master, void* params_fp16,
 }
 
 // ------------------------------------------------------------------------- live segments
-// workspace: [int count | 12 B pad | int list[capacity] | uint8 flags[capacity]]
-static size_t live_ws_bytes(long capacity) { return (size_t)(16 + 4 * capacity + ((capacity + 15) / 16) * 16); }
-static const int* live_count_of(const void* ws) { return static_cast<const int*>(ws); }
-static const int* live_list_of(const void* ws) { return reinterpret_cast<const int*>(static_cast<const uint8_t*>(ws) + 16); }
 
 extern "C" size_t rtxn_live_segments_workspace_bytes(long segment_capacity) {
   return segment_capacity < 0 ? 0 : live_ws_bytes(segment_capacity);
@@ -2219,8 +2250,10 @@ extern "C" int rtxn_train_gradients(const rtxn_train_batch* b, rtxn_stream_t str
   rc = hash ? hashgrid_encode_impl(b->grid, b->n_dir_freqs, b->table_fp16, src, b->encT, b->t_vals, b->t_scale, cap_samples, dc, stream)
             : encode_frequency_impl(m, src, b->encT, b->t_vals, b->t_scale, cap_samples, dc, stream);
   if (rc != RTXN_OK) return rc;
-  // network->forward (main.cu:721)
-  rc = train_forward_impl(m, b->encT, cap_samples, b->workspace, b->output_half, b->radiance, dc, stream);
+  // network->forward (main.cu:721).  Saved-activation models with a live list and the NeRF compositor (whose gradient vanishes
+  // behind the first surface): outputs only here, the activations of the live segments are saved after the compositor.
+  const bool two_pass = !recompute && b->live_ws != nullptr && b->vr_mode == RTXN_VR_NERF;
+  rc = train_forward_impl(m, b->encT, cap_samples, two_pass ? nullptr : b->workspace, b->output_half, b->radiance, dc, stream);
   if (rc != RTXN_OK) return rc;
   // launch_volrender_cuda, loss->evaluate, launch_volrender_backward_cuda (main.cu:737-767): per ray, no sample count needed
   if (b->vr_mode == RTXN_VR_NERF) {
@@ -2245,6 +2278,10 @@ extern "C" int rtxn_train_gradients(const rtxn_train_batch* b, rtxn_stream_t str
   }
   const int* ll = use_live ? live_list_of(b->live_ws) : nullptr;
   const int* lc = use_live ? live_count_of(b->live_ws) : nullptr;
+  if (two_pass) {
+    rc = train_forward_impl(m, b->encT, cap_samples, b->workspace, nullptr, nullptr, dc, stream, ll, lc);
+    if (rc != RTXN_OK) return rc;
+  }
   rc = recompute ? train_backward_recompute_impl(m, b->encT, b->output_half, b->radiance_gradients, cap_samples, b->dparams, b->dencT, dc, stream, ll, lc)
                  : train_backward_impl(m, b->encT, b->output_half, b->radiance_gradients, cap_samples, b->workspace, b->dparams,
                                        hash ? b->dencT : nullptr, dc, stream, ll, lc);

@@ -112,6 +112,13 @@ class Trainer:
         # lies behind the first surface, where dL/d(radiance) is exactly 0).  A column tile of the backward kernels is one
         # segment, so a block tile can be any eight of them.  Needs the folded sampler.  RTXN_TRAIN_LIVE_SEGMENTS=0: every segment.
         self.live_segments = self.fold_sampler and os.environ.get("RTXN_TRAIN_LIVE_SEGMENTS", "1") != "0"
+        # Saved-activation models (128 wide, or RTXN_TRAIN_RECOMPUTE=0) in "nerf" mode: the forward of a step runs OUTPUTS-ONLY over
+        # the whole batch, and the activations are saved afterwards for the live segments alone (rtxn_mlp_train_forward_live) --
+        # the full saving forward is HBM-bound on activations of which 70-90 % are never read.  ("compat" mode: the reference's
+        # backward has no transmittance factor, every segment is live, one saving pass is the cheaper form.)
+        # RTXN_TRAIN_TWO_PASS=0: one saving pass over everything.
+        self.two_pass = (not self.recompute and self.live_segments and mode == "nerf"
+                         and os.environ.get("RTXN_TRAIN_TWO_PASS", "1") != "0")
         # ---- per-step buffers at capacity ---------------------------------------------------------
         B = batch_rays
         self.max_segments = int(max_segments) if max_segments else 64 * B
@@ -185,7 +192,9 @@ class Trainer:
         rewritten with the same values the folded path produced)."""
         self._sample(n, min(int(self.total.item()), self.max_segments))
 
-    def _forward(self, S, from_samples=False):
+    def _forward(self, S, from_samples=False, save=True):
+        """encoding + network->forward over the batch's S samples; save=False: outputs only (rendering; the first pass of the
+        two-pass step)."""
         P = S // api.NUM_SAMPLES_PER_SEGMENT
         t_scale = self.density_scale if self.mode == "nerf" else 1.0
         with _Stage(self, "encode"):
@@ -201,7 +210,7 @@ class Trainer:
             else:
                 self.net.encode_frequency(self.samples[:S], self.encT)
         with _Stage(self, "mlp_fwd"):
-            if self.recompute:
+            if self.recompute or not save:
                 self.net.train_forward_outputs(self.encT, S, self.out, self.radiance)
             else:
                 self.net.train_forward(self.encT, S, self.ws, self.out, self.radiance)
@@ -215,7 +224,7 @@ class Trainer:
             self._sample(n, P)
         if S:
             if radiance_fn is None:
-                self._forward(S)
+                self._forward(S, save=False)
             else:
                 self.radiance[:S] = radiance_fn(self.samples[:S])
         vr = api.VR_NERF if self.mode == "nerf" else api.VR_COMPAT
@@ -274,7 +283,7 @@ class Trainer:
             return 0
         if not self.fold_sampler:
             self._sample(n, P)
-        self._forward(S)
+        self._forward(S, save=not self.two_pass)
         if self.mode == "nerf" and self.fuse_compositor:
             with _Stage(self, "composite_fwd+l2+bwd"):   # one launch: the backward's first sweep IS the forward
                 api.volrender_l2_train(self.radiance, self.t_vals, self.num_stored, self.indices, n, K, targets, self.loss_scale,
@@ -291,6 +300,9 @@ class Trainer:
         if self.live_segments:
             with _Stage(self, "live_segments"):
                 api.live_segments(self.dout, P, self.max_segments, self.live_ws)
+        if self.two_pass:
+            with _Stage(self, "mlp_fwd_live"):       # the activations of the segments the backward is about to visit
+                self.net.train_forward_live(self.encT, S, self.ws, self.live_ws)
         with _Stage(self, "mlp_bwd+wgrad"):
             if self.live_segments and self.recompute:
                 self.net.train_backward_recompute_live(self.encT, self.out, self.dout, S, self.live_ws, self.dparams, self.dencT)

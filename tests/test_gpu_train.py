@@ -470,6 +470,25 @@ def test_live_segment_backward_of_the_saved_activation_path(gpu, W, L):
     a, b = de_full.cpu().numpy()[:, :S], de_live.cpu().numpy()[:, :S]
     np.testing.assert_array_equal(a[:, cols], b[:, cols])
     assert np.all(b[:, ~cols] == 7.0)
+    # Two-pass forward (round 3): outputs for everything (no workspace), activations for the LIVE segments only, saved into
+    # the workspace where the one-pass forward puts them; the live backward on that workspace gives the same results, and
+    # nothing outside the listed segments' columns is written (the fill value survives there).
+    out2 = net.train_forward_outputs(encT, S)
+    d = (out2.float() - out.float()).abs()
+    assert float(d.max()) <= 2e-3            # W = 64: 16x16x32 layer stack vs the saving kernel's 32x32x16 (fp16-ulp); W = 128: same kernel
+    if W == 128:
+        assert torch.equal(out2, out)
+    ws2 = torch.full_like(ws, 3.0)
+    net.train_forward_live(encT, S, ws2, lws)
+    acts_full = ws[:L * W * Sp].view(L, W, Sp)[:, :, :S].cpu().numpy()
+    acts_live = ws2[:L * W * Sp].view(L, W, Sp)[:, :, :S].cpu().numpy()
+    np.testing.assert_array_equal(acts_live[:, :, cols], acts_full[:, :, cols])
+    assert np.all(acts_live[:, :, ~cols] == 3.0)
+    dp2 = torch.zeros(net.n_params(), device="cuda")
+    de2 = torch.full((E, Sp), 7.0, dtype=torch.float16, device="cuda")
+    net.train_backward_live(encT, out, dout_d, S, ws2, lws, dp2, de2)
+    assert float((dp2 - dp_live).norm()) <= 1e-5 * float(dp_live.norm())
+    np.testing.assert_array_equal(de2.cpu().numpy()[:, :S][:, cols], b[:, cols])
 
 
 def test_hashgrid_out_of_domain_positions_stay_inside_the_table(gpu, oracle):
