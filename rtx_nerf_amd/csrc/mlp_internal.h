@@ -165,32 +165,6 @@ __device__ __forceinline__ void lds_wait_insn() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// pack2 unit P (0 .. 8*CT-1) of a finished accumulator tile -> dword (P%4) of B fragment dst[k0 + (P%8)/4][P/8]
-template <int NB, int CT, int P>
-__device__ __forceinline__ void convert_unit(const floatx16 (&acc)[CT], half8 (&dst)[NB][CT], int k0) {
-  constexpr int ct = P / 8, q = P % 8, s = q / 4, e = q % 4;
-  int4v t = __builtin_bit_cast(int4v, dst[k0 + s][ct]);
-  int r;
-  asm volatile("v_cvt_pk_f16_f32 %0, %1, %2\n\tv_pk_max_i16 %0, %0, 0"
-               : "=v"(r)
-               : "v"(acc[ct][8 * s + 2 * e]), "v"(acc[ct][8 * s + 2 * e + 1]));
-  t[e] = r;
-  dst[k0 + s][ct] = __builtin_bit_cast(half8, t);
-}
-template <int NB, int CT, int P0, int P1>
-__device__ __forceinline__ void convert_units(const floatx16 (&acc)[CT], half8 (&dst)[NB][CT], int k0) {
-  if constexpr (P0 < P1) {
-    convert_unit<NB, CT, P0>(acc, dst, k0);
-    convert_units<NB, CT, P0 + 1, P1>(acc, dst, k0);
-  }
-}
-// units [kk*U, (kk+1)*U) clipped to 8*CT
-template <int NB, int CT, int U, int KK>
-__device__ __forceinline__ void convert_slice(const floatx16 (&acc)[CT], half8 (&dst)[NB][CT], int k0) {
-  constexpr int p0 = KK * U < 8 * CT ? KK * U : 8 * CT, p1 = (KK + 1) * U < 8 * CT ? (KK + 1) * U : 8 * CT;
-  convert_units<NB, CT, p0, p1>(acc, dst, k0);
-}
-
 // The weights of the FOLLOWING stage are fetched while this one computes: one 1-KiB fragment per wave per k-step
 // (LDS-DMA), issued behind that k-step's MFMAs so that neither the address arithmetic nor the M0 set-up costs a slot in
 // which the matrix core idles.  Everything in a StageJob is wave-uniform.
@@ -209,50 +183,80 @@ __device__ __forceinline__ void stage_chunk(const StageJob& sj, int wave_u, int 
   }
 }
 
-// RT row tiles (RT == 0: the output layer's single tile, accumulated in acc[0] and left there unconverted).
-// PEND: acc[1] holds the previous layer's last row tile, to be converted into bf[KS-2], bf[KS-1].
-template <int RT, int KS, int NB, int CT, bool PEND, int I>
+// One k-step of the 32x32x16 pipeline (training forward, CT = 2) with NOTHING left to the compiler: the two MFMAs, accumulating
+// in place, and the NUP ReLU/convert units of the finished row tile as ONE asm statement, units interleaved with the MFMAs
+// (M0 u.. M1 u..).  Builtin MFMAs that hipcc may move, merge or re-allocate around asm units it cannot see into produced wrong,
+// timing-dependent values three times in this kernel family (history of 3.4); as one statement per k-step the step
+// is what the source says.  ZERO: first k-step of a row tile, C = 0.  Hazards, by construction: a unit reads a tile whose last
+// MFMA is at least two 16-pass MFMAs behind it; nothing here reads `dst`.
+#define RTXN_M32(ACC, B, C) "v_mfma_f32_32x32x16_f16 %[" ACC "], %[a], %[" B "], " C "\n\t"
+#define RTXN_PAIR32_CASES(M0, M1, ACC0, ACC1)                                                                                          \
+  if constexpr (NUP == 0) asm volatile(M0 M1 : ACC0, ACC1 : RTXN_IN32);                                                                  \
+  else if constexpr (NUP == 2)                                                                                                    \
+    asm volatile(M0 RTXN_UNIT32("0") M1 RTXN_UNIT32("1") : ACC0, ACC1, RTXN_UOUT(0, 0), RTXN_UOUT(1, 1) : RTXN_IN32, RTXN_UIN(0, 0), RTXN_UIN(1, 1)); \
+  else                                                                                                                            \
+    asm volatile(M0 RTXN_UNIT32("0") RTXN_UNIT32("1") M1 RTXN_UNIT32("2") RTXN_UNIT32("3")                                         \
+                 : ACC0, ACC1, RTXN_UOUT(0, 0), RTXN_UOUT(1, 1), RTXN_UOUT(2, 2), RTXN_UOUT(3, 3)                                         \
+                 : RTXN_IN32, RTXN_UIN(0, 0), RTXN_UIN(1, 1), RTXN_UIN(2, 2), RTXN_UIN(3, 3));
+#define RTXN_UNIT32(U) "v_cvt_pk_f16_f32 %[r" U "], %[x" U "], %[y" U "]\n\tv_pk_max_i16 %[r" U "], %[r" U "], 0\n\t"
+#define RTXN_IN32 [a] "v"(a), [b0] "v"(b0), [b1] "v"(b1)
+#define RTXN_UOUT(U, I) [r##U] "=&v"(r[I])
+#define RTXN_UIN(U, I) [x##U] "v"(x[I]), [y##U] "v"(y[I])
+template <bool ZERO, int NUP>
+__device__ __forceinline__ void pair32(floatx16& acc0, floatx16& acc1, const half8& a, const half8& b0, const half8& b1,
+                                       int (&r)[NUP > 0 ? NUP : 1], const float (&x)[NUP > 0 ? NUP : 1], const float (&y)[NUP > 0 ? NUP : 1]) {
+  static_assert(NUP == 0 || NUP == 2 || NUP == 4, "unit pattern not written");
+  if constexpr (ZERO) {
+    RTXN_PAIR32_CASES(RTXN_M32("c0", "b0", "0"), RTXN_M32("c1", "b1", "0"), [c0] "=&v"(acc0), [c1] "=&v"(acc1))
+  } else {
+    RTXN_PAIR32_CASES(RTXN_M32("c0", "b0", "%[c0]"), RTXN_M32("c1", "b1", "%[c1]"), [c0] "+v"(acc0), [c1] "+v"(acc1))
+  }
+}
+
+// RT row tiles of 32 rows (RT even: the LAST one is left unconverted in acc[1] for the caller), KS k-steps of 16, two
+// 32-sample column tiles.  A fragments come through a register ring of RTXN_PIPE slots filled with inline-asm ds_read_b128
+// that many k-steps ahead, with a counted s_waitcnt lgkmcnt(N) in front of each consumer (nothing else in this function may
+// touch LDS or SMEM); accumulators are double-buffered by row-tile parity: acc[rt & 1] collects row tile rt while the
+// finished tile rt-1 in acc[~rt & 1] is converted, U pack units per k-step, inside that k-step's asm statement.
+template <int RT, int KS, int NB, int I>
 struct PipeStep {
-  static constexpr int D = RTXN_PIPE, N = (RT ? RT : 1) * KS;
-  static constexpr int U = (8 * CT + KS - 1) / KS;                 // units per k-step, row tiles 1..
-  static constexpr int WIN = KS - 3 > 1 ? KS - 3 : 1;              // k-steps of row tile 0 the pending tile is spread over
-  static constexpr int UP = (8 * CT + WIN - 1) / WIN;
-  static constexpr int WAVES = RTXN_NW;
-  static constexpr int CHUNKS = N < 32 / WAVES ? N : 32 / WAVES;   // k-steps that carry a staging chunk: up to 32 KiB
+  static constexpr int CT = 2, D = RTXN_PIPE, N = RT * KS;
+  static constexpr int U = (8 * CT + KS - 1) / KS;                 // units per k-step, row tiles 1..: 2 (KS = 8) or 4 (KS = 4)
   __device__ static __forceinline__ void run(unsigned addr, half8 (&bf)[NB][CT], half8 (&nbf)[NB][CT], half8 (&ring)[D],
-                                             floatx16 (&acc)[2][CT], const StageJob& sj, int wave_u, int lane) {
+                                             floatx16 (&acc)[2][CT]) {
     constexpr int rt = I / KS, kk = I % KS, cur = rt & 1;
     constexpr int outstanding = (N - 1 - I) < (D - 1) ? (N - 1 - I) : (D - 1);   // reads issued after fragment I
-    lds_wait<outstanding>();
-    const half8 a = ring[I % D];
-    if (kk == 0) {
+    lds_wait_insn<outstanding>();
+    constexpr int p0 = rt > 0 ? (kk * U < 8 * CT ? kk * U : 8 * CT) : 0, p1 = rt > 0 ? ((kk + 1) * U < 8 * CT ? (kk + 1) * U : 8 * CT) : 0;
+    constexpr int NUP = p1 - p0;
+    int r[NUP > 0 ? NUP : 1];
+    float x[NUP > 0 ? NUP : 1], y[NUP > 0 ? NUP : 1];
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[cur][ct][e] = 0.0f;
+    for (int i = 0; i < NUP; ++i) {      // pack unit P: registers 8s + 2e, 8s + 2e + 1 of column tile P / 8 (s = (P % 8) / 4, e = P % 4)
+      const int P = p0 + i, ct = P / 8, q = P % 8;
+      x[i] = acc[cur ^ 1][ct][8 * (q / 4) + 2 * (q % 4)];
+      y[i] = acc[cur ^ 1][ct][8 * (q / 4) + 2 * (q % 4) + 1];
     }
+    pair32<kk == 0, NUP>(acc[cur][0], acc[cur][1], ring[I % D], bf[kk][0], bf[kk][1], r, x, y);
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) acc[cur][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[kk][ct], acc[cur][ct], 0, 0, 0);
-    if constexpr (rt > 0) convert_slice<NB, CT, U, kk>(acc[cur ^ 1], nbf, 2 * (rt - 1));
-    else if constexpr (PEND && kk < WIN) convert_slice<NB, CT, UP, kk>(acc[1], bf, KS - 2);
+    for (int i = 0; i < NUP; ++i) {      // -> dword e of B fragment nbf[2 (rt - 1) + s][ct]
+      const int P = p0 + i, ct = P / 8, q = P % 8;
+      int4v t = __builtin_bit_cast(int4v, nbf[2 * (rt - 1) + q / 4][ct]);
+      t[q % 4] = r[i];
+      nbf[2 * (rt - 1) + q / 4][ct] = __builtin_bit_cast(half8, t);
+    }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (I + D < N) lds_read_frag<(I + D) * 1024>(ring[I % D], addr);
-    if constexpr (I < CHUNKS) {
-      stage_chunk<I, WAVES>(sj, wave_u, lane);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if constexpr (I + 1 < N) PipeStep<RT, KS, NB, CT, PEND, I + 1>::run(addr, bf, nbf, ring, acc, sj, wave_u, lane);
+    if constexpr (I + 1 < N) PipeStep<RT, KS, NB, I + 1>::run(addr, bf, nbf, ring, acc);
   }
 };
 
-template <int RT, int KS, int NB, int CT, bool PEND>
-__device__ __forceinline__ void pipe_layer(const uint8_t* lds_buf, const StageJob& sj, half8 (&bf)[NB][CT], half8 (&nbf)[NB][CT],
-                                           floatx16 (&acc)[2][CT], int wave_u, int lane) {
-  constexpr int D = RTXN_PIPE, N = (RT ? RT : 1) * KS;
+template <int RT, int KS, int NB>
+__device__ __forceinline__ void pipe_layer(const uint8_t* lds_buf, half8 (&bf)[NB][2], half8 (&nbf)[NB][2], floatx16 (&acc)[2][2], int lane) {
+  constexpr int D = RTXN_PIPE, N = RT * KS;
   static_assert(D >= 1 && D <= 4, "ring depth");
-  static_assert(RT % 2 == 0, "the pending row tile must land in acc[1]");
-  static_assert(CT >= 2, "a unit must never read the accumulator of the MFMA issued just before it");
-  static_assert(!PEND || KS >= 4, "pending tile needs k-steps to hide in");
+  static_assert(RT % 2 == 0 && RT >= 2, "the pending row tile must land in acc[1]");
+  static_assert(KS == 4 || KS == 8, "unit patterns written for 2 or 4 units per k-step");
   static_assert(N * 1024 <= 65535 + 1024, "fragment offsets must fit the 16-bit ds offset");
   half8 ring[D];
   const unsigned addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) uint8_t*)lds_buf + lane * 16;
@@ -260,7 +264,10 @@ __device__ __forceinline__ void pipe_layer(const uint8_t* lds_buf, const StageJo
   if constexpr (D > 1 && N > 1) lds_read_frag<1024>(ring[1 % D], addr);
   if constexpr (D > 2 && N > 2) lds_read_frag<2048>(ring[2 % D], addr);
   if constexpr (D > 3 && N > 3) lds_read_frag<3072>(ring[3 % D], addr);
-  PipeStep<RT, KS, NB, CT, PEND, 0>::run(addr, bf, nbf, ring, acc, sj, wave_u, lane);
+  PipeStep<RT, KS, NB, 0>::run(addr, bf, nbf, ring, acc);
+  // the caller converts the pending tile in acc[1] with ordinary code, and hipcc cannot see the asm MFMAs that wrote it: the
+  // MFMA-result -> VALU-read wait states (16 passes + margin) are spent here, once per layer
+  asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -305,7 +312,7 @@ __device__ __forceinline__ void convert_slice16(const floatx4 (&acc)[CT], half8 
   convert_units16<NB, CT, RTI, p0, p1>(acc, dst);
 }
 
-// One k-step of the 16x16x32 pipeline with NOTHING left to the compiler (RTXN_ILV16, default on): the CT MFMAs, accumulating
+// One k-step of the 16x16x32 pipeline with NOTHING left to the compiler: the CT MFMAs, accumulating
 // in place, and the ReLU/convert units [P0, P1) of the finished tile RTI (accumulators `fin`) as asm, the units interleaved
 // with the MFMAs (M cvt M max ...).  Why: builtin MFMAs that hipcc may move, merge or re-allocate around asm units it cannot
 // see into produced wrong, timing-dependent values three times in this kernel family; as one asm statement per
@@ -314,9 +321,6 @@ __device__ __forceinline__ void convert_slice16(const floatx4 (&acc)[CT], half8 
 // step, interleaved 80, behind the last 98); it is the partner wave of the SIMD that hides it.
 // ZERO: first k-step of a row tile, C = 0.  Hazards, by construction as before: a unit reads a tile whose last MFMA is at
 // least CT MFMAs behind it; a chain accumulator meets its next MFMA CT - 1 MFMAs later; nothing here reads `dst`.
-#ifndef RTXN_ILV16
-#define RTXN_ILV16 1
-#endif
 // Two MFMAs and the NUP units behind them as ONE asm statement: between separate statements hipcc's hazard recogniser pads
 // a cvt -> max pair it cannot see through with s_nop (4 issue cycles).  NUP = 1: M0 cvt M1 max; 2: M0 cvt max M1 cvt max.
 #define RTXN_M16(ACC, B, C) "v_mfma_f32_16x16x32_f16 %[" ACC "], %[a], %[" B "], " C "\n\t"
@@ -324,8 +328,6 @@ __device__ __forceinline__ void convert_slice16(const floatx4 (&acc)[CT], half8 
 #define RTXN_MAX16(U) "v_pk_max_i16 %[r" U "], %[r" U "], 0\n\t"
 #define RTXN_UNIT16(U) RTXN_CVT16(U) RTXN_MAX16(U)
 #define RTXN_IN16 [a] "v"(a), [b0] "v"(b0), [b1] "v"(b1)
-#define RTXN_UOUT(U, I) [r##U] "=&v"(r[I])
-#define RTXN_UIN(U, I) [x##U] "v"(x[I]), [y##U] "v"(y[I])
 #define RTXN_PAIR16_CASES(M0, M1, ACC0, ACC1)                                                                                          \
   if constexpr (NUP == 0) asm volatile(M0 M1 : ACC0, ACC1 : RTXN_IN16);                                                                  \
   else if constexpr (NUP == 1) asm volatile(M0 RTXN_CVT16("0") M1 RTXN_MAX16("0") : ACC0, ACC1, RTXN_UOUT(0, 0) : RTXN_IN16, RTXN_UIN(0, 0)); \
@@ -396,7 +398,6 @@ struct PipeStep16 {
                                              floatx4 (&acc)[2][CT], const StageJob& sj, int wave_u, int lane) {
     constexpr int rt = I / KS, kk = I % KS, cur = rt & 1;
     constexpr int outstanding = (N - 1 - I) < (D - 1) ? (N - 1 - I) : (D - 1);
-#if RTXN_ILV16
     lds_wait_insn<outstanding>();
     if constexpr (rt > 0) {
       using R = UnitRange16<CT, U, kk>;
@@ -407,20 +408,6 @@ struct PipeStep16 {
     } else {
       mfma_convert_step16<NB, CT, 0, 0, 0, kk == 0>(ring[I % D], bf[kk], acc[cur], acc[cur], nbf);
     }
-#else
-    lds_wait<outstanding>();
-    const half8 a = ring[I % D];
-    if (kk == 0) {
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[cur][ct][e] = 0.0f;
-    }
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) acc[cur][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bf[kk][ct], acc[cur][ct], 0, 0, 0);
-    if constexpr (rt > 0) convert_slice16<NB, CT, rt - 1, U, kk>(acc[cur ^ 1], nbf);
-    else if constexpr (PEND && kk < WIN) convert_slice16<NB, CT, 2 * KS - 1, UP, kk>(acc[1], bf);
-#endif
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (I + D < N) lds_read_frag<(I + D) * 1024>(ring[I % D], addr);
     if constexpr (I < CHUNKS) {
@@ -448,11 +435,9 @@ __device__ __forceinline__ void pipe_layer16(const uint8_t* lds_buf, const Stage
   if constexpr (D > 2 && N > 2) lds_read_frag<2048>(ring[2 % D], addr);
   if constexpr (D > 3 && N > 3) lds_read_frag<3072>(ring[3 % D], addr);
   PipeStep16<RT, KS, NB, CT, PEND, 0>::run(addr, bf, nbf, ring, acc, sj, wave_u, lane);
-#if RTXN_ILV16
   // RT == 0: the caller reads acc[0] with ordinary code right behind this, and hipcc cannot see the asm MFMAs that wrote it:
   // the MFMA-result -> VALU-read wait states (8 passes + margin) are spent here, once per tile
   if constexpr (RT == 0) asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
-#endif
 }
 
 // The same 16x16x32 pipeline over one CHUNK of a streamed layer (the 256-wide kernel: a layer is 128 KiB of fragments and goes
@@ -476,7 +461,6 @@ struct PipeStep16c {
                                              floatx4 (&acc)[2][CT], const StageJob& sj, int wave_u, int lane) {
     constexpr int r = I / KS, kk = I % KS, cur = r & 1;
     constexpr int outstanding = (N - 1 - I) < (D - 1) ? (N - 1 - I) : (D - 1);
-#if RTXN_ILV16
     lds_wait_insn<outstanding>();
     if constexpr (r > 0 && kk >= 1) {
       using R = UnitRange16<CT, U, kk - 1>;
@@ -488,24 +472,6 @@ struct PipeStep16c {
     } else {
       mfma_convert_step16<NB, CT, 0, 0, 0, kk == 0>(ring[I % D], in[kk], acc[cur], acc[cur], out);
     }
-#else
-    lds_wait<outstanding>();
-    const half8 a = ring[I % D];
-    if (kk == 0) {
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[cur][ct][e] = 0.0f;
-    }
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) acc[cur][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, in[kk][ct], acc[cur][ct], 0, 0, 0);
-    if constexpr (r > 0) {
-      if constexpr (kk >= 1) convert_slice16<NB, CT, RT0 + r - 1, U, kk - 1>(acc[cur ^ 1], out);
-    } else if constexpr (PEND && kk < WIN) {
-      if constexpr (RT0 > 0) convert_slice16<NB, CT, RT0 - 1, UP, kk>(acc[1], out);
-      else convert_slice16<NB, CT, 2 * NB - 1, UP, kk>(acc[1], in);
-    }
-#endif
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (I + D < N) lds_read_frag<(I + D) * 1024>(ring[I % D], addr);
     if constexpr (I < CHUNKS) {

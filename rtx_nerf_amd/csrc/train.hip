@@ -562,9 +562,8 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_train_fwd_kernel(TrainArgs a)
   // compiler-scheduled loop kept all RT tiles live and spilled at W = 128); nothing is staged underneath it here, and
   // the row tile it leaves pending is converted at once because the activations are stored after every layer
   auto hidden_layer = [&](half8 (&in)[KS][2], half8 (&out)[KS][2]) {
-    const rtxn::StageJob none{a.packed, smem, 0};
     floatx16 acc2[2][2];
-    rtxn::pipe_layer<RT, KS, KS, 2, false>(smem, none, in, out, acc2, 0, lane);
+    rtxn::pipe_layer<RT, KS, KS>(smem, in, out, acc2, lane);
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
