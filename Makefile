@@ -6,7 +6,7 @@ SRCS := $(wildcard $(CSRC)/*.hip)
 OBJS := $(patsubst $(CSRC)/%.hip,build/%.o,$(SRCS)) build/loader.o
 HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -Iinclude -I$(CSRC) -Wall -Wno-unused-function
 
-all: rtx_nerf_amd/librtxn.so oracle examples/render_host
+all: rtx_nerf_amd/librtxn.so oracle examples/render_host check-isa
 
 # train.hip: -amdgpu-mfma-vgpr-form.  Its one kernel above 256 registers (mlp_bwd_fused64_kernel, one wave per SIMD) keeps the
 # weight-gradient accumulators in AGPRs by hand (asm "+a"); left to its heuristic, hipcc put the destination of EVERY MFMA of
@@ -15,6 +15,15 @@ build/train.o: EXTRA := -mllvm -amdgpu-mfma-vgpr-form
 build/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/mlp_internal.h $(CSRC)/hashgrid_internal.h include/rtxn.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) $(EXTRA) -c $< -o $@
+
+# ISA text of the files that hold asm MFMAs, and the static check that no compiler-generated instruction reads an asm MFMA's
+# result inside its wait states (tools/check_asm_mfma_reads.py; the round-3 hoisted-conversion bug)
+build/train.s: EXTRA := -mllvm -amdgpu-mfma-vgpr-form
+build/%.s: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/mlp_internal.h $(CSRC)/hashgrid_internal.h include/rtxn.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) $(EXTRA) -S --cuda-device-only $< -o $@
+check-isa: build/train.s build/mlp.s build/hashmlp.s
+	python3 tools/check_asm_mfma_reads.py $^
 
 build/loader.o: $(CSRC)/loader.cpp $(CSRC)/common.h include/rtxn.h
 	@mkdir -p build
@@ -35,4 +44,4 @@ clean:
 	rm -rf build rtx_nerf_amd/librtxn.so examples/render_host
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean
+.PHONY: all oracle clean check-isa

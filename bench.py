@@ -104,7 +104,7 @@ def extra_train_config3(steps, warmup, kernel_steps=5, train_to=1500, frames=12)
     occ = torch.from_numpy(scenes.pack_occupancy(dense).view(np.int32).copy()).cuda()
     hgd = dict(n_levels=16, n_features=2, log2_hashmap_size=19, base_resolution=16, per_level_scale=1.5)
     tr = Trainer(R, occ, encoding="hash", n_neurons=64, n_hidden_layers=4, hashgrid=hgd, n_dir_freqs=4,
-                 batch_rays=128 * 128, max_segments=128 * 128 * 24, lr=1e-2, loss_scale=128.0, density_scale=300.0, mode="nerf")
+                 batch_rays=128 * 128, max_segments=128 * 128 * 32, lr=1e-2, loss_scale=128.0, density_scale=300.0, mode="nerf")
     focal = scenes.lego_focal_length(True)
     ro, rd, tg = [], [], []
     for i in range(8):
@@ -231,7 +231,7 @@ def extra_render_hash(tr, step_captured, trained_steps, kernel_steps, train_to=1
     worst = pipe.calibrate(poses)
     # teacher frames of the held-out views: the trainer's staged path with the analytic field in place of the network, in chunks
     psnrs = []
-    B = tr.B
+    B = tr.B // 2                      # 8192 rays per chunk: an 800x800 view's chunks stay inside the trainer's segment capacity
     for la in held:
         o, d = camera_rays(la, focal, W, H)
         gt = torch.cat([tr.render_rays(o[i:i + B].contiguous(), d[i:i + B].contiguous(), radiance_fn=scenes.teacher_field).clone()

@@ -28,20 +28,50 @@ __device__ __forceinline__ unsigned hg_index(unsigned x, unsigned y, unsigned z,
   return ((x * 1u) ^ (y * 2654435761u) ^ (z * 805459861u)) % size;
 }
 
-// hg_index without the integer division: a hashed level's size is the table cap, a power of two (mask); a densely stored
-// level's index is below twice its size for a position inside the domain (x, y, z <= res), so one conditional subtract is the
-// modulo.  A position OUTSIDE [-1, 1]^3 (or an Inf / NaN) reaching the public encode / backward entry points gives cell
-// coordinates beyond res: the second compare then falls back to the real `% size`, so the index stays inside the level
-// whatever the input is -- the same wrap hg_index (and tcnn's grid_index) performs; never taken for in-domain samples.
-// `hashed` is uniform per launch row (one level), so the choice is a scalar branch.
+// hg_index without the integer division, for cell coordinates INSIDE the level (x, y, z <= res: a position in [-1, 1]^3 and
+// its +1 corners): a hashed level's size is the table cap, a power of two (mask); a densely stored level's index is then
+// below twice its size, so one conditional subtract is the modulo.  `hashed` is uniform per launch row / loop iteration (one
+// level), so the choice is a scalar branch and the rest is branch-free.
 __device__ __forceinline__ unsigned hg_index_nodiv(unsigned x, unsigned y, unsigned z, unsigned res, unsigned size, bool hashed) {
   if (hashed) return ((x * 1u) ^ (y * 2654435761u) ^ (z * 805459861u)) & (size - 1u);
-  unsigned i = x + y * res + z * res * res;
-  if (i >= size) {
-    i -= size;
-    if (__builtin_expect(i >= size, 0)) i %= size;
+  const unsigned i = x + y * res + z * res * res;
+  return i >= size ? i - size : i;
+}
+// A position OUTSIDE the domain (or an Inf / NaN) reaching the public encode / backward entry points gives a base cell
+// coordinate beyond res - 1 (negative coordinates convert to huge unsigned values): the single subtract above would then leave
+// the level.  The kernels test the base cell ONCE per sample and level -- three compares, wave-reduced with a ballot so that
+// the decision is a scalar branch -- and send such a wave through hg_index's real `% size`, the wrap tcnn's grid_index and the
+// oracle perform; in-domain waves never take it.  (Hashed levels are masked: always in range.)
+__device__ __forceinline__ bool hg_wave_out_of_domain(const unsigned (&g)[3], unsigned res) {
+  return __ballot((g[0] >= res) | (g[1] >= res) | (g[2] >= res)) != 0ull;
+}
+// The eight corner indices of base cell g, chosen by ONE scalar branch per level: lo[yz] = index of (g0, g1 + (yz & 1),
+// g2 + (yz >> 1)), hi[yz] the same with g0 + 1 (corner c of the trilinear loops = (c & 1 ? hi : lo)[c >> 1]).  Same values as
+// hg_index for every input.
+__device__ __forceinline__ void hg_corner_indices(const unsigned (&g)[3], unsigned res, unsigned size, bool hashed, unsigned (&lo)[4],
+                                                  unsigned (&hi)[4]) {
+  if (hashed) {
+    const unsigned m = size - 1u;
+#pragma unroll
+    for (int yz = 0; yz < 4; ++yz) {
+      const unsigned h = ((g[1] + (unsigned)(yz & 1)) * 2654435761u) ^ ((g[2] + (unsigned)(yz >> 1)) * 805459861u);
+      lo[yz] = (g[0] ^ h) & m;
+      hi[yz] = ((g[0] + 1u) ^ h) & m;
+    }
+  } else if (!hg_wave_out_of_domain(g, res)) {
+#pragma unroll
+    for (int yz = 0; yz < 4; ++yz) {
+      const unsigned i = g[0] + (g[1] + (unsigned)(yz & 1)) * res + (g[2] + (unsigned)(yz >> 1)) * res * res, j = i + 1u;
+      lo[yz] = i >= size ? i - size : i;
+      hi[yz] = j >= size ? j - size : j;
+    }
+  } else {
+#pragma unroll
+    for (int yz = 0; yz < 4; ++yz) {
+      lo[yz] = hg_index(g[0], g[1] + (unsigned)(yz & 1), g[2] + (unsigned)(yz >> 1), res, size);
+      hi[yz] = hg_index(g[0] + 1u, g[1] + (unsigned)(yz & 1), g[2] + (unsigned)(yz >> 1), res, size);
+    }
   }
-  return i;
 }
 
 __device__ __forceinline__ float sin_turns(float x, int f, int ph) {

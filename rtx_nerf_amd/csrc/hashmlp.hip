@@ -187,12 +187,7 @@ __global__ __launch_bounds__(kThreads, 3) void hashmlp_fwd_kernel(HashMlpArgs a)
       const bool shared = hashed && (gi[0] & 1u) == 0;
       unsigned e8[8], i_lo[4], i_hi[4];
       uint2 pr[4];
-#pragma unroll
-      for (int yz = 0; yz < 4; ++yz) {
-        const unsigned py = gi[1] + (unsigned)(yz & 1), pz = gi[2] + (unsigned)(yz >> 1);
-        i_lo[yz] = hg_index_nodiv(gi[0], py, pz, res, size, hashed);
-        i_hi[yz] = hg_index_nodiv(gi[0] + 1u, py, pz, res, size, hashed);
-      }
+      rtxn::hg_corner_indices(gi, res, size, hashed, i_lo, i_hi);
 #pragma unroll
       for (int yz = 0; yz < 4; ++yz) pr[yz] = *reinterpret_cast<const uint2*>(base + ((i_lo[yz] & ~1u) << 2));
       unsigned hi[4] = {0u, 0u, 0u, 0u};

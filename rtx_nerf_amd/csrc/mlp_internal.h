@@ -183,6 +183,20 @@ __device__ __forceinline__ void stage_chunk(const StageJob& sj, int wave_u, int 
   }
 }
 
+// Accumulators written by asm MFMAs and read next by ORDINARY code (a caller's conversion or epilogue): hipcc cannot see the
+// MFMAs, so the MFMA-result -> VALU-read wait states (16 passes + margin) are spent by hand -- and the accumulators must go
+// THROUGH the statement that spends them ("+v").  A bare `asm volatile("s_nop ..." ::: "memory")` orders nothing that lives in
+// registers: in the outputs-only 128-wide training forward hipcc hoisted the caller's first v_cvt_pk_f16_f32 above it, and
+// that one conversion read elements 0, 1 of the last column tile's pending row tile before the last k-step had landed
+// (features 96, 97, 100, 101 of column tile 1 one k-step short, every layer; found with tools/probe/fwd_hidden_dump.py,
+// profiles/r03/asm_tail_hazard.txt).  As operands of the statement no read of them can be scheduled above it.
+template <typename Acc, int CT>
+__device__ __forceinline__ void mfma_results_settle(Acc (&acc)[CT]) {
+  static_assert(CT == 2 || CT == 4, "operand lists written for 2 or 4 column tiles");
+  if constexpr (CT == 2) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]));
+  else asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+}
+
 // One k-step of the 32x32x16 pipeline (training forward, CT = 2) with NOTHING left to the compiler: the two MFMAs, accumulating
 // in place, and the NUP ReLU/convert units of the finished row tile as ONE asm statement, units interleaved with the MFMAs
 // (M0 u.. M1 u..).  Builtin MFMAs that hipcc may move, merge or re-allocate around asm units it cannot see into produced wrong,
@@ -265,9 +279,8 @@ __device__ __forceinline__ void pipe_layer(const uint8_t* lds_buf, half8 (&bf)[N
   if constexpr (D > 2 && N > 2) lds_read_frag<2048>(ring[2 % D], addr);
   if constexpr (D > 3 && N > 3) lds_read_frag<3072>(ring[3 % D], addr);
   PipeStep<RT, KS, NB, 0>::run(addr, bf, nbf, ring, acc);
-  // the caller converts the pending tile in acc[1] with ordinary code, and hipcc cannot see the asm MFMAs that wrote it: the
-  // MFMA-result -> VALU-read wait states (16 passes + margin) are spent here, once per layer
-  asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+  // the caller converts the pending tile in acc[1] with ordinary code: see mfma_results_settle
+  mfma_results_settle(acc[1]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -435,9 +448,8 @@ __device__ __forceinline__ void pipe_layer16(const uint8_t* lds_buf, const Stage
   if constexpr (D > 2 && N > 2) lds_read_frag<2048>(ring[2 % D], addr);
   if constexpr (D > 3 && N > 3) lds_read_frag<3072>(ring[3 % D], addr);
   PipeStep16<RT, KS, NB, CT, PEND, 0>::run(addr, bf, nbf, ring, acc, sj, wave_u, lane);
-  // RT == 0: the caller reads acc[0] with ordinary code right behind this, and hipcc cannot see the asm MFMAs that wrote it:
-  // the MFMA-result -> VALU-read wait states (8 passes + margin) are spent here, once per tile
-  if constexpr (RT == 0) asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+  // RT == 0: the caller reads acc[0] with ordinary code right behind this: see mfma_results_settle
+  if constexpr (RT == 0) mfma_results_settle(acc[0]);
 }
 
 // The same 16x16x32 pipeline over one CHUNK of a streamed layer (the 256-wide kernel: a layer is 128 KiB of fragments and goes

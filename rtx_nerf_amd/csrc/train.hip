@@ -234,12 +234,7 @@ __global__ __launch_bounds__(kThreads) void hashgrid_encode_f2_kernel(HgLevels l
     // measured no better (91 us): past this point the kernel is bound by the gather rate, not by the round trips.
     unsigned e[8], i_lo[4], i_hi[4];
     uint2 pr[4];
-#pragma unroll
-    for (int yz = 0; yz < 4; ++yz) {
-      const unsigned py = g[1] + (unsigned)(yz & 1), pz = g[2] + (unsigned)(yz >> 1);
-      i_lo[yz] = hg_index_nodiv(g[0], py, pz, res, size, hashed);
-      i_hi[yz] = hg_index_nodiv(g[0] + 1u, py, pz, res, size, hashed);
-    }
+    rtxn::hg_corner_indices(g, res, size, hashed, i_lo, i_hi);
 #pragma unroll
     for (int yz = 0; yz < 4; ++yz) pr[yz] = *reinterpret_cast<const uint2*>(base + ((i_lo[yz] & ~1u) << 2));
     unsigned hi[4] = {0u, 0u, 0u, 0u};
@@ -372,6 +367,8 @@ __global__ __launch_bounds__(kThreads) void hashgrid_backward_kernel(HgLevels lv
     g[a] = (unsigned)(int)fl;
     fr[a] = p - fl;
   }
+  unsigned i_lo[4], i_hi[4];
+  rtxn::hg_corner_indices(g, lv.res[l], lv.size[l], hashed_level, i_lo, i_hi);
   int run_start = lane;
   bool run_last = true;
   const unsigned k0 = ok ? (g[0] | (g[1] << 16)) : 0xffffffffu, k1 = ok ? g[2] : (unsigned)lane;
@@ -403,7 +400,7 @@ __global__ __launch_bounds__(kThreads) void hashgrid_backward_kernel(HgLevels lv
       w *= hi ? fr[a] : 1.0f - fr[a];
       p[a] = g[a] + (unsigned)hi;
     }
-    const unsigned idx = hg_index_nodiv(p[0], p[1], p[2], lv.res[l], lv.size[l], hashed_level);
+    const unsigned idx = (corner & 1) ? i_hi[corner >> 1] : i_lo[corner >> 1];
     if (PK) {
       float v0 = w * d[0], v1 = w * d[1];
       if (aggregate) {

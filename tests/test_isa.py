@@ -1,0 +1,52 @@
+"""Static check of the built ISA (no GPU): tools/check_asm_mfma_reads.py on the files that hold asm MFMAs, and the checker
+itself on two small texts (the round-3 hoisted-conversion bug and its fix)."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import check_asm_mfma_reads as chk  # noqa: E402
+
+BAD = """
+_Z6kernelv:
+	;;#ASMSTART
+	v_mfma_f32_32x32x16_f16 v[2:17], v[18:21], v[22:25], v[2:17]
+	;;#ASMEND
+	v_cvt_pk_f16_f32 v30, v2, v3
+	;;#ASMSTART
+	s_nop 15
+	s_nop 7
+	;;#ASMEND
+	v_cvt_pk_f16_f32 v31, v4, v5
+	s_endpgm
+"""
+GOOD = BAD.replace("	v_cvt_pk_f16_f32 v30, v2, v3\n", "").replace("v31, v4, v5", "v31, v2, v3")
+
+
+def test_checker_flags_a_read_hoisted_above_the_wait_states(tmp_path):
+    bad, good = tmp_path / "bad.s", tmp_path / "good.s"
+    bad.write_text(BAD)
+    good.write_text(GOOD)
+    found = chk.check(str(bad))
+    assert len(found) == 1 and "reads v2 0 wait states" in found[0]
+    assert chk.check(str(good)) == []
+
+
+def test_checker_ignores_reads_inside_asm_and_compiler_mfmas(tmp_path):
+    text = BAD.replace("	v_cvt_pk_f16_f32 v30, v2, v3\n", "	;;#ASMSTART\n	v_cvt_pk_f16_f32 v30, v2, v3\n	;;#ASMEND\n")
+    f = tmp_path / "a.s"
+    f.write_text(text)
+    assert chk.check(str(f)) == []
+    g = tmp_path / "b.s"
+    g.write_text(BAD.replace("	;;#ASMSTART\n	v_mfma", "	v_mfma", 1).replace("v[2:17]\n	;;#ASMEND", "v[2:17]", 1))
+    assert chk.check(str(g)) == []          # hipcc pads the MFMAs it emits itself
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not present")
+def test_built_isa_keeps_compiler_reads_behind_asm_mfma_wait_states():
+    out = subprocess.run(["make", "-C", ROOT, "-s", "-j4", "check-isa"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
