@@ -542,6 +542,9 @@ typedef struct rtxn_train_batch {
   void* dtable_hashed_half;         /* hash grid, optional: as rtxn_hashgrid_backward_segments */
   void* live_ws;                    /* optional: rtxn_live_segments_workspace_bytes(capacity); the backward then
                                        visits only the segments that carry a loss gradient (rtxn_live_segments) */
+  int skip_table_backward;          /* hash grid: != 0 stops after network->backward (dparams and dencT complete): the caller
+                                       runs rtxn_hashgrid_backward_segments[_live] itself -- data parallel: after handing the MLP
+                                       gradient to its all-reduce, which then runs beside the scatter */
 } rtxn_train_batch;
 int rtxn_train_gradients(const rtxn_train_batch* batch, rtxn_stream_t stream);
 
@@ -580,6 +583,22 @@ int rtxn_hashgrid_backward_segments_live(const rtxn_hashgrid* g, const float* st
  * data-parallel exchange sends the hashed levels' gradient in fp16 -- tiny-cuda-nn holds that gradient in fp16 throughout. */
 int rtxn_convert_f32_to_f16(const float* src, void* dst_half, long n, rtxn_stream_t stream);
 int rtxn_convert_f16_to_f32(const void* src_half, float* dst, long n, rtxn_stream_t stream);
+
+/* ---- sparse view of a half2 gradient (data-parallel exchange; no counterpart in the single-GPU reference) ----
+ * `values` is half2[n_entries] (the hashed levels' gradient: one entry = both features of a grid corner), cut into blocks of
+ * block_entries entries (one hash-grid level each).  A rank's batch touches 0.2 % .. 25 % of a 2^19-entry level, so a level
+ * is exchanged as (index, half2) pairs where that is smaller than the level: count, let the ranks agree per block, pack the
+ * chosen blocks, gather the lists, add every rank's list (the rank's own included, in rank order) into the cleared blocks.
+ *   rtxn_half2_count_nonzero: counts[b] = entries of block b with a non-zero half (device int[ceil(n_entries / block_entries)]).
+ *   rtxn_half2_pack_nonzero:  pairs (device uint32[capacity][2]: entry index, half2 bits) of the non-zero entries of the blocks
+ *     whose bit is set in block_mask (at most 64 blocks), in no particular order; *count (device int) = entries needed, which
+ *     may exceed capacity (the list is then cut off: size it from the counts).  clear != 0: the selected blocks are left zero.
+ *   rtxn_half2_add_pairs:     values[index] += value for `count` pairs (indices unique within a list; out-of-range ones are
+ *     ignored); fp16 adds. */
+int rtxn_half2_count_nonzero(const void* values, long n_entries, long block_entries, int* counts, rtxn_stream_t stream);
+int rtxn_half2_pack_nonzero(void* values, long n_entries, long block_entries, unsigned long long block_mask, long capacity,
+                            void* pairs, int* count, int clear, rtxn_stream_t stream);
+int rtxn_half2_add_pairs(void* values, long n_entries, const void* pairs, long count, rtxn_stream_t stream);
 
 /* ---- dataset loader (host only) ------------------------------------------------------- */
 /* Replaces load_images_json (loader/data_loader.cpp:34-94; jsoncpp + stb_image's stbi_loadf).

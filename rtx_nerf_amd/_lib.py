@@ -91,7 +91,8 @@ class TrainBatch(C.Structure):
                 ("encT", C.c_void_p), ("dencT", C.c_void_p), ("workspace", C.c_void_p), ("output_half", C.c_void_p),
                 ("radiance", C.c_void_p), ("t_vals", C.c_void_p), ("radiance_gradients", C.c_void_p),
                 ("pixels", C.c_void_p), ("loss_gradients_half", C.c_void_p), ("loss_sum", C.c_void_p),
-                ("dparams", C.c_void_p), ("dtable", C.c_void_p), ("dtable_hashed_half", C.c_void_p), ("live_ws", C.c_void_p)]
+                ("dparams", C.c_void_p), ("dtable", C.c_void_p), ("dtable_hashed_half", C.c_void_p), ("live_ws", C.c_void_p),
+                ("skip_table_backward", C.c_int)]
 
 
 class RenderConfig(C.Structure):
@@ -161,6 +162,9 @@ SYMBOLS = {
     "rtxn_hashgrid_encoded_width": (_I, [_P, _I]),
     "rtxn_hashgrid_level_offset": (_L, [_P, _I]),
     "rtxn_hashgrid_level_is_hashed": (_I, [_P, _I]),
+    "rtxn_half2_count_nonzero": (_I, [_P, _L, _L, _P, _P]),
+    "rtxn_half2_pack_nonzero": (_I, [_P, _L, _L, C.c_ulonglong, _L, _P, _P, _I, _P]),
+    "rtxn_half2_add_pairs": (_I, [_P, _L, _P, _L, _P]),
     "rtxn_convert_f32_to_f16": (_I, [_P, _P, _L, _P]),
     "rtxn_convert_f16_to_f32": (_I, [_P, _P, _L, _P]),
     "rtxn_hashgrid_encode": (_I, [_P, _I, _P, _P, _P, _L, _P]),

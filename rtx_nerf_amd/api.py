@@ -571,7 +571,7 @@ def adam_step_captured(master, params_fp16, grads, m, v, effective_lr, beta1=0.9
 def train_gradients(net, *, grid=None, n_dir_freqs=0, table=None, start_points, end_points, seg_view, num_stored, indices,
                     total_segments, segment_capacity, n_rays, sample_type, t_scale=1.0, vr_mode, targets, loss_scale,
                     encT, dencT=None, workspace=None, output_half, radiance, t_vals, radiance_gradients, pixels, loss_gradients,
-                    loss_sum=None, dparams, dtable=None, dtable_hashed_half=None, live_ws=None):
+                    loss_sum=None, dparams, dtable=None, dtable_hashed_half=None, live_ws=None, skip_table_backward=False):
     """rtxn_train_gradients: sampler ... backward of one batch with the segment count taken on the device (main.cu:703-781)."""
     b = _lib.TrainBatch()
     b.mlp, b.grid = net._h, (grid._h if grid is not None else None)
@@ -594,6 +594,7 @@ def train_gradients(net, *, grid=None, n_dir_freqs=0, table=None, start_points, 
     if live_ws is not None and live_ws.numel() * live_ws.element_size() < live_segments_workspace_bytes(segment_capacity):
         raise _lib.RtxnError("train_gradients: live_ws smaller than live_segments_workspace_bytes(segment_capacity)")
     b.live_ws = _ptr(live_ws, None, "live_ws")
+    b.skip_table_backward = 1 if skip_table_backward else 0
     for nm, t, need in (("encT", encT, net.encoded_width() * padded_samples(32 * int(segment_capacity))),
                         ("output_half", output_half, 32 * int(segment_capacity) * 16), ("radiance", radiance, 32 * int(segment_capacity) * 4),
                         ("t_vals", t_vals, 32 * int(segment_capacity)), ("radiance_gradients", radiance_gradients, 32 * int(segment_capacity) * 4),
@@ -603,6 +604,33 @@ def train_gradients(net, *, grid=None, n_dir_freqs=0, table=None, start_points, 
         if t.numel() < need:
             raise _lib.RtxnError(f"train_gradients: {nm} holds {t.numel()} elements, {need} needed for capacity {segment_capacity} / {n_rays} rays")
     check(_lib.lib().rtxn_train_gradients(C.byref(b), _stream()), "rtxn_train_gradients")
+
+
+def half2_count_nonzero(values, block_entries, counts=None):
+    """rtxn_half2_count_nonzero: non-zero half2 entries per block of `values` (fp16, two halves per entry) -> int32[blocks]."""
+    n = values.numel() // 2
+    nb = (n + block_entries - 1) // block_entries
+    if counts is None:
+        counts = torch.empty(nb, dtype=torch.int32, device=values.device)
+    check(_lib.lib().rtxn_half2_count_nonzero(_ptr(values, torch.float16, "values"), n, int(block_entries),
+                                              _ptr(counts, torch.int32, "counts"), _stream()), "rtxn_half2_count_nonzero")
+    return counts
+
+
+def half2_pack_nonzero(values, block_entries, block_mask, pairs, count, clear=True):
+    """rtxn_half2_pack_nonzero: (index, half2 bits) of the non-zero entries of the masked blocks -> pairs int32[capacity][2];
+    count (device int32[1]) = entries needed."""
+    check(_lib.lib().rtxn_half2_pack_nonzero(_ptr(values, torch.float16, "values"), values.numel() // 2, int(block_entries),
+                                             int(block_mask), pairs.numel() // 2, _ptr(pairs, torch.int32, "pairs"),
+                                             _ptr(count, torch.int32, "count"), 1 if clear else 0, _stream()), "rtxn_half2_pack_nonzero")
+
+
+def half2_add_pairs(values, pairs, count):
+    """rtxn_half2_add_pairs: values[index] += value over the first `count` pairs of one list."""
+    if count > pairs.numel() // 2:
+        raise _lib.RtxnError(f"half2_add_pairs: count {count} > {pairs.numel() // 2} pairs held")
+    check(_lib.lib().rtxn_half2_add_pairs(_ptr(values, torch.float16, "values"), values.numel() // 2, _ptr(pairs, torch.int32, "pairs"),
+                                          int(count), _stream()), "rtxn_half2_add_pairs")
 
 
 def live_segments_workspace_bytes(segment_capacity):

@@ -1954,6 +1954,120 @@ extern "C" int rtxn_convert_f16_to_f32(const void* src_half, float* dst, long n,
   RTXN_LAUNCH_CHECK("f16_to_f32_kernel");
   return RTXN_OK;
 }
+// ------------------------------------------------------------------------- sparse view of a half2 gradient
+// The data-parallel exchange of the hashed levels' gradient.  One rank's batch touches 0.2 % (late in training) to
+// 25 % (first steps, finest level) of a 2^19-entry level (tools/probe/hash_grad_density.py), so a level travels as a list of
+// (entry index, half2 bits) pairs wherever that is smaller than the level itself.  An entry is one half2 (both features of a
+// grid corner, as the scatter adds them); "non-zero" ignores the sign of a zero.
+__device__ __forceinline__ bool half2_nonzero(unsigned bits) { return (bits & 0x7fff7fffu) != 0u; }
+
+__global__ __launch_bounds__(kThreads) void half2_count_kernel(const unsigned* __restrict__ v, long n, long block_entries,
+                                                               int* __restrict__ counts) {
+  const int lane = threadIdx.x & 63;
+  for (long base = ((long)blockIdx.x * kThreads + threadIdx.x - lane); base < n; base += (long)gridDim.x * kThreads) {
+    const long i = base + lane;
+    const bool nz = i < n && half2_nonzero(v[i]);
+    const long b_first = base / block_entries, b_last = (base + 63 < n ? base + 63 : n - 1) / block_entries;
+    if (b_first == b_last) {                      // the wave's 64 entries lie in one block: one atomic
+      const int c = __popcll(__ballot(nz));
+      if (lane == 0 && c) atomicAdd(&counts[b_first], c);
+    } else if (nz) {
+      atomicAdd(&counts[i / block_entries], 1);
+    }
+  }
+}
+
+// Appends the non-zero entries of the selected blocks (bit b of block_mask) to `pairs` (wave-aggregated: one atomic per wave
+// and 64 entries); *count ends as the number of entries NEEDED -- entries past `capacity` are counted, not written.  CLEAR:
+// every entry of a selected block is left zero (the exchange adds all ranks' lists, the rank's own included, back into it).
+// The order of the list is whatever the atomics give; indices within a list are unique, so adding it is order-independent.
+template <bool CLEAR>
+__global__ __launch_bounds__(kThreads) void half2_pack_kernel(unsigned* __restrict__ v, long n, long block_entries,
+                                                              unsigned long long block_mask, long capacity,
+                                                              uint2* __restrict__ pairs, int* __restrict__ count) {
+  const int lane = threadIdx.x & 63;
+  for (long base = ((long)blockIdx.x * kThreads + threadIdx.x - lane); base < n; base += (long)gridDim.x * kThreads) {
+    const long i = base + lane;
+    unsigned bits = 0;
+    bool nz = false;
+    if (i < n && ((block_mask >> (i / block_entries)) & 1ull)) {
+      bits = v[i];
+      nz = half2_nonzero(bits);
+    }
+    if (CLEAR && bits != 0u) v[i] = 0u;           // the non-zero entries and any -0
+    const unsigned long long m = __ballot(nz);
+    if (m == 0ull) continue;                      // wave-uniform
+    int at = 0;
+    if (lane == 0) at = atomicAdd(count, __popcll(m));
+    at = __shfl(at, 0) + __popcll(m & ((1ull << lane) - 1ull));
+    if (nz && at < capacity) pairs[at] = make_uint2((unsigned)i, bits);
+  }
+}
+
+// values[index] += value for every pair of ONE list (unique indices: plain read-modify-write).  fp16 adds, as the scatter's
+// packed atomics do; every rank applies the ranks' lists in rank order to zeroed entries, so all ranks end bit-identical.
+__global__ __launch_bounds__(kThreads) void half2_add_pairs_kernel(unsigned* __restrict__ v, long n, const uint2* __restrict__ pairs,
+                                                                   long count) {
+  for (long k = (long)blockIdx.x * kThreads + threadIdx.x; k < count; k += (long)gridDim.x * kThreads) {
+    const uint2 e = pairs[k];
+    if (e.x >= (unsigned long long)n) continue;   // a foreign list is data, not a contract
+    const half2v a = __builtin_bit_cast(half2v, v[e.x]), b = __builtin_bit_cast(half2v, e.y);
+    const half2v r = {(_Float16)(a[0] + b[0]), (_Float16)(a[1] + b[1])};
+    v[e.x] = __builtin_bit_cast(unsigned, r);
+  }
+}
+
+static unsigned half2_grid(long n) {
+  const long blocks = (n + kThreads - 1) / kThreads;
+  return (unsigned)(blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks));
+}
+
+extern "C" int rtxn_half2_count_nonzero(const void* values, long n_entries, long block_entries, int* counts, rtxn_stream_t stream) {
+  RTXN_REQUIRE(n_entries >= 0 && block_entries > 0 && n_entries < (1L << 32), "rtxn_half2_count_nonzero: n_entries = %ld, block_entries = %ld",
+               n_entries, block_entries);
+  RTXN_DEVICE_OR_FAIL();
+  if (n_entries == 0) return RTXN_OK;
+  RTXN_REQUIRE(values && counts, "rtxn_half2_count_nonzero: NULL buffer");
+  const long n_blocks = (n_entries + block_entries - 1) / block_entries;
+  RTXN_HIP(hipMemsetAsync(counts, 0, sizeof(int) * n_blocks, rtxn::as_stream(stream)));
+  half2_count_kernel<<<half2_grid(n_entries), kThreads, 0, rtxn::as_stream(stream)>>>(static_cast<const unsigned*>(values), n_entries,
+                                                                                   block_entries, counts);
+  RTXN_LAUNCH_CHECK("half2_count_kernel");
+  return RTXN_OK;
+}
+
+extern "C" int rtxn_half2_pack_nonzero(void* values, long n_entries, long block_entries, unsigned long long block_mask, long capacity,
+                                       void* pairs, int* count, int clear, rtxn_stream_t stream) {
+  RTXN_REQUIRE(n_entries >= 0 && block_entries > 0 && n_entries < (1L << 32) && capacity >= 0,
+               "rtxn_half2_pack_nonzero: n_entries = %ld, block_entries = %ld, capacity = %ld", n_entries, block_entries, capacity);
+  RTXN_REQUIRE((n_entries + block_entries - 1) / block_entries <= 64, "rtxn_half2_pack_nonzero: %ld blocks do not fit the 64-bit block_mask",
+               (n_entries + block_entries - 1) / block_entries);
+  RTXN_DEVICE_OR_FAIL();
+  RTXN_REQUIRE(count, "rtxn_half2_pack_nonzero: NULL count");
+  RTXN_HIP(hipMemsetAsync(count, 0, sizeof(int), rtxn::as_stream(stream)));
+  if (n_entries == 0 || block_mask == 0ull) return RTXN_OK;
+  RTXN_REQUIRE(values && (pairs || capacity == 0), "rtxn_half2_pack_nonzero: NULL buffer");
+  if (clear)
+    half2_pack_kernel<true><<<half2_grid(n_entries), kThreads, 0, rtxn::as_stream(stream)>>>(
+        static_cast<unsigned*>(values), n_entries, block_entries, block_mask, capacity, static_cast<uint2*>(pairs), count);
+  else
+    half2_pack_kernel<false><<<half2_grid(n_entries), kThreads, 0, rtxn::as_stream(stream)>>>(
+        static_cast<unsigned*>(values), n_entries, block_entries, block_mask, capacity, static_cast<uint2*>(pairs), count);
+  RTXN_LAUNCH_CHECK("half2_pack_kernel");
+  return RTXN_OK;
+}
+
+extern "C" int rtxn_half2_add_pairs(void* values, long n_entries, const void* pairs, long count, rtxn_stream_t stream) {
+  RTXN_REQUIRE(n_entries >= 0 && count >= 0 && n_entries < (1L << 32), "rtxn_half2_add_pairs: n_entries = %ld, count = %ld", n_entries, count);
+  RTXN_DEVICE_OR_FAIL();
+  if (count == 0) return RTXN_OK;
+  RTXN_REQUIRE(values && pairs, "rtxn_half2_add_pairs: NULL buffer");
+  half2_add_pairs_kernel<<<half2_grid(count), kThreads, 0, rtxn::as_stream(stream)>>>(static_cast<unsigned*>(values), n_entries,
+                                                                                  static_cast<const uint2*>(pairs), count);
+  RTXN_LAUNCH_CHECK("half2_add_pairs_kernel");
+  return RTXN_OK;
+}
+
 extern "C" long rtxn_hashgrid_n_params(const rtxn_hashgrid* g) { return g ? g->n_params : -1; }
 extern "C" int rtxn_hashgrid_encoded_width(const rtxn_hashgrid* g, int n_dir_freqs) {
   if (!g || n_dir_freqs < 0) return -1;
@@ -2282,7 +2396,7 @@ extern "C" int rtxn_train_gradients(const rtxn_train_batch* b, rtxn_stream_t str
                  : train_backward_impl(m, b->encT, b->output_half, b->radiance_gradients, cap_samples, b->workspace, b->dparams,
                                        hash ? b->dencT : nullptr, dc, stream, ll, lc);
   if (rc != RTXN_OK) return rc;
-  if (hash) {
+  if (hash && !b->skip_table_backward) {
     const SampleSrc bsrc{nullptr, b->start_points, b->end_points, nullptr, b->sample_type == RTXN_SAMPLING_MIDPOINT_WORLD};
     rc = hashgrid_backward_impl(b->grid, bsrc, b->dencT, cap_samples, b->dtable, b->dtable_hashed_half, dc, stream, ll, lc);
   }

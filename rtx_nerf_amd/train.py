@@ -20,6 +20,7 @@ steps, exact gradients) that actually converges.  All arithmetic is in librtxn.s
 torch only owns buffers and a few trivial elementwise glue ops.
 """
 import json
+import os
 import struct
 
 import numpy as np
@@ -27,6 +28,10 @@ import torch
 import torch.distributed as dist
 
 from . import api
+
+
+def _world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
 class _Stage:
@@ -150,6 +155,12 @@ class Trainer:
         self.pixels = torch.empty((B, 3), device=d)
         self.loss_grads = torch.empty((B, 3), dtype=torch.float16, device=d)
         self.loss = torch.zeros(1, device=d)
+        # data parallel (world > 1): the MLP gradient's all-reduce is issued from inside gradients(), right behind the MLP
+        # backward, and runs beside the hash scatter; the hashed levels go through dp.Half2GradExchange (lists where a level
+        # is sparse, RTXN_DP_SPARSE=0: always the dense fp16 level)
+        self._dp_pending = None
+        self._dp_table = None
+        self.dp_sparse = os.environ.get("RTXN_DP_SPARSE", "1") != "0"         # "force": lists for every level (tests)
 
     # ------------------------------------------------------------------------------------------
     def _segments(self, rays_o, rays_d, n):
@@ -278,6 +289,7 @@ class Trainer:
                     self.dtable_h.zero_()
                 else:
                     self.dtable.zero_()
+        self._dp_pending = None
         if S == 0:
             self.loss.zero_()
             return 0
@@ -312,6 +324,8 @@ class Trainer:
                 self.net.train_backward_recompute(self.encT, self.out, self.dout, S, self.dparams, self.dencT)
             else:
                 self.net.train_backward(self.encT, self.out, self.dout, S, self.ws, self.dparams, self.dencT)
+        if _world() > 1:                       # the MLP gradient is complete: its all-reduce runs beside the hash scatter
+            self._dp_pending = [dist.all_reduce(self.dparams, async_op=True)]
         if self.encoding == "hash":
             with _Stage(self, "hash_bwd"):
                 if self.fold_sampler:
@@ -358,13 +372,14 @@ class Trainer:
         gradients are SUMMED across ranks and the mean over ranks is folded into Adam's loss_scale divisor.  EVERY rank
         takes part in the all-reduces and runs Adam in every step -- also a rank whose rays all miss the grid (its
         gradients are zero) -- so the ranks can neither deadlock nor drift apart in step count."""
-        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        world = _world()
         S = self.gradients(rays_o, rays_d, targets)
         if S == 0 and world == 1:
             return self.loss                  # nothing to learn from: no Adam step, step_count unchanged
         if world > 1:
             with _Stage(self, "allreduce"):
-                pending = [dist.all_reduce(self.dparams, async_op=True)]
+                # issued by gradients() behind the MLP backward; a rank without samples returned before that and joins here
+                pending, self._dp_pending = (self._dp_pending or [dist.all_reduce(self.dparams, async_op=True)]), None
                 if self.encoding == "hash":
                     pending.extend(self._allreduce_table_grad())
                 for w in pending:
@@ -387,6 +402,15 @@ class Trainer:
         pending = []
         if lo > 0:
             pending.append(dist.all_reduce(self.dtable[:lo], async_op=True))
+        if n > lo and self.hash_fp16 and self.dp_sparse:
+            # Round 3: with the scatter restricted to the live segments a level IS sparse (0.2 .. 25 % of its entries per
+            # rank and step): per level, lists of (index, half2) where they are smaller than the level -- see dp.py
+            if self._dp_table is None:
+                from .dp import Half2GradExchange
+                self._dp_table = Half2GradExchange(self.dtable_h, 1 << self.hg.cfg.log2_hashmap_size,
+                                                   force_lists=os.environ.get("RTXN_DP_SPARSE") == "force")
+            pending.extend(self._dp_table.exchange())
+            return pending
         if n > lo:
             if not self.hash_fp16:      # fp32 scatter (F != 2 or switched off): stage the hashed part in fp16 for the wire
                 if self.dtable_h is None:
@@ -403,10 +427,15 @@ class Trainer:
     def dp_bytes_per_step(self, world):
         """Bytes one rank sends (= receives) per step in a ring all-reduce of its gradients, for DESIGN.md 6."""
         f = 2.0 * (world - 1) / world
-        b = 4 * self.dparams.numel()
+        b = f * 4 * self.dparams.numel()
         if self.encoding == "hash":
-            b += 4 * self.hashed_lo + 2 * (self.dtable.numel() - self.hashed_lo)
-        return f * b
+            b += f * 4 * self.hashed_lo
+            last = self._dp_table.last if self._dp_table is not None else None
+            if last is not None and last["world"] == world:
+                b += last["bytes"]             # what the last step's exchange of the hashed levels moved (lists + dense levels)
+            else:
+                b += f * 2 * (self.dtable.numel() - self.hashed_lo)      # before any exchange ran: every level dense
+        return b
 
     def time_stages(self, rays_o, rays_d, targets, steps=5):
         """Run `steps` optimisation steps with HIP events around every stage (on the stream the kernels are launched on);
@@ -533,8 +562,12 @@ class Trainer:
         self._g_step = torch.full((1,), self.step_count, dtype=torch.int64, device=d)
         self._g_idx = torch.zeros(1, dtype=torch.int64, device=d)
         self._g_lr = torch.zeros((1, 2), device=d)
-        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        world = _world()
         self._g_world = world
+        # data parallel + hash grid: the scatter is captured as a graph of its own (rtxn_train_batch.skip_table_backward), so
+        # that the MLP gradient's all-reduce can be issued between the two and run beside it
+        self._g_split = world > 1 and self.encoding == "hash" and self.live_segments
+        self._g_split_table = None
 
         # one eager pass on a side stream (kernel attributes, lazy module state), then capture
         side = torch.cuda.Stream(device=d)
@@ -548,6 +581,8 @@ class Trainer:
             for k in range(len(sets)):
                 self._captured_traverse(k)
             self._captured_gradients(0)
+            if self._g_split:
+                self._captured_table_bwd(0)
             self._captured_apply(float(world))
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
@@ -602,6 +637,8 @@ class Trainer:
                             "prime": [capture(lambda k=k: self._captured_traverse(k)) for k in (0, 1)]}
         if not one:
             self._graphs["apply"] = capture(lambda: self._captured_apply(float(world)))
+            if self._g_split:
+                self._graphs["table_bwd"] = [capture(lambda k=k: self._captured_table_bwd(k)) for k in range(len(sets))]
         return self
 
     def _clear_grads(self):
@@ -638,7 +675,13 @@ class Trainer:
                             output_half=self.out, radiance=self.radiance, t_vals=self.t_vals, radiance_gradients=self.dout,
                             pixels=self.pixels, loss_gradients=self.loss_grads, loss_sum=self.loss, dparams=self.dparams,
                             dtable=self.dtable if hash_ else None, dtable_hashed_half=self.dtable_h if (hash_ and self.hash_fp16) else None,
-                            live_ws=self.live_ws if self.live_segments else None)
+                            live_ws=self.live_ws if self.live_segments else None, skip_table_backward=self._g_split)
+
+    def _captured_table_bwd(self, k):
+        """the hash scatter of set k's batch over the live list the gradient graph left (its count is on the device)"""
+        st = self._g_sets[k]
+        self.hg.backward_segments(st["start"], st["end"], self._g_cap, self._stype(), self.dencT, self.dtable,
+                                  self.dtable_h if self.hash_fp16 else None, live_ws=self.live_ws)
 
     def _captured_apply(self, grad_divisor):
         self._g_step.add_(1)
@@ -683,6 +726,8 @@ class Trainer:
         """world > 1: sum the gradients the gradient graph left, then replay the optimizer graph"""
         pending = [dist.all_reduce(self.dparams, async_op=True)]
         if self.encoding == "hash":
+            if self._g_split_table is not None:          # the scatter was left out of the gradient graph: it runs now, beside
+                self._graphs["table_bwd"][self._g_split_table].replay()      # the MLP gradient's all-reduce
             pending.extend(self._allreduce_table_grad())
         for w in pending:
             w.wait()
@@ -707,6 +752,7 @@ class Trainer:
             self._g_step_host += 1
             self._graphs["step"][0].replay()
             if self._g_world > 1:
+                self._g_split_table = 0 if self._g_split else None
                 self._finish_dp()
             return self.loss
         k = self._g_next
@@ -721,6 +767,7 @@ class Trainer:
         self._graphs["step"][k].replay()                # traverse into set k || train on set 1-k (the pending one)
         self._g_pending = k
         if self._g_world > 1:
+            self._g_split_table = 1 - k if self._g_split else None
             self._finish_dp()
         return self.loss
 
@@ -740,6 +787,7 @@ class Trainer:
         self._graphs["flush"][k].replay()
         self._g_pending = None
         if self._g_world > 1:
+            self._g_split_table = k if self._g_split else None
             self._finish_dp()
         return self.loss
 

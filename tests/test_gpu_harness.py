@@ -99,6 +99,27 @@ def test_data_parallel_captured_step(gpu, tmp_path):
     assert np.median(np.abs(pa - pb)) < 1e-4 and (np.abs(pa - pb) < 1e-2).mean() > 0.95
 
 
+@pytest.mark.parametrize("captured", [False, True])
+def test_data_parallel_lists_equal_dense_levels(gpu, tmp_path, captured):
+    """Round 3: the hashed levels' gradient travels as (index, half2) lists where a level is sparse (rtx_nerf_amd/dp.py).  Two
+    ranks, every level forced into list form (RTXN_DP_SPARSE=force) against every level dense (=0): the same training up to
+    the atomics order of two runs; the tool asserts that MLP and hash table are bit-identical across the ranks of a run.  captured: the gradient graph is split so that the scatter runs beside the
+    MLP gradient's all-reduce (rtxn_train_batch.skip_table_backward)."""
+    tool = os.path.join(ROOT, "tools", "train_dp_check.py")
+    outs = {}
+    for mode, port in (("force", 29561), ("0", 29563)):
+        env = dict(os.environ, RTXN_REHEARSE_ON_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", RTXN_DP_SPARSE=mode)
+        outs[mode] = str(tmp_path / f"dp_{mode}.npy")
+        subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                               "--master-addr", "127.0.0.1", "--master-port", str(port), tool, "--out", outs[mode], "--steps", "4"]
+                              + (["--captured"] if captured else []), env=env, timeout=900)
+    a, b = np.load(outs["force"]), np.load(outs["0"])
+    assert np.isfinite(a).all() and np.abs(a[1]).max() > 0
+    # two runs: their weight-gradient / scatter atomics differ in order (fp32 / fp16 sums), which Adam's 1/sqrt(v) turns into
+    # +-lr on entries whose gradient is ~0; the exchange adds nothing to that (tests/test_dp_exchange.py: bit-equal sums)
+    assert np.median(np.abs(a[1] - b[1])) < 1e-4 and (np.abs(a[1] - b[1]) < 1e-2).mean() > 0.95
+
+
 def test_data_parallel_rank_without_samples_keeps_in_step(gpu, tmp_path):
     """a rank whose rays all miss the grid used to return before the gradient all-reduce (the others then hung)
     with its Adam step index out of line.  Rank 1 of 2 gets only missing rays in every step: both ranks must finish, with

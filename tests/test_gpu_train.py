@@ -526,6 +526,64 @@ def test_outputs_only_forward_against_saving_forward_and_torch_per_column_tile(g
         assert torch.equal(saved, outs)
 
 
+def test_half2_sparse_gradient_primitives(gpu):
+    """rtxn_half2_count_nonzero / _pack_nonzero / _add_pairs (the device side of rtx_nerf_amd/dp.py): counts per block, a list
+    that holds exactly the non-zero entries of the masked blocks (any order, -0 is zero), the masked blocks cleared, capacity
+    respected with the full need reported, and pack -> add restoring the gradient bit for bit."""
+    torch = gpu
+    from rtx_nerf_amd import api
+    rng = np.random.default_rng(3)
+    block, nb = 1 << 12, 5
+    n = block * nb - 100                                   # ragged last block
+    v = np.zeros((n, 2), np.float16)
+    dens = [0.5, 0.01, 0.0, 0.2, 0.03]
+    for b in range(nb):
+        lo, hi = b * block, min(n, (b + 1) * block)
+        at = lo + np.nonzero(rng.uniform(size=hi - lo) < dens[b])[0]
+        v[at] = rng.standard_normal((at.size, 2)).astype(np.float16)
+        v[at[::7], 1] = 0                                  # entries with one zero half still count
+    v[block + 5] = (np.float16(-0.0), np.float16(0.0))
+    nz = (v.view(np.uint16) & 0x7fff).any(axis=1)
+    vals = _dev(torch, v.reshape(-1).copy())
+    counts = api.half2_count_nonzero(vals, block).cpu().numpy()
+    want_counts = [int(nz[b * block:(b + 1) * block].sum()) for b in range(nb)]
+    assert counts.tolist() == want_counts
+    mask = 0b11010                                         # blocks 1, 3, 4
+    need = want_counts[1] + want_counts[3] + want_counts[4]
+    pairs = torch.zeros((need + 10, 2), dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    api.half2_pack_nonzero(vals, block, mask, pairs, cnt, clear=True)
+    assert int(cnt.item()) == need
+    got = pairs[:need].cpu().numpy()
+    sel = np.zeros(n, bool)
+    for b in (1, 3, 4):
+        sel[b * block:(b + 1) * block] = True
+    want_idx = np.nonzero(nz & sel)[0]
+    order = np.argsort(got[:, 0])
+    np.testing.assert_array_equal(got[order, 0], want_idx)
+    np.testing.assert_array_equal(got[order, 1].view(np.uint32), v.view(np.uint32).reshape(-1)[want_idx])
+    after = vals.cpu().numpy().reshape(n, 2)
+    assert not after[sel].view(np.uint16).any()            # masked blocks cleared (the -0 too)
+    np.testing.assert_array_equal(after[~sel].view(np.uint16), v[~sel].view(np.uint16))
+    api.half2_add_pairs(vals, pairs, need)                 # 0 + x = x: the gradient is back
+    back = vals.cpu().numpy().reshape(n, 2)
+    np.testing.assert_array_equal(back[nz].view(np.uint16), v[nz].view(np.uint16))
+    assert not back[~nz].view(np.uint16).any()
+    api.half2_add_pairs(vals, pairs, need)                 # fp16 adds: x + x
+    twice = vals.cpu().numpy().reshape(n, 2)
+    np.testing.assert_array_equal(twice[sel], (v[sel].astype(np.float32) * 2).astype(np.float16))
+    # capacity smaller than the need: the list is cut off, the need still reported, nothing written past the capacity
+    vals2 = _dev(torch, v.reshape(-1).copy())
+    small = torch.full((8, 2), -1, dtype=torch.int32, device="cuda")
+    api.half2_pack_nonzero(vals2, block, mask, small[:4], cnt, clear=False)
+    assert int(cnt.item()) == need and (small[4:] == -1).all() and (small[:4, 0] >= 0).all()
+    np.testing.assert_array_equal(vals2.cpu().numpy().view(np.uint16), v.reshape(-1).view(np.uint16))     # clear=False
+    # a foreign list with an index past the end is ignored
+    bad = torch.tensor([[n + 3, 0x3c003c00], [0, 0]], dtype=torch.int32, device="cuda")
+    api.half2_add_pairs(vals2, bad, 1)
+    np.testing.assert_array_equal(vals2.cpu().numpy().view(np.uint16), v.reshape(-1).view(np.uint16))
+
+
 def test_hashgrid_out_of_domain_positions_stay_inside_the_table(gpu, oracle):
     """hg_index_nodiv replaced `% size` by one conditional subtract on the densely stored levels, which only covers
     positions inside [-1, 1]^3.  Out-of-domain and non-finite positions handed to the public encode / backward entry points

@@ -69,6 +69,12 @@ if world > 1:                                                           # ... an
     ref_p = mine_p.clone()
     dist.broadcast(ref_p, src=0)
     assert torch.equal(mine_p, ref_p), f"rank {rank}: parameters diverged from rank 0"
+    if a.encoding == "hash":
+        ref_t = tr.table_master.clone()
+        dist.broadcast(ref_t, src=0)
+        assert torch.equal(tr.table_master, ref_t), f"rank {rank}: hash table diverged from rank 0"
+        if rank == 0 and tr._dp_table is not None and tr._dp_table.last is not None:
+            print("hashed levels, last step's exchange:", {k: v for k, v in tr._dp_table.last.items()}, flush=True)
 if rank == 0:
     np.save(a.out, np.stack([g0, np.concatenate([tr.master.cpu().numpy(),
                                                  tr.table_master.cpu().numpy() if a.encoding == "hash" else []])]))
