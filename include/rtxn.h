@@ -589,15 +589,19 @@ int rtxn_convert_f16_to_f32(const void* src_half, float* dst, long n, rtxn_strea
  * block_entries entries (one hash-grid level each).  A rank's batch touches 0.2 % .. 25 % of a 2^19-entry level, so a level
  * is exchanged as (index, half2) pairs where that is smaller than the level: count, let the ranks agree per block, pack the
  * chosen blocks, gather the lists, add every rank's list (the rank's own included, in rank order) into the cleared blocks.
- *   rtxn_half2_count_nonzero: counts[b] = entries of block b with a non-zero half (device int[ceil(n_entries / block_entries)]).
+ *   rtxn_half2_count_nonzero: workspace (rtxn_half2_workspace_bytes) begins with int counts[ceil(n_entries / block_entries)]
+ *     = entries of each block with a non-zero half; behind them the per-wave counts the pack pass places its entries with.
  *   rtxn_half2_pack_nonzero:  pairs (device uint32[capacity][2]: entry index, half2 bits) of the non-zero entries of the blocks
- *     whose bit is set in block_mask (at most 64 blocks), in no particular order; *count (device int) = entries needed, which
- *     may exceed capacity (the list is then cut off: size it from the counts).  clear != 0: the selected blocks are left zero.
+ *     whose bit is set in block_mask (at most 64 blocks), in ascending index; `workspace` as rtxn_half2_count_nonzero left it
+ *     for these same values (no global append counter: one address takes ~10 ns per atomic).  *count (device int) = entries
+ *     needed, which may exceed capacity (the list is then cut off: size it from the counts).  clear != 0: the selected blocks
+ *     are left zero.
  *   rtxn_half2_add_pairs:     values[index] += value for `count` pairs (indices unique within a list; out-of-range ones are
  *     ignored); fp16 adds. */
-int rtxn_half2_count_nonzero(const void* values, long n_entries, long block_entries, int* counts, rtxn_stream_t stream);
-int rtxn_half2_pack_nonzero(void* values, long n_entries, long block_entries, unsigned long long block_mask, long capacity,
-                            void* pairs, int* count, int clear, rtxn_stream_t stream);
+size_t rtxn_half2_workspace_bytes(long n_entries, long block_entries);
+int rtxn_half2_count_nonzero(const void* values, long n_entries, long block_entries, void* workspace, rtxn_stream_t stream);
+int rtxn_half2_pack_nonzero(void* values, long n_entries, long block_entries, const void* workspace, unsigned long long block_mask,
+                            long capacity, void* pairs, int* count, int clear, rtxn_stream_t stream);
 int rtxn_half2_add_pairs(void* values, long n_entries, const void* pairs, long count, rtxn_stream_t stream);
 
 /* ---- dataset loader (host only) ------------------------------------------------------- */

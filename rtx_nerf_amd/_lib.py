@@ -162,8 +162,9 @@ SYMBOLS = {
     "rtxn_hashgrid_encoded_width": (_I, [_P, _I]),
     "rtxn_hashgrid_level_offset": (_L, [_P, _I]),
     "rtxn_hashgrid_level_is_hashed": (_I, [_P, _I]),
+    "rtxn_half2_workspace_bytes": (C.c_size_t, [_L, _L]),
     "rtxn_half2_count_nonzero": (_I, [_P, _L, _L, _P, _P]),
-    "rtxn_half2_pack_nonzero": (_I, [_P, _L, _L, C.c_ulonglong, _L, _P, _P, _I, _P]),
+    "rtxn_half2_pack_nonzero": (_I, [_P, _L, _L, _P, C.c_ulonglong, _L, _P, _P, _I, _P]),
     "rtxn_half2_add_pairs": (_I, [_P, _L, _P, _L, _P]),
     "rtxn_convert_f32_to_f16": (_I, [_P, _P, _L, _P]),
     "rtxn_convert_f16_to_f32": (_I, [_P, _P, _L, _P]),

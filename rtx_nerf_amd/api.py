@@ -606,23 +606,34 @@ def train_gradients(net, *, grid=None, n_dir_freqs=0, table=None, start_points, 
     check(_lib.lib().rtxn_train_gradients(C.byref(b), _stream()), "rtxn_train_gradients")
 
 
-def half2_count_nonzero(values, block_entries, counts=None):
-    """rtxn_half2_count_nonzero: non-zero half2 entries per block of `values` (fp16, two halves per entry) -> int32[blocks]."""
+def half2_workspace(values, block_entries):
+    """int32 workspace of rtxn_half2_count_nonzero / _pack_nonzero for `values` (fp16, two halves per entry)."""
+    nbytes = int(_lib.lib().rtxn_half2_workspace_bytes(values.numel() // 2, int(block_entries)))
+    return torch.zeros(nbytes // 4, dtype=torch.int32, device=values.device)
+
+
+def half2_count_nonzero(values, block_entries, workspace=None):
+    """rtxn_half2_count_nonzero: non-zero half2 entries per block of `values` -> workspace (its first `blocks` ints are the
+    per-block counts; returns (counts view, workspace))."""
     n = values.numel() // 2
     nb = (n + block_entries - 1) // block_entries
-    if counts is None:
-        counts = torch.empty(nb, dtype=torch.int32, device=values.device)
+    if workspace is None:
+        workspace = half2_workspace(values, block_entries)
     check(_lib.lib().rtxn_half2_count_nonzero(_ptr(values, torch.float16, "values"), n, int(block_entries),
-                                              _ptr(counts, torch.int32, "counts"), _stream()), "rtxn_half2_count_nonzero")
-    return counts
+                                              _ptr(workspace, torch.int32, "workspace"), _stream()), "rtxn_half2_count_nonzero")
+    return workspace[:nb], workspace
 
 
-def half2_pack_nonzero(values, block_entries, block_mask, pairs, count, clear=True):
-    """rtxn_half2_pack_nonzero: (index, half2 bits) of the non-zero entries of the masked blocks -> pairs int32[capacity][2];
-    count (device int32[1]) = entries needed."""
+def half2_pack_nonzero(values, block_entries, workspace, block_mask, pairs, count, clear=True):
+    """rtxn_half2_pack_nonzero: (index, half2 bits) of the non-zero entries of the masked blocks, ascending -> pairs
+    int32[capacity][2]; count (device int32[1]) = entries needed.  workspace: as half2_count_nonzero left it for these values."""
+    need = int(_lib.lib().rtxn_half2_workspace_bytes(values.numel() // 2, int(block_entries)))
+    if workspace.numel() * 4 < need:
+        raise _lib.RtxnError(f"half2_pack_nonzero: workspace of {workspace.numel() * 4} bytes, {need} needed")
     check(_lib.lib().rtxn_half2_pack_nonzero(_ptr(values, torch.float16, "values"), values.numel() // 2, int(block_entries),
-                                             int(block_mask), pairs.numel() // 2, _ptr(pairs, torch.int32, "pairs"),
-                                             _ptr(count, torch.int32, "count"), 1 if clear else 0, _stream()), "rtxn_half2_pack_nonzero")
+                                             _ptr(workspace, torch.int32, "workspace"), int(block_mask), pairs.numel() // 2,
+                                             _ptr(pairs, torch.int32, "pairs"), _ptr(count, torch.int32, "count"),
+                                             1 if clear else 0, _stream()), "rtxn_half2_pack_nonzero")
 
 
 def half2_add_pairs(values, pairs, count):

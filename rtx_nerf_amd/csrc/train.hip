@@ -1961,46 +1961,121 @@ extern "C" int rtxn_convert_f16_to_f32(const void* src_half, float* dst, long n,
 // grid corner, as the scatter adds them); "non-zero" ignores the sign of a zero.
 __device__ __forceinline__ bool half2_nonzero(unsigned bits) { return (bits & 0x7fff7fffu) != 0u; }
 
+// Geometry shared by the count and the pack kernel: a block (level) is cut into kHalf2Waves chunks of whole uint4s, one wave
+// each (blockIdx.y = block, 4 waves per workgroup).  The count pass leaves every wave's count in the workspace, so the pack
+// pass knows where each wave's entries go WITHOUT a global atomic: 18 k appends to one counter cost 177 us (same-address
+// atomics retire one at a time, ~10 ns each), the two passes below read their 25 MB in ~10 us each -- and the list comes out
+// sorted by entry index, the same on every run.
+constexpr int kHalf2Waves = 128;
+struct Half2Geom {
+  long chunk;        // entries per wave, a multiple of 4
+  int waves;         // waves per block that have entries (<= kHalf2Waves)
+};
+__host__ __device__ __forceinline__ Half2Geom half2_geom(long block_entries) {
+  long chunk = (block_entries + kHalf2Waves - 1) / kHalf2Waves;
+  chunk = (chunk + 3) / 4 * 4;
+  if (chunk < 256) chunk = 256;                    // one iteration of a wave
+  return Half2Geom{chunk, (int)((block_entries + chunk - 1) / chunk)};
+}
+// the calling wave's entries [lo, hi) and its index within the block; false: nothing to do
+__device__ __forceinline__ bool half2_wave_range(long n, long block_entries, long& lo, long& hi, int& wl) {
+  const Half2Geom g = half2_geom(block_entries);
+  wl = (int)blockIdx.x * (kThreads / 64) + (int)(threadIdx.x >> 6);
+  const long b_lo = (long)blockIdx.y * block_entries, b_hi = b_lo + block_entries < n ? b_lo + block_entries : n;
+  lo = b_lo + (long)wl * g.chunk;
+  hi = lo + g.chunk < b_hi ? lo + g.chunk : b_hi;
+  return wl < g.waves && lo < hi;
+}
+
+// ws: int counts[n_blocks] | int wave_counts[n_blocks][kHalf2Waves]
 __global__ __launch_bounds__(kThreads) void half2_count_kernel(const unsigned* __restrict__ v, long n, long block_entries,
-                                                               int* __restrict__ counts) {
+                                                               int n_blocks, int* __restrict__ ws) {
+  long lo, hi;
+  int wl;
+  const bool any = half2_wave_range(n, block_entries, lo, hi, wl);
   const int lane = threadIdx.x & 63;
-  for (long base = ((long)blockIdx.x * kThreads + threadIdx.x - lane); base < n; base += (long)gridDim.x * kThreads) {
-    const long i = base + lane;
-    const bool nz = i < n && half2_nonzero(v[i]);
-    const long b_first = base / block_entries, b_last = (base + 63 < n ? base + 63 : n - 1) / block_entries;
-    if (b_first == b_last) {                      // the wave's 64 entries lie in one block: one atomic
-      const int c = __popcll(__ballot(nz));
-      if (lane == 0 && c) atomicAdd(&counts[b_first], c);
-    } else if (nz) {
-      atomicAdd(&counts[i / block_entries], 1);
+  int c = 0;
+  if (any) {
+    const bool vec = (lo & 3) == 0 && ((uintptr_t)v & 15) == 0;
+    const long n4 = vec ? (hi - lo) / 4 : 0;
+    const uint4* v4 = reinterpret_cast<const uint4*>(v + lo);
+    for (long q = lane; q < n4; q += 64) {
+      const uint4 w = v4[q];
+      c += (int)half2_nonzero(w.x) + (int)half2_nonzero(w.y) + (int)half2_nonzero(w.z) + (int)half2_nonzero(w.w);
     }
+    for (long i = lo + 4 * n4 + lane; i < hi; i += 64) c += (int)half2_nonzero(v[i]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if (lane == 0 && wl < kHalf2Waves) {
+    ws[n_blocks + (int)blockIdx.y * kHalf2Waves + wl] = c;
+    if (c) atomicAdd(&ws[blockIdx.y], c);          // <= 128 per address
   }
 }
 
-// Appends the non-zero entries of the selected blocks (bit b of block_mask) to `pairs` (wave-aggregated: one atomic per wave
-// and 64 entries); *count ends as the number of entries NEEDED -- entries past `capacity` are counted, not written.  CLEAR:
-// every entry of a selected block is left zero (the exchange adds all ranks' lists, the rank's own included, back into it).
-// The order of the list is whatever the atomics give; indices within a list are unique, so adding it is order-independent.
+// Writes the non-zero entries of the selected blocks (bit b of block_mask) to `pairs`, in ascending entry index, at the
+// positions the counts of the count pass (same values!) give; *count = the entries NEEDED -- entries past `capacity` are
+// counted, not written.  CLEAR: every entry of a selected block is left zero (the exchange adds all ranks' lists, the rank's own
+// included, back into it).
 template <bool CLEAR>
-__global__ __launch_bounds__(kThreads) void half2_pack_kernel(unsigned* __restrict__ v, long n, long block_entries,
+__global__ __launch_bounds__(kThreads) void half2_pack_kernel(unsigned* __restrict__ v, long n, long block_entries, int n_blocks,
                                                               unsigned long long block_mask, long capacity,
-                                                              uint2* __restrict__ pairs, int* __restrict__ count) {
+                                                              uint2* __restrict__ pairs, int* __restrict__ count,
+                                                              const int* __restrict__ ws) {
   const int lane = threadIdx.x & 63;
-  for (long base = ((long)blockIdx.x * kThreads + threadIdx.x - lane); base < n; base += (long)gridDim.x * kThreads) {
-    const long i = base + lane;
-    unsigned bits = 0;
-    bool nz = false;
-    if (i < n && ((block_mask >> (i / block_entries)) & 1ull)) {
-      bits = v[i];
-      nz = half2_nonzero(bits);
-    }
-    if (CLEAR && bits != 0u) v[i] = 0u;           // the non-zero entries and any -0
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    int need = 0;
+    for (int b = 0; b < n_blocks; ++b) need += ((block_mask >> b) & 1ull) ? ws[b] : 0;
+    *count = need;
+  }
+  if (!((block_mask >> blockIdx.y) & 1ull)) return;
+  long lo, hi;
+  int wl;
+  if (!half2_wave_range(n, block_entries, lo, hi, wl)) return;
+  // where this wave's entries start: the selected blocks before this one, then the waves before this one
+  int before = 0;
+  for (int b = lane; b < (int)blockIdx.y; b += 64) before += ((block_mask >> b) & 1ull) ? ws[b] : 0;
+  const int* wc = ws + n_blocks + (int)blockIdx.y * kHalf2Waves;
+  for (int w = lane; w < wl; w += 64) before += wc[w];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
+  if (wc[wl] == 0 && !CLEAR) return;               // wave-uniform
+  long at = before;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const bool vec = (lo & 3) == 0 && ((uintptr_t)v & 15) == 0;
+  const long n4 = vec ? (hi - lo) / 4 : 0;
+  uint4* v4 = reinterpret_cast<uint4*>(v + lo);
+  for (long q0 = 0; q0 < n4; q0 += 64) {           // whole waves iterate together: the ballots need every lane
+    const long q = q0 + lane;
+    uint4 w = make_uint4(0u, 0u, 0u, 0u);
+    if (q < n4) w = v4[q];
+    const unsigned e[4] = {w.x, w.y, w.z, w.w};
+    if (CLEAR && (w.x | w.y | w.z | w.w) != 0u) v4[q] = make_uint4(0u, 0u, 0u, 0u);      // the non-zero entries and any -0
+    unsigned long long m[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m[j] = __ballot(half2_nonzero(e[j]));
+    if ((m[0] | m[1] | m[2] | m[3]) == 0ull) continue;      // wave-uniform
+    // ascending index = lane-major, then j: the entries of the lanes below, then this lane's earlier ones
+    long mine = at + __popcll(m[0] & below) + __popcll(m[1] & below) + __popcll(m[2] & below) + __popcll(m[3] & below);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (half2_nonzero(e[j])) {
+        if (mine < capacity) pairs[mine] = make_uint2((unsigned)(lo + 4 * q + j), e[j]);
+        ++mine;
+      }
+    at += __popcll(m[0]) + __popcll(m[1]) + __popcll(m[2]) + __popcll(m[3]);
+  }
+  for (long i0 = lo + 4 * n4; i0 < hi; i0 += 64) {
+    const long i = i0 + lane;
+    unsigned bits = 0u;
+    if (i < hi) bits = v[i];
+    if (CLEAR && bits != 0u) v[i] = 0u;
+    const bool nz = half2_nonzero(bits);
     const unsigned long long m = __ballot(nz);
-    if (m == 0ull) continue;                      // wave-uniform
-    int at = 0;
-    if (lane == 0) at = atomicAdd(count, __popcll(m));
-    at = __shfl(at, 0) + __popcll(m & ((1ull << lane) - 1ull));
-    if (nz && at < capacity) pairs[at] = make_uint2((unsigned)i, bits);
+    if (m == 0ull) continue;
+    const long mine = at + __popcll(m & below);
+    if (nz && mine < capacity) pairs[mine] = make_uint2((unsigned)i, bits);
+    at += __popcll(m);
   }
 }
 
@@ -2021,38 +2096,55 @@ static unsigned half2_grid(long n) {
   const long blocks = (n + kThreads - 1) / kThreads;
   return (unsigned)(blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks));
 }
+static dim3 half2_grid2(long n_entries, long block_entries) {
+  const long nb = (n_entries + block_entries - 1) / block_entries;
+  const Half2Geom g = half2_geom(block_entries);
+  return dim3((unsigned)((g.waves + kThreads / 64 - 1) / (kThreads / 64)), (unsigned)nb);
+}
 
-extern "C" int rtxn_half2_count_nonzero(const void* values, long n_entries, long block_entries, int* counts, rtxn_stream_t stream) {
+extern "C" size_t rtxn_half2_workspace_bytes(long n_entries, long block_entries) {
+  if (n_entries < 0 || block_entries <= 0) return 0;
+  const long nb = (n_entries + block_entries - 1) / block_entries;
+  return sizeof(int) * (size_t)(nb > 0 ? nb : 1) * (1 + kHalf2Waves);
+}
+
+extern "C" int rtxn_half2_count_nonzero(const void* values, long n_entries, long block_entries, void* workspace, rtxn_stream_t stream) {
   RTXN_REQUIRE(n_entries >= 0 && block_entries > 0 && n_entries < (1L << 32), "rtxn_half2_count_nonzero: n_entries = %ld, block_entries = %ld",
                n_entries, block_entries);
   RTXN_DEVICE_OR_FAIL();
   if (n_entries == 0) return RTXN_OK;
-  RTXN_REQUIRE(values && counts, "rtxn_half2_count_nonzero: NULL buffer");
+  RTXN_REQUIRE(values && workspace, "rtxn_half2_count_nonzero: NULL buffer");
   const long n_blocks = (n_entries + block_entries - 1) / block_entries;
-  RTXN_HIP(hipMemsetAsync(counts, 0, sizeof(int) * n_blocks, rtxn::as_stream(stream)));
-  half2_count_kernel<<<half2_grid(n_entries), kThreads, 0, rtxn::as_stream(stream)>>>(static_cast<const unsigned*>(values), n_entries,
-                                                                                   block_entries, counts);
+  RTXN_REQUIRE(n_blocks <= 65535, "rtxn_half2_count_nonzero: %ld blocks", n_blocks);
+  RTXN_HIP(hipMemsetAsync(workspace, 0, sizeof(int) * n_blocks, rtxn::as_stream(stream)));
+  half2_count_kernel<<<half2_grid2(n_entries, block_entries), kThreads, 0, rtxn::as_stream(stream)>>>(
+      static_cast<const unsigned*>(values), n_entries, block_entries, (int)n_blocks, static_cast<int*>(workspace));
   RTXN_LAUNCH_CHECK("half2_count_kernel");
   return RTXN_OK;
 }
 
-extern "C" int rtxn_half2_pack_nonzero(void* values, long n_entries, long block_entries, unsigned long long block_mask, long capacity,
-                                       void* pairs, int* count, int clear, rtxn_stream_t stream) {
+extern "C" int rtxn_half2_pack_nonzero(void* values, long n_entries, long block_entries, const void* workspace,
+                                       unsigned long long block_mask, long capacity, void* pairs, int* count, int clear,
+                                       rtxn_stream_t stream) {
   RTXN_REQUIRE(n_entries >= 0 && block_entries > 0 && n_entries < (1L << 32) && capacity >= 0,
                "rtxn_half2_pack_nonzero: n_entries = %ld, block_entries = %ld, capacity = %ld", n_entries, block_entries, capacity);
-  RTXN_REQUIRE((n_entries + block_entries - 1) / block_entries <= 64, "rtxn_half2_pack_nonzero: %ld blocks do not fit the 64-bit block_mask",
-               (n_entries + block_entries - 1) / block_entries);
+  const long n_blocks = (n_entries + block_entries - 1) / block_entries;
+  RTXN_REQUIRE(n_blocks <= 64, "rtxn_half2_pack_nonzero: %ld blocks do not fit the 64-bit block_mask", n_blocks);
   RTXN_DEVICE_OR_FAIL();
   RTXN_REQUIRE(count, "rtxn_half2_pack_nonzero: NULL count");
-  RTXN_HIP(hipMemsetAsync(count, 0, sizeof(int), rtxn::as_stream(stream)));
-  if (n_entries == 0 || block_mask == 0ull) return RTXN_OK;
-  RTXN_REQUIRE(values && (pairs || capacity == 0), "rtxn_half2_pack_nonzero: NULL buffer");
+  if (n_entries == 0 || block_mask == 0ull) {
+    RTXN_HIP(hipMemsetAsync(count, 0, sizeof(int), rtxn::as_stream(stream)));
+    return RTXN_OK;
+  }
+  RTXN_REQUIRE(values && workspace && (pairs || capacity == 0), "rtxn_half2_pack_nonzero: NULL buffer");
   if (clear)
-    half2_pack_kernel<true><<<half2_grid(n_entries), kThreads, 0, rtxn::as_stream(stream)>>>(
-        static_cast<unsigned*>(values), n_entries, block_entries, block_mask, capacity, static_cast<uint2*>(pairs), count);
+    half2_pack_kernel<true><<<half2_grid2(n_entries, block_entries), kThreads, 0, rtxn::as_stream(stream)>>>(
+        static_cast<unsigned*>(values), n_entries, block_entries, (int)n_blocks, block_mask, capacity, static_cast<uint2*>(pairs), count,
+        static_cast<const int*>(workspace));
   else
-    half2_pack_kernel<false><<<half2_grid(n_entries), kThreads, 0, rtxn::as_stream(stream)>>>(
-        static_cast<unsigned*>(values), n_entries, block_entries, block_mask, capacity, static_cast<uint2*>(pairs), count);
+    half2_pack_kernel<false><<<half2_grid2(n_entries, block_entries), kThreads, 0, rtxn::as_stream(stream)>>>(
+        static_cast<unsigned*>(values), n_entries, block_entries, (int)n_blocks, block_mask, capacity, static_cast<uint2*>(pairs), count,
+        static_cast<const int*>(workspace));
   RTXN_LAUNCH_CHECK("half2_pack_kernel");
   return RTXN_OK;
 }

@@ -23,14 +23,19 @@ class _HipOps:
     """rtxn_half2_count_nonzero / rtxn_half2_pack_nonzero / rtxn_half2_add_pairs on the current stream."""
 
     @staticmethod
-    def count(values, block_entries, counts):
+    def workspace(values, block_entries):
         from . import api
-        api.half2_count_nonzero(values, block_entries, counts)
+        return api.half2_workspace(values, block_entries)
 
     @staticmethod
-    def pack(values, block_entries, mask, pairs, count):
+    def count(values, block_entries, ws):
         from . import api
-        api.half2_pack_nonzero(values, block_entries, mask, pairs, count, clear=True)
+        api.half2_count_nonzero(values, block_entries, ws)
+
+    @staticmethod
+    def pack(values, block_entries, ws, mask, pairs, count):
+        from . import api
+        api.half2_pack_nonzero(values, block_entries, ws, mask, pairs, count, clear=True)
 
     @staticmethod
     def add(values, pairs, n):
@@ -52,7 +57,8 @@ class Half2GradExchange:
         self.group = group
         self.force_lists = force_lists     # tests: every block as lists whatever the counts say
         dev = values.device
-        self.counts = torch.zeros(self.nb, dtype=torch.int32, device=dev)
+        self.ws = self.ops.workspace(values, self.block)     # int32: per-block counts first, then what pack needs of count
+        self.counts = self.ws[:self.nb]
         self.count1 = torch.zeros(1, dtype=torch.int32, device=dev)
         self.pairs = None            # int32[cap][2], grown on demand
         self.gathered = None         # int32[world][cap][2]
@@ -75,7 +81,7 @@ class Half2GradExchange:
         """Returns the async work handles of the dense part (wait on them before reading `values`); the sparse part is
         complete -- in stream order -- when this returns."""
         world = dist.get_world_size(self.group)
-        self.ops.count(self.values, self.block, self.counts)
+        self.ops.count(self.values, self.block, self.ws)
         lst = [torch.empty_like(self.counts) for _ in range(world)]
         dist.all_gather(lst, self.counts, group=self.group)
         c = torch.stack(lst).cpu().tolist()                      # the one host read: list lengths
@@ -106,7 +112,7 @@ class Half2GradExchange:
             for b in sparse:
                 mask |= 1 << b
             mine = self.pairs[:cap]
-            self.ops.pack(self.values, self.block, mask, mine, self.count1)
+            self.ops.pack(self.values, self.block, self.ws, mask, mine, self.count1)
             parts = [self.gathered[r, :cap] for r in range(world)]
             dist.all_gather(parts, mine, group=self.group)
             for r in range(world):                               # rank order on every rank: bit-identical sums

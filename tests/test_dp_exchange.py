@@ -24,13 +24,17 @@ class CpuOps:
         return values.view(torch.int32)
 
     @staticmethod
-    def count(values, block, counts):
-        nz = (CpuOps._bits(values) & 0x7fff7fff) != 0
-        for b in range(counts.numel()):
-            counts[b] = int(nz[b * block:(b + 1) * block].sum())
+    def workspace(values, block):
+        return torch.zeros((values.numel() // 2 + block - 1) // block, dtype=torch.int32)
 
     @staticmethod
-    def pack(values, block, mask, pairs, count):
+    def count(values, block, ws):
+        nz = (CpuOps._bits(values) & 0x7fff7fff) != 0
+        for b in range(ws.numel()):
+            ws[b] = int(nz[b * block:(b + 1) * block].sum())
+
+    @staticmethod
+    def pack(values, block, ws, mask, pairs, count):
         bits = CpuOps._bits(values)
         sel = torch.tensor([(mask >> (i // block)) & 1 for i in range(bits.numel())], dtype=torch.bool)
         idx = torch.nonzero(((bits & 0x7fff7fff) != 0) & sel).flatten()

@@ -545,16 +545,18 @@ def test_half2_sparse_gradient_primitives(gpu):
     v[block + 5] = (np.float16(-0.0), np.float16(0.0))
     nz = (v.view(np.uint16) & 0x7fff).any(axis=1)
     vals = _dev(torch, v.reshape(-1).copy())
-    counts = api.half2_count_nonzero(vals, block).cpu().numpy()
+    counts_d, ws = api.half2_count_nonzero(vals, block)
+    counts = counts_d.cpu().numpy()
     want_counts = [int(nz[b * block:(b + 1) * block].sum()) for b in range(nb)]
     assert counts.tolist() == want_counts
     mask = 0b11010                                         # blocks 1, 3, 4
     need = want_counts[1] + want_counts[3] + want_counts[4]
     pairs = torch.zeros((need + 10, 2), dtype=torch.int32, device="cuda")
     cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
-    api.half2_pack_nonzero(vals, block, mask, pairs, cnt, clear=True)
+    api.half2_pack_nonzero(vals, block, ws, mask, pairs, cnt, clear=True)
     assert int(cnt.item()) == need
     got = pairs[:need].cpu().numpy()
+    assert (np.diff(got[:, 0]) > 0).all()                  # ascending entry index: the same list on every run
     sel = np.zeros(n, bool)
     for b in (1, 3, 4):
         sel[b * block:(b + 1) * block] = True
@@ -575,7 +577,7 @@ def test_half2_sparse_gradient_primitives(gpu):
     # capacity smaller than the need: the list is cut off, the need still reported, nothing written past the capacity
     vals2 = _dev(torch, v.reshape(-1).copy())
     small = torch.full((8, 2), -1, dtype=torch.int32, device="cuda")
-    api.half2_pack_nonzero(vals2, block, mask, small[:4], cnt, clear=False)
+    api.half2_pack_nonzero(vals2, block, ws, mask, small[:4], cnt, clear=False)      # ws: counted on the same values
     assert int(cnt.item()) == need and (small[4:] == -1).all() and (small[:4, 0] >= 0).all()
     np.testing.assert_array_equal(vals2.cpu().numpy().view(np.uint16), v.reshape(-1).view(np.uint16))     # clear=False
     # a foreign list with an index past the end is ignored

@@ -48,3 +48,42 @@ for _ in range(1200):
     idx = torch.randint(0, ro.shape[0], (B,), device="cuda", generator=g)
     tr.step(ro[idx].contiguous(), rd[idx].contiguous(), tg[idx].contiguous())
 report("step 1500")
+
+# ---- cost of the exchange's device side on this gradient, and the bytes it would move (every rank assumed to hold this much)
+from rtx_nerf_amd import api
+idx = torch.randint(0, ro.shape[0], (B,), device="cuda", generator=g)
+tr.gradients(ro[idx].contiguous(), rd[idx].contiguous(), tg[idx].contiguous())
+vals = tr.dtable_h
+T = 1 << 19
+nb = vals.numel() // 2 // T
+counts, ws = api.half2_count_nonzero(vals, T)
+c = counts.cpu().tolist()
+cap = sum(c)
+pairs = torch.zeros((cap + 1024, 2), dtype=torch.int32, device="cuda")
+cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+keep = vals.clone()
+
+
+def timed(fn, reps=20):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn(); torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+t_count = timed(lambda: api.half2_count_nonzero(vals, T, ws))
+t_pack = timed(lambda: api.half2_pack_nonzero(vals, T, ws, (1 << nb) - 1, pairs, cnt, clear=False))
+api.half2_pack_nonzero(vals, T, ws, (1 << nb) - 1, pairs, cnt, clear=True)
+t_add = timed(lambda: api.half2_add_pairs(vals, pairs, cap))
+print(f"exchange primitives on {nb} levels x 2^19 entries ({vals.numel() * 2 / 1e6:.1f} MB), {cap} non-zero entries: "
+      f"count {t_count:.1f} us, pack {t_pack:.1f} us, add one list {t_add:.1f} us")
+dense = 4.0 * nb * T
+for N in (2, 4, 8):
+    sparse_levels = [b for b in range(nb) if N * c[b] < T]
+    lists = (N - 1) * 8.0 * sum(c[b] for b in sparse_levels)
+    dn = 2.0 * (N - 1) / N * 4.0 * T * (nb - len(sparse_levels))
+    print(f"  N = {N}: {len(sparse_levels)}/{nb} levels as lists: {lists / 1e6:.2f} MB lists + {dn / 1e6:.2f} MB dense levels per rank and step "
+          f"(all dense: {2.0 * (N - 1) / N * dense / 1e6:.2f} MB)")
