@@ -356,7 +356,37 @@ def train_ref_record(batch_rays, grid_res, steps, warmup, dense_grid=True, mode=
                      "note": "whole step; the MLP kernels materialise activations and dZ (2 B x 128 per sample and layer, written once and read "
                              "twice): their HBM floor is 8 layers x 128 x 2 B x 5 passes = 10 KB per sample"},
     }
-    mlp_ms = sum(stages.get(k, 0.0) for k in ("mlp_fwd", "mlp_bwd+wgrad"))
+    if captured:
+        # the same step as ONE hipGraph with the traversal of the next batch beside the gradient kernels (Trainer.capture_step,
+        # as train_config3's headline): no host read of the segment count (main.cu:632 synchronises for it), no launch gaps
+        tr.capture_step(B, launch_segments=min(cap, int(1.3 * S / 32) + 1024), prefetch=True)
+
+        def into_graph():
+            idx = torch.randint(0, ro.shape[0], (B,), device="cuda", generator=g)
+            torch.index_select(ro, 0, idx, out=tr.graph_rays_o)
+            torch.index_select(rd, 0, idx, out=tr.graph_rays_d)
+            torch.index_select(tg, 0, idx, out=tr.graph_targets)
+
+        for _ in range(max(2, warmup) + 1):
+            into_graph()
+            tr.step_captured()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            into_graph()
+            loss_c = tr.step_captured()
+        torch.cuda.synchronize()
+        dt_c = time.perf_counter() - t0
+        tr.flush_captured()
+        ms_c = 1e3 * dt_c / steps
+        rec["ms_per_step_host_count"] = rec["ms_per_step"]
+        rec["ms_per_step"], rec["mrays_s"] = round(ms_c, 4), round(B * steps / dt_c / 1e6, 4)
+        rec["step_form"] = "one hipGraph per step, traversal of the next batch beside the gradient kernels (segment count on the device)"
+        rec["truncated_steps"] = tr.truncated_steps
+        rec["loss_last_captured"] = float(loss_c.item())
+        tf = flop * S / (ms_c * 1e-3) / 1e12
+        rec["roofline"]["achieved"], rec["roofline"]["frac"] = round(tf, 1), round(tf / MFMA_F16_DENSE_PEAK_TFLOPS, 4)
+    mlp_ms = sum(stages.get(k, 0.0) for k in ("mlp_fwd", "mlp_fwd_live", "mlp_bwd+wgrad"))
     if mlp_ms > 0:
         rec["roofline"]["mlp_kernels_ms"] = round(mlp_ms, 4)
         rec["roofline"]["mlp_kernels_frac"] = round(flop * S / (mlp_ms * 1e-3) / 1e12 / MFMA_F16_DENSE_PEAK_TFLOPS, 4)
@@ -370,8 +400,8 @@ def extra_train_ref8x128(steps, warmup):
     # (the 4096-ray variant first: measured in the same process AFTER the two large ones -- 70-GB workspaces allocated and
     # released -- its steps took twice as long)
     small = train_ref_record(4096, 128, 3 * steps, warmup, dense_grid=False, mode="nerf")
-    return {"b22528_dense8": train_ref_record(128 * 176, 8, steps, warmup),
-            "b45056_dense8": train_ref_record(256 * 176, 8, max(4, steps // 2), warmup),
+    return {"b22528_dense8": train_ref_record(128 * 176, 8, steps, warmup, captured=False),
+            "b45056_dense8": train_ref_record(256 * 176, 8, max(4, steps // 2), warmup, captured=False),
             "b4096_lego128_nerf": small}
 
 

@@ -15,6 +15,12 @@ inline hipStream_t as_stream(rtxn_stream_t s) { return reinterpret_cast<hipStrea
 // The library has no CPU path: every compute entry point goes through this.
 int require_device();
 
+// Zeroes n_words 32-bit words with a KERNEL.  Not hipMemsetAsync: as a memset node of a captured hipGraph it filled the 4 bytes
+// of a loss sum with a stray byte (0xE8E8E8E8, 0x78787878, ...) on the graph's FIRST launch and with zeros from the second on
+// (ROCm 7.2, round 3: tools/probe/captured_loss_dbg.py, profiles/r03/graph_memset_first_launch.txt), so nothing on a capturable
+// path uses it any more.
+hipError_t zero_words(void* p, size_t n_words, hipStream_t stream);
+
 }  // namespace rtxn
 
 #define RTXN_HIP(expr)                                           \

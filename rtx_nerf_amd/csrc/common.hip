@@ -33,6 +33,17 @@ int require_device() {
 
 const char* last_error() { return g_err; }
 
+static __global__ void zero_words_kernel(unsigned* p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+
+hipError_t zero_words(void* p, size_t n_words, hipStream_t stream) {
+  if (n_words == 0) return hipSuccess;
+  const size_t blocks = (n_words + 255) / 256;
+  zero_words_kernel<<<(unsigned)(blocks > 1024 ? 1024 : blocks), 256, 0, stream>>>(static_cast<unsigned*>(p), n_words);
+  return hipGetLastError();
+}
+
 }  // namespace rtxn
 
 extern "C" int rtxn_version(void) { return RTXN_VERSION; }

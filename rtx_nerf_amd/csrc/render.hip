@@ -313,7 +313,7 @@ extern "C" int rtxn_render_create(const rtxn_render_config* cfg, void* workspace
   }
   // per-slot totals start at 0 (a status query before the first frame reads them), and the hierarchy is built once here
   for (int i = 0; i < r->n_slots; ++i)
-    if ((e = hipMemsetAsync(r->slots[i].total, 0, sizeof(int), nullptr)) != hipSuccess) return fail(rtxn::fail_hip(e, "hipMemsetAsync(total)"));
+    if ((e = rtxn::zero_words(r->slots[i].total, 1, nullptr)) != hipSuccess) return fail(rtxn::fail_hip(e, "zero_words(total)"));
   rc = build_hierarchy(r, nullptr);
   if (rc != RTXN_OK) return fail(rc);
   if ((e = hipStreamSynchronize(nullptr)) != hipSuccess) return fail(rtxn::fail_hip(e, "hipStreamSynchronize"));

@@ -2116,7 +2116,7 @@ extern "C" int rtxn_half2_count_nonzero(const void* values, long n_entries, long
   RTXN_REQUIRE(values && workspace, "rtxn_half2_count_nonzero: NULL buffer");
   const long n_blocks = (n_entries + block_entries - 1) / block_entries;
   RTXN_REQUIRE(n_blocks <= 65535, "rtxn_half2_count_nonzero: %ld blocks", n_blocks);
-  RTXN_HIP(hipMemsetAsync(workspace, 0, sizeof(int) * n_blocks, rtxn::as_stream(stream)));
+  RTXN_HIP(rtxn::zero_words(workspace, (size_t)n_blocks, rtxn::as_stream(stream)));
   half2_count_kernel<<<half2_grid2(n_entries, block_entries), kThreads, 0, rtxn::as_stream(stream)>>>(
       static_cast<const unsigned*>(values), n_entries, block_entries, (int)n_blocks, static_cast<int*>(workspace));
   RTXN_LAUNCH_CHECK("half2_count_kernel");
@@ -2133,7 +2133,7 @@ extern "C" int rtxn_half2_pack_nonzero(void* values, long n_entries, long block_
   RTXN_DEVICE_OR_FAIL();
   RTXN_REQUIRE(count, "rtxn_half2_pack_nonzero: NULL count");
   if (n_entries == 0 || block_mask == 0ull) {
-    RTXN_HIP(hipMemsetAsync(count, 0, sizeof(int), rtxn::as_stream(stream)));
+    RTXN_HIP(rtxn::zero_words(count, 1, rtxn::as_stream(stream)));
     return RTXN_OK;
   }
   RTXN_REQUIRE(values && workspace && (pairs || capacity == 0), "rtxn_half2_pack_nonzero: NULL buffer");
@@ -2277,7 +2277,7 @@ extern "C" int rtxn_l2_loss(const float* pred, const float* target, long n, floa
   RTXN_REQUIRE(n >= 0, "rtxn_l2_loss: n = %ld < 0", n);
   RTXN_DEVICE_OR_FAIL();
   hipStream_t s = rtxn::as_stream(stream);
-  if (loss_sum) RTXN_HIP(hipMemsetAsync(loss_sum, 0, sizeof(float), s));
+  if (loss_sum) RTXN_HIP(rtxn::zero_words(loss_sum, 1, s));
   if (n == 0) return RTXN_OK;
   RTXN_REQUIRE(pred && target, "rtxn_l2_loss: NULL buffer");
   const unsigned blocks = (unsigned)((n + kThreads - 1) / kThreads < 1024 ? (n + kThreads - 1) / kThreads : 1024);
@@ -2364,7 +2364,7 @@ extern "C" int rtxn_live_segments(const void* radiance_gradients_half4, long n_s
   RTXN_REQUIRE(live_ws && ((uintptr_t)live_ws & 15) == 0, "rtxn_live_segments: workspace NULL or not 16-byte aligned");
   RTXN_DEVICE_OR_FAIL();
   if (n_segments == 0) {
-    RTXN_HIP(hipMemsetAsync(live_ws, 0, 16, rtxn::as_stream(stream)));
+    RTXN_HIP(rtxn::zero_words(live_ws, 4, rtxn::as_stream(stream)));
     return RTXN_OK;
   }
   RTXN_REQUIRE(radiance_gradients_half4 && ((uintptr_t)radiance_gradients_half4 & 7) == 0, "rtxn_live_segments: gradients NULL or not 8-byte aligned");

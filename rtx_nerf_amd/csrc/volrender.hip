@@ -717,7 +717,7 @@ extern "C" int rtxn_volrender_l2_train(const float* network_outputs, const float
   RTXN_REQUIRE(num_samples_per_hit > 0, "rtxn_volrender_l2_train: num_samples_per_hit = %d", num_samples_per_hit);
   RTXN_DEVICE_OR_FAIL();
   hipStream_t s = rtxn::as_stream(stream);
-  if (loss_sum) RTXN_HIP(hipMemsetAsync(loss_sum, 0, sizeof(float), s));
+  if (loss_sum) RTXN_HIP(rtxn::zero_words(loss_sum, 1, s));
   if (batch_size == 0) return RTXN_OK;
   RTXN_REQUIRE(network_outputs && ray_hit && num_hits && indices && target && pixels && radiance_gradients,
                "rtxn_volrender_l2_train: NULL buffer");

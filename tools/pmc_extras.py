@@ -19,6 +19,6 @@ if what == "config3":
     print(json.dumps({"train_config3": a, "render_hash4x64": b}))
 elif what == "ref8x128":
     print(json.dumps({"b4096_lego128_nerf": bench.train_ref_record(4096, 128, 8, 2, dense_grid=False, mode="nerf"),
-                      "b22528_dense8": bench.train_ref_record(128 * 176, 8, 3, 1)}))
+                      "b22528_dense8": bench.train_ref_record(128 * 176, 8, 3, 1, captured=False)}))
 else:
     print(json.dumps({"config5": bench.extra_config5(4, 2, 2)}))
