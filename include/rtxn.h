@@ -491,6 +491,15 @@ float rtxn_adam_effective_lr(float lr, float beta1, float beta2, int step);
 int rtxn_adam_step_captured(long n, float* master, void* params_fp16, void* grads, int grad_flags, float* m, float* v,
                             const float* effective_lr, float beta1, float beta2, float eps, float loss_scale,
                             rtxn_stream_t stream);
+/* tiny-cuda-nn's Adam for its "non-matrix" parameters, i.e. the hash table (optimizers/adam.h, adam_step -- [upstream], the
+ * reference's optimizer, main.cu:36-46,787): an entry whose gradient is EXACTLY zero is skipped (moments and weight unchanged),
+ * and the bias correction lr*sqrt(1-beta2^t)/(1-beta1^t) uses the entry's own update count t = ++param_steps[i] (uint32[n],
+ * zero-initialised, part of the optimizer state).  No step number in the arguments: the call is capturable as it is.
+ * grad_flags as rtxn_adam_step_captured.  HBM: the gradient everywhere, the 18 B of state per parameter only where it is
+ * non-zero (a batch touches 0.2 .. 25 % of a hashed level). */
+int rtxn_adam_step_sparse(long n, float* master, void* params_fp16, void* grads, int grad_flags, float* m, float* v,
+                          unsigned* param_steps, float lr, float beta1, float beta2, float eps, float loss_scale,
+                          rtxn_stream_t stream);
 
 /* ---- one training batch without a host round trip ------------------------------------------------------------------
  * The body of the reference's training loop between the traversal and the optimizer (main.cu:703-781: launchSampler ->

@@ -306,3 +306,13 @@ def adam_step(master, grads, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e
     lib().orc_adam_step(C.c_long(master.size), _p(master), _p(p16), _p(_f32(grads)), _p(m), _p(v), C.c_int(step),
                         C.c_float(lr), C.c_float(beta1), C.c_float(beta2), C.c_float(eps), C.c_float(loss_scale))
     return p16
+
+
+def adam_step_sparse(master, grads, m, v, steps, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, loss_scale=1.0):
+    """tiny-cuda-nn's Adam for hash-table entries: zero-gradient entries skipped, per-entry step counts (uint32 array `steps`);
+    in-place on master/m/v/steps; returns the fp16 copy of the entries it updated (zeros elsewhere)."""
+    p16 = np.zeros(master.size, np.float16)
+    assert steps.dtype == np.uint32
+    lib().orc_adam_step_sparse(C.c_long(master.size), _p(master), _p(p16), _p(_f32(grads)), _p(m), _p(v), _p(steps),
+                               C.c_float(lr), C.c_float(beta1), C.c_float(beta2), C.c_float(eps), C.c_float(loss_scale))
+    return p16

@@ -1006,3 +1006,20 @@ void orc_adam_step(long n, float* master, uint16_t* params_f16, const float* gra
     params_f16[i] = orc_f32_to_f16_bits(master[i]);
   }
 }
+
+/* tiny-cuda-nn's adam_step for its NON-MATRIX parameters (the hash table; optimizers/adam.h [upstream], the optimizer the
+ * reference configures at main.cu:36-46 and steps at :787): `if (gradient == 0) return;`, and the bias correction uses the
+ * parameter's own update count, `current_step = ++param_steps[i]`. */
+void orc_adam_step_sparse(long n, float* master, uint16_t* params_f16, const float* grads, float* m, float* v, uint32_t* steps,
+                          float lr, float beta1, float beta2, float eps, float loss_scale) {
+  for (long i = 0; i < n; ++i) {
+    float g = grads[i] / loss_scale;
+    if (g == 0.0f) continue;
+    m[i] = beta1 * m[i] + (1.0f - beta1) * g;
+    v[i] = beta2 * v[i] + (1.0f - beta2) * g * g;
+    float t = (float)(++steps[i]);
+    float lr_eff = lr * sqrtf(1.0f - powf(beta2, t)) / (1.0f - powf(beta1, t));
+    master[i] -= lr_eff * m[i] / (sqrtf(v[i]) + eps);
+    params_f16[i] = orc_f32_to_f16_bits(master[i]);
+  }
+}

@@ -185,6 +185,7 @@ SYMBOLS = {
     "rtxn_adam_step_half_grads": (_I, [_L, _P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _P]),
     "rtxn_adam_effective_lr": (_F, [_F, _F, _F, _I]),
     "rtxn_adam_step_captured": (_I, [_L, _P, _P, _P, _I, _P, _P, _P, _F, _F, _F, _F, _P]),
+    "rtxn_adam_step_sparse": (_I, [_L, _P, _P, _P, _I, _P, _P, _P, _F, _F, _F, _F, _F, _P]),
     "rtxn_train_gradients": (_I, [C.POINTER(TrainBatch), _P]),
     "rtxn_live_segments_workspace_bytes": (C.c_size_t, [_L]),
     "rtxn_live_segments": (_I, [_P, _L, _L, _P, _P]),

@@ -568,6 +568,20 @@ def adam_step_captured(master, params_fp16, grads, m, v, effective_lr, beta1=0.9
                                              _stream()), "rtxn_adam_step_captured")
 
 
+def adam_step_sparse(master, params_fp16, grads, m, v, param_steps, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, loss_scale=1.0,
+                     zero_grads=False):
+    """rtxn_adam_step_sparse: tiny-cuda-nn's Adam for the hash table -- entries with a zero gradient are skipped, bias correction
+    by the entry's own update count (param_steps, int32/uint32[n]).  grads: fp32 or fp16."""
+    half = grads.dtype == torch.float16
+    flags = (ADAM_GRADS_FP16 if half else 0) | (ADAM_ZERO_GRADS if zero_grads else 0)
+    check(_lib.lib().rtxn_adam_step_sparse(master.numel(), _ptr(master, torch.float32, "master"),
+                                           _ptr(params_fp16, torch.float16, "params"),
+                                           _ptr(grads, torch.float16 if half else torch.float32, "grads"), flags,
+                                           _ptr(m, torch.float32, "m"), _ptr(v, torch.float32, "v"),
+                                           _ptr(param_steps, torch.int32, "param_steps"), lr, beta1, beta2, eps, loss_scale,
+                                           _stream()), "rtxn_adam_step_sparse")
+
+
 def train_gradients(net, *, grid=None, n_dir_freqs=0, table=None, start_points, end_points, seg_view, num_stored, indices,
                     total_segments, segment_capacity, n_rays, sample_type, t_scale=1.0, vr_mode, targets, loss_scale,
                     encT, dencT=None, workspace=None, output_half, radiance, t_vals, radiance_gradients, pixels, loss_gradients,

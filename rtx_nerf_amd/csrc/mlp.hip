@@ -206,7 +206,7 @@ __global__ void pack_kernel(const _Float16* __restrict__ params, _Float16* __res
 // Block geometry, LDS plan, staging protocol and wave-group skew: see the file header.  Who holds what: lane (c = l & 15, g = l >> 4) owns sample 16 ct + c of the wave's four 16-column tiles
 // and, of every 32 features, the eight perm_feature16 gives its lane group.
 // Layer 0 / the encoder.  Lane group g evaluates a block of FB = ceil(F/4) consecutive frequencies of every input dimension
-// (enc16_feature): the inputs are pre-scaled once per tile by 2^(FB g) (exact), the block's lowest octave comes from ONE
+// (enc16_feature): the inputs are pre-scaled once per tile by 2^(FB g) / 2 (exact), the block's lowest octave comes from ONE
 // v_sin_f32 + ONE v_cos_f32 (exact range reduction as before) and its other octaves from the double-angle identities
 // s' = 2 s c, c' = 1 - 2 s^2 -- three 4-cycle instructions per octave instead of two 8-cycle transcendentals with their
 // range reductions: 64 issue cycles per (dimension, column tile) for six features, where the direct form took 120.  The error
@@ -225,14 +225,15 @@ struct EncSpec16 {
   static_assert(ND <= 8, "direction dwords are placed before the pipeline starts: k-steps 0 and 1 only");
 };
 
-// One dimension of one sample: NK dwords {sin, cos} of octaves 0..NK-1 of the lane group's block.  xg = x 2^(FB g).
+// One dimension of one sample: NK dwords {sin, cos} of octaves 0..NK-1 of the lane group's block.  xg = x 2^(FB g) / 2: the
+// argument of the block's lowest octave in TURNS (sin(2^k pi x) = sin(2 pi (2^k x / 2))), the halving folded into the tile's one
+// exact pre-scaling (round 3; v_fract stays: v_sin_f32 returns 0 outside +-256 turns, and the C ABI takes any position).
 template <int NK>
 __device__ __forceinline__ void octave_unit(float xg, int (&d)[3]) {
   float t, u, sn, cs;
   if constexpr (NK == 3) {
     asm volatile(
-        "v_mul_f32 %3, 0.5, %7\n\t"
-        "v_fract_f32 %3, %3\n\t"
+        "v_fract_f32 %3, %7\n\t"
         "v_sin_f32 %5, %3\n\t"
         "v_cos_f32 %6, %3\n\t"
         "s_nop 0\n\t"
@@ -249,8 +250,7 @@ __device__ __forceinline__ void octave_unit(float xg, int (&d)[3]) {
         : "v"(xg));
   } else if constexpr (NK == 2) {
     asm volatile(
-        "v_mul_f32 %2, 0.5, %6\n\t"
-        "v_fract_f32 %2, %2\n\t"
+        "v_fract_f32 %2, %6\n\t"
         "v_sin_f32 %4, %2\n\t"
         "v_cos_f32 %5, %2\n\t"
         "s_nop 0\n\t"
@@ -264,8 +264,7 @@ __device__ __forceinline__ void octave_unit(float xg, int (&d)[3]) {
     d[2] = 0;
   } else {
     asm volatile(
-        "v_mul_f32 %1, 0.5, %4\n\t"
-        "v_fract_f32 %1, %1\n\t"
+        "v_fract_f32 %1, %4\n\t"
         "v_sin_f32 %2, %1\n\t"
         "v_cos_f32 %3, %1\n\t"
         "s_nop 0\n\t"
@@ -413,7 +412,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd16_kernel(FwdArgs a) {
   stage<OUT_BYTES, THREADS>(a.packed + layer_off(n_layers - 1), smem + L0_BYTES, tid);
   int qs = 0;                               // hidden stages this wave has begun (ring slot = qs % 3)
 
-  const float pos_scale = (float)(1u << (ES::FBP * g)), dir_scale = (float)(1u << (ES::FBD * g));   // 2^(FB g): see EncSpec16
+  const float pos_scale = 0.5f * (float)(1u << (ES::FBP * g)), dir_scale = 0.5f * (float)(1u << (ES::FBD * g));   // 2^(FB g) / 2 turns per unit: see EncSpec16
   float xq[CT][5];                          // inputs of the lane's four samples, already scaled for its lane group
   auto sample_of = [&](int tile, int ct, bool& valid) -> long {
     if (IN_MODE == 1) {
@@ -695,7 +694,7 @@ __global__ __launch_bounds__(kThreads256, 2) void mlp_fwd256x16_kernel(FwdArgs a
   const int g_end = my_tiles * n_chunks;
   int gq = 0;  // chunks consumed so far by this block
 
-  const float pos_scale = (float)(1u << (ES::FBP * g)), dir_scale = (float)(1u << (ES::FBD * g));   // 2^(FB g): see EncSpec16
+  const float pos_scale = 0.5f * (float)(1u << (ES::FBP * g)), dir_scale = 0.5f * (float)(1u << (ES::FBD * g));   // 2^(FB g) / 2 turns per unit: see EncSpec16
   float xq[CT][5];
   auto sample_of = [&](int tile, int ct, bool& valid) -> long {
     if (IN_MODE == 1) {

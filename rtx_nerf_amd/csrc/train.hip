@@ -1534,6 +1534,72 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(long n, float* __restric
   }
 }
 
+// tiny-cuda-nn's Adam as it treats "non-matrix" parameters -- the hash table (optimizers/adam.h, adam_step): an entry whose
+// gradient is exactly zero is SKIPPED (neither moment decays, the weight stays), and the bias correction uses the entry's OWN
+// count of updates (param_steps), "since some parameters might see fewer steps than others".  A step's batch touches 0.2 .. 25 %
+// of a hashed level, so this is also the cheap form: the gradient is read everywhere (2 or 4 B per parameter), the 14 B of
+// state only where it is non-zero.  Four parameters per thread; ZERO clears the gradient as it is consumed.
+template <bool HALF_GRADS, bool ZERO>
+__global__ __launch_bounds__(kThreads) void adam_sparse_kernel(long n, float* __restrict__ master, __half* __restrict__ params,
+                                                               void* __restrict__ grads_v, float* __restrict__ m, float* __restrict__ v,
+                                                               unsigned* __restrict__ steps, float lr, float beta1, float beta2,
+                                                               float eps, float inv_loss_scale, float log2_beta1, float log2_beta2) {
+  float* gf = static_cast<float*>(grads_v);
+  __half* gh = static_cast<__half*>(grads_v);
+  auto one = [&](float g, float& mi, float& vi, float& w, unsigned& st) {
+    if (g == 0.0f) return;
+    st += 1u;
+    const float t = (float)st;
+    // beta^t = 2^(t log2 beta): one v_exp_f32 each (a libm powf here made the kernel slower than the dense one while the
+    // gradient is still dense, early in training); relative error ~1e-6 of a factor that multiplies lr
+    const float lr_eff = lr * sqrtf(1.0f - __builtin_amdgcn_exp2f(t * log2_beta2)) / (1.0f - __builtin_amdgcn_exp2f(t * log2_beta1));
+    adam_one(g, mi, vi, w, lr_eff, beta1, beta2, eps);
+  };
+  const bool vec = (((uintptr_t)master | (uintptr_t)m | (uintptr_t)v | (uintptr_t)steps | (uintptr_t)grads_v) & 15) == 0 && ((uintptr_t)params & 7) == 0;
+  const long n4 = vec ? n / 4 : 0;
+  for (long q = (long)blockIdx.x * kThreads + threadIdx.x; q < n4; q += (long)gridDim.x * kThreads) {
+    float g[4];
+    if (HALF_GRADS) {
+      const uint2 raw = reinterpret_cast<const uint2*>(gh)[q];
+      if (((raw.x | raw.y) & 0x7fff7fffu) == 0u) continue;
+      const half4v h = __builtin_bit_cast(half4v, raw);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] = (float)h[e] * inv_loss_scale;
+      if (ZERO) reinterpret_cast<uint2*>(gh)[q] = make_uint2(0u, 0u);
+    } else {
+      const float4 f = reinterpret_cast<const float4*>(gf)[q];
+      if (f.x == 0.0f && f.y == 0.0f && f.z == 0.0f && f.w == 0.0f) continue;
+      g[0] = f.x * inv_loss_scale; g[1] = f.y * inv_loss_scale; g[2] = f.z * inv_loss_scale; g[3] = f.w * inv_loss_scale;
+      if (ZERO) reinterpret_cast<float4*>(gf)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 w4 = reinterpret_cast<float4*>(master)[q], m4 = reinterpret_cast<float4*>(m)[q], v4 = reinterpret_cast<float4*>(v)[q];
+    uint4 s4 = reinterpret_cast<uint4*>(steps)[q];
+    one(g[0], m4.x, v4.x, w4.x, s4.x);
+    one(g[1], m4.y, v4.y, w4.y, s4.y);
+    one(g[2], m4.z, v4.z, w4.z, s4.z);
+    one(g[3], m4.w, v4.w, w4.w, s4.w);
+    reinterpret_cast<float4*>(master)[q] = w4;
+    reinterpret_cast<float4*>(m)[q] = m4;
+    reinterpret_cast<float4*>(v)[q] = v4;
+    reinterpret_cast<uint4*>(steps)[q] = s4;
+    const half4v o = {(_Float16)w4.x, (_Float16)w4.y, (_Float16)w4.z, (_Float16)w4.w};
+    reinterpret_cast<half4v*>(params)[q] = o;
+  }
+  for (long i = 4 * n4 + (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
+    const float g = (HALF_GRADS ? __half2float(gh[i]) : gf[i]) * inv_loss_scale;
+    if (g == 0.0f) continue;
+    if (ZERO) { if (HALF_GRADS) gh[i] = __float2half(0.0f); else gf[i] = 0.0f; }
+    float mi = m[i], vi = v[i], w = master[i];
+    unsigned st = steps[i];
+    one(g, mi, vi, w, st);
+    m[i] = mi;
+    v[i] = vi;
+    master[i] = w;
+    steps[i] = st;
+    params[i] = __float2half(w);
+  }
+}
+
 // fp32 <-> fp16 copies of a gradient block (8 elements per thread): the data-parallel exchange of the hashed levels' gradient
 // travels in fp16 (tcnn keeps that gradient in fp16 to begin with), see rtx_nerf_amd/train.py
 __global__ __launch_bounds__(kThreads) void f32_to_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, long n) {
@@ -2337,6 +2403,31 @@ extern "C" int rtxn_adam_step_captured(long n, float* master, void* params_fp16,
   RTXN_REQUIRE((grad_flags & ~3) == 0, "rtxn_adam_step_captured: grad_flags = %d (RTXN_ADAM_GRADS_FP16 | RTXN_ADAM_ZERO_GRADS)", grad_flags);
   return adam_impl("rtxn_adam_step_captured", n, master, params_fp16, grads, grad_flags & RTXN_ADAM_GRADS_FP16,
                    (grad_flags & RTXN_ADAM_ZERO_GRADS) != 0, m, v, 0.0f, effective_lr, beta1, beta2, eps, loss_scale, stream);
+}
+
+extern "C" int rtxn_adam_step_sparse(long n, float* master, void* params_fp16, void* grads, int grad_flags, float* m, float* v,
+                                     unsigned* param_steps, float lr, float beta1, float beta2, float eps, float loss_scale,
+                                     rtxn_stream_t stream) {
+  RTXN_REQUIRE(n >= 0, "rtxn_adam_step_sparse: n = %ld", n);
+  RTXN_REQUIRE((grad_flags & ~3) == 0, "rtxn_adam_step_sparse: grad_flags = %d (RTXN_ADAM_GRADS_FP16 | RTXN_ADAM_ZERO_GRADS)", grad_flags);
+  RTXN_REQUIRE(loss_scale != 0.0f, "rtxn_adam_step_sparse: loss_scale = 0");
+  RTXN_DEVICE_OR_FAIL();
+  if (n == 0) return RTXN_OK;
+  RTXN_REQUIRE(master && params_fp16 && grads && m && v && param_steps, "rtxn_adam_step_sparse: NULL buffer");
+  const long blocks = (n / 4 + kThreads - 1) / kThreads;
+  const unsigned gridx = (unsigned)(blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks));
+  hipStream_t st = rtxn::as_stream(stream);
+  const float ils = 1.0f / loss_scale;
+  RTXN_REQUIRE(beta1 > 0.0f && beta1 < 1.0f && beta2 > 0.0f && beta2 < 1.0f, "rtxn_adam_step_sparse: beta1 = %g, beta2 = %g outside (0, 1)", beta1, beta2);
+  const float l2b1 = (float)log2((double)beta1), l2b2 = (float)log2((double)beta2);
+  __half* p16 = static_cast<__half*>(params_fp16);
+  const bool half = grad_flags & RTXN_ADAM_GRADS_FP16, zero = grad_flags & RTXN_ADAM_ZERO_GRADS;
+  if (half && zero) adam_sparse_kernel<true, true><<<gridx, kThreads, 0, st>>>(n, master, p16, grads, m, v, param_steps, lr, beta1, beta2, eps, ils, l2b1, l2b2);
+  else if (half) adam_sparse_kernel<true, false><<<gridx, kThreads, 0, st>>>(n, master, p16, grads, m, v, param_steps, lr, beta1, beta2, eps, ils, l2b1, l2b2);
+  else if (zero) adam_sparse_kernel<false, true><<<gridx, kThreads, 0, st>>>(n, master, p16, grads, m, v, param_steps, lr, beta1, beta2, eps, ils, l2b1, l2b2);
+  else adam_sparse_kernel<false, false><<<gridx, kThreads, 0, st>>>(n, master, p16, grads, m, v, param_steps, lr, beta1, beta2, eps, ils, l2b1, l2b2);
+  RTXN_LAUNCH_CHECK("adam_sparse_kernel");
+  return RTXN_OK;
 }
 
 // ------------------------------------------------------------------------- live segments

@@ -80,12 +80,17 @@ class Trainer:
             self.table = self.table_master.half()
             self.table_m = torch.zeros_like(self.table_master)
             self.table_v = torch.zeros_like(self.table_master)
+            # tiny-cuda-nn's Adam treats the table as "non-matrix" parameters: entries with a zero gradient are skipped and
+            # each entry counts its own updates for the bias correction (librtxn: rtxn_adam_step_sparse).  Also the cheap
+            # form -- a batch touches 0.2 .. 25 % of a hashed level.  RTXN_TABLE_ADAM=dense: every entry every step, global
+            # step count (rounds 1-2; A/B).
+            self.table_steps = torch.zeros(self.hg.n_params(), dtype=torch.int32, device=d)
+            self.table_adam_sparse = os.environ.get("RTXN_TABLE_ADAM", "sparse") != "dense"
             self.dtable = torch.zeros_like(self.table_master)
             # The hashed levels' gradient lives in fp16 (dtable_h = parameters hashed_lo..): the scatter writes both features
             # of a corner with one packed fp16 atomic (tiny-cuda-nn's grid gradient is __half2 too), the data-parallel
             # exchange sends it as it is, and it is widened into dtable[hashed_lo:] for Adam.  The densely stored leading
             # levels (thousands of contributions per entry) stay fp32.  RTXN_HASH_GRAD_FP16=0: everything fp32.
-            import os
             self.hashed_lo = self.hg.hashed_offset()
             self.hash_fp16 = (self.hg.cfg.n_features == 2 and self.hashed_lo < self.hg.n_params()
                               and os.environ.get("RTXN_HASH_GRAD_FP16", "1") != "0")
@@ -105,7 +110,6 @@ class Trainer:
         # 64-wide models (configs[2]): forward without saved activations + ONE fused backward kernel that recomputes them and
         # keeps every weight gradient on the chip (librtxn: mlp_bwd_fused64_kernel).  RTXN_TRAIN_RECOMPUTE=0 selects the
         # three-kernel path (saved activations, dgrad chain, weight-gradient GEMM) for A/B runs.
-        import os
         self.recompute = self.net.recompute_supported() and os.environ.get("RTXN_TRAIN_RECOMPUTE", "1") != "0"
         # launchSampler folded into the encoders / the hash scatter (they form the samples from the packed segments): the
         # float[S][5] samples and the separate sampler launch exist only for teacher rendering (render_rays(radiance_fn)) and
@@ -347,7 +351,9 @@ class Trainer:
             if self.encoding == "hash":
                 kw = dict(lr=self.lr * 10.0, eps=1e-15, loss_scale=self.loss_scale * grad_divisor)
                 lo = self.hashed_lo
-                if self.hash_fp16:     # dense levels from the fp32 gradient, hashed levels straight from the fp16 one
+                if self.table_adam_sparse:
+                    self._table_adam_sparse(**kw)
+                elif self.hash_fp16:     # dense levels from the fp32 gradient, hashed levels straight from the fp16 one
                     if lo > 0:
                         api.adam_step(self.table_master[:lo], self.table[:lo], self.dtable[:lo], self.table_m[:lo], self.table_v[:lo],
                                       self.step_count, **kw)
@@ -355,6 +361,14 @@ class Trainer:
                                              self.table_v[lo:], self.step_count, **kw)
                 else:
                     api.adam_step(self.table_master, self.table, self.dtable, self.table_m, self.table_v, self.step_count, **kw)
+
+    def _table_adam_sparse(self, **kw):
+        """rtxn_adam_step_sparse over the table: the densely stored levels from the fp32 gradient, the hashed ones from the fp16 one"""
+        lo = self.hashed_lo
+        parts = [(slice(0, lo), self.dtable[:lo]), (slice(lo, None), self.dtable_h)] if self.hash_fp16 else [(slice(None), self.dtable)]
+        for sl, g in parts:
+            if g.numel():
+                api.adam_step_sparse(self.table_master[sl], self.table[sl], g, self.table_m[sl], self.table_v[sl], self.table_steps[sl], **kw)
 
     def table_grad(self):
         """The hash grid's gradient as ONE fp32 vector in table layout (a copy; tests and tools).  In the default mixed form
@@ -459,7 +473,7 @@ class Trainer:
         arrs = {"mlp_master": self.master, "mlp_params": self.params, "mlp_adam_m": self.adam_m, "mlp_adam_v": self.adam_v}
         if self.encoding == "hash":
             arrs.update(table_master=self.table_master, table_params=self.table, table_adam_m=self.table_m,
-                        table_adam_v=self.table_v)
+                        table_adam_v=self.table_v, table_adam_steps=self.table_steps)
         return arrs
 
     def save_checkpoint(self, path):
@@ -574,7 +588,8 @@ class Trainer:
         self._g_side = side
         side.wait_stream(torch.cuda.current_stream())
         state = (self.master.clone(), self.params.clone(), self.adam_m.clone(), self.adam_v.clone())
-        tstate = (self.table_master.clone(), self.table.clone(), self.table_m.clone(), self.table_v.clone()) if self.encoding == "hash" else None
+        tstate = (self.table_master.clone(), self.table.clone(), self.table_m.clone(), self.table_v.clone(),
+                  self.table_steps.clone()) if self.encoding == "hash" else None
         clear_grads = self._clear_grads
         with torch.cuda.stream(side):
             clear_grads()
@@ -590,7 +605,7 @@ class Trainer:
         for dst, src in zip((self.master, self.params, self.adam_m, self.adam_v), state):
             dst.copy_(src)
         if tstate is not None:
-            for dst, src in zip((self.table_master, self.table, self.table_m, self.table_v), tstate):
+            for dst, src in zip((self.table_master, self.table, self.table_m, self.table_v, self.table_steps), tstate):
                 dst.copy_(src)
         self.net.set_params_training(self.params)
         self._g_step.fill_(self.step_count)
@@ -691,7 +706,9 @@ class Trainer:
         ls = self.loss_scale * grad_divisor
         api.adam_step_captured(self.master, self.params, self.dparams, self.adam_m, self.adam_v, lr_mlp, loss_scale=ls, zero_grads=True)
         self.net.set_params_training(self.params)
-        if self.encoding == "hash":
+        if self.encoding == "hash" and self.table_adam_sparse:
+            self._table_adam_sparse(lr=self.lr * 10.0, eps=1e-15, loss_scale=ls, zero_grads=True)    # no step number: per-entry counts
+        elif self.encoding == "hash":
             lo = self.hashed_lo
             if self.hash_fp16:
                 if lo > 0:

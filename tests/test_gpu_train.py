@@ -526,6 +526,43 @@ def test_outputs_only_forward_against_saving_forward_and_torch_per_column_tile(g
         assert torch.equal(saved, outs)
 
 
+@pytest.mark.parametrize("half_grads", [False, True])
+def test_adam_sparse_matches_oracle(gpu, oracle, half_grads):
+    """rtxn_adam_step_sparse (the hash table's optimizer) against oracle.adam_step_sparse over five steps of gradients that are
+    zero on a different 90 % of the entries each time: identical update counts, weights and moments to fp32 rounding of the
+    in-kernel bias correction (powf), untouched entries bit-identical to where they started; ZERO clears what it consumed."""
+    torch = gpu
+    from rtx_nerf_amd import api
+    rng = np.random.default_rng(11)
+    n = 10_003
+    master = rng.standard_normal(n).astype(np.float32) * 1e-2
+    m, v, st = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.uint32)
+    md, mm, vv = _dev(torch, master.copy()), _dev(torch, m.copy()), _dev(torch, v.copy())
+    sd = torch.zeros(n, dtype=torch.int32, device="cuda")
+    p16d = torch.zeros(n, dtype=torch.float16, device="cuda")
+    start = master.copy()
+    never = np.ones(n, bool)
+    for step in range(5):
+        g = (rng.standard_normal(n) * 0.3).astype(np.float16 if half_grads else np.float32)
+        g[rng.uniform(size=n) < 0.9] = 0
+        if step == 2:
+            g[:64] = 0                                    # whole 4-parameter groups and waves without a gradient
+        never &= g == 0
+        gd = _dev(torch, g.copy())
+        api.adam_step_sparse(md, p16d, gd, mm, vv, sd, lr=1e-2, eps=1e-15, loss_scale=4.0, zero_grads=(step % 2 == 0))
+        oracle.adam_step_sparse(master, g.astype(np.float32), m, v, st, lr=1e-2, eps=1e-15, loss_scale=4.0)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(sd.cpu().numpy().view(np.uint32), st)
+        np.testing.assert_allclose(md.cpu().numpy(), master, rtol=0, atol=3e-7)
+        np.testing.assert_allclose(mm.cpu().numpy(), m, rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(vv.cpu().numpy(), v, rtol=1e-6, atol=1e-12)
+        left = gd.cpu().numpy()
+        assert not left.any() if step % 2 == 0 else np.array_equal(left, g)
+        touched = st > 0
+        np.testing.assert_array_equal(p16d.cpu().numpy()[touched], md.cpu().numpy()[touched].astype(np.float16))
+    assert never.any() and np.array_equal(md.cpu().numpy()[never], start[never]) and not st[never].any()
+
+
 def test_half2_sparse_gradient_primitives(gpu):
     """rtxn_half2_count_nonzero / _pack_nonzero / _add_pairs (the device side of rtx_nerf_amd/dp.py): counts per block, a list
     that holds exactly the non-zero entries of the masked blocks (any order, -0 is zero), the masked blocks cleared, capacity

@@ -106,8 +106,11 @@ def test_config3_training_step_matches_oracle_chain(gpu, oracle):
     O.adam_step(master0, got_dp, m, v, 1, lr=1e-2, loss_scale=ls)
     np.testing.assert_allclose(tr.master.cpu().numpy(), master0, rtol=0, atol=2e-6)
     m, v = np.zeros_like(tmaster0), np.zeros_like(tmaster0)
-    O.adam_step(tmaster0, got_dt, m, v, 1, lr=1e-1, eps=1e-15, loss_scale=ls)
+    steps = np.zeros(tmaster0.size, np.uint32)           # the table: tiny-cuda-nn's non-matrix rule (zero gradient -> untouched)
+    O.adam_step_sparse(tmaster0, got_dt, m, v, steps, lr=1e-1, eps=1e-15, loss_scale=ls)
     np.testing.assert_allclose(tr.table_master.cpu().numpy(), tmaster0, rtol=0, atol=2e-6)
+    np.testing.assert_array_equal(tr.table_steps.cpu().numpy().view(np.uint32), steps)
+    assert 0 < int(steps.sum()) < steps.size
 
 
 def test_compat_training_step_matches_oracle_chain(gpu, oracle):

@@ -155,3 +155,22 @@ def test_adam_first_steps_known_answer(oracle):
     vv = 0.999 * 0.001 * g * g + 0.001 * g * g
     lr_eff = 1e-3 * np.sqrt(1 - 0.999 ** 2) / (1 - 0.9 ** 2)
     np.testing.assert_allclose(w, np.array([1.0 - 1e-3, -2.0 + 1e-3, 0.5]) - lr_eff * mm / (np.sqrt(vv) + 1e-8), atol=3e-7)
+
+
+def test_adam_sparse_known_answer(oracle):
+    """tiny-cuda-nn's Adam for hash-table entries (oracle.adam_step_sparse): an entry with a zero gradient is untouched, and an
+    entry's FIRST update moves it by exactly lr * sign(g) whenever that happens (bias correction by its own count), where the
+    dense rule at global step 2 would move it by lr * 0.1 / sqrt(0.001) * sqrt(1 - 0.999^2) / (1 - 0.9^2) != lr."""
+    w = np.array([1.0, 2.0, 3.0, -1.0], np.float32)
+    m, v = np.zeros(4, np.float32), np.zeros(4, np.float32)
+    st = np.zeros(4, np.uint32)
+    oracle.adam_step_sparse(w, np.array([0.0, 0.5, 0.0, -0.0], np.float32), m, v, st, lr=1e-2, eps=0.0)
+    np.testing.assert_allclose(w, [1.0, 1.99, 3.0, -1.0], rtol=0, atol=1e-7)
+    assert st.tolist() == [0, 1, 0, 0] and m[0] == 0 and v[0] == 0
+    p16 = oracle.adam_step_sparse(w, np.array([-0.25 * 8, 0.5 * 8, 0.0, 0.0], np.float32), m, v, st, lr=1e-2, eps=0.0, loss_scale=8.0)
+    assert st.tolist() == [1, 2, 0, 0]
+    assert abs(w[0] - 1.01) < 1e-7                        # first update of entry 0, at the optimizer's second call
+    # entry 1, second update with the same gradient: m_hat = v_hat^(1/2) = 0.5 -> moves by lr again
+    assert abs(w[1] - 1.98) < 2e-7
+    assert w[2] == 3.0 and w[3] == -1.0 and m[2] == 0 and v[3] == 0
+    assert p16[0] == np.float16(w[0]) and p16[1] == np.float16(w[1])
