@@ -63,14 +63,10 @@ inline ImageDataset load_images_json(std::string basename, std::string s) {
   return dataset;
 }
 
+// Same observable behaviour as the reference's function of this name (data_loader.cpp:96-107): it names three splits and
+// returns after the first, so the result holds exactly one dataset, the "train" split.
 inline std::vector<ImageDataset> load_synthetic_data(std::string directory) {
-  std::vector<std::string> strings = {"train", "val", "test"};
-  std::vector<ImageDataset> datasets;
-  for (const auto& string : strings) {
-    datasets.push_back(load_images_json(directory, string));
-    break;  // data_loader.cpp:103
-  }
-  return datasets;
+  return std::vector<ImageDataset>(1, load_images_json(directory, "train"));
 }
 
 // Not in the reference (its LLFF branch is a stub): <directory>/poses_bounds.npy + <directory>/images_<factor>/*.png.
