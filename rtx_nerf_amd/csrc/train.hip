@@ -533,9 +533,8 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_train_fwd_kernel(TrainArgs a)
 #pragma unroll
         for (int j = 0; j < 8; ++j)
           if (store_s[ct]) *row_elem(dst, perm_feature(kk, 0, j), a.Sp, lane_off[ct]) = ok_s[ct] ? v[kk][ct][j] : (_Float16)0.0f;
-    // sign masks for the backward chain (read by mlp_bwd_kernel<64> only, see there): values are post-ReLU (>= 0), so
-    // "> 0" is "the half is not +0"
-    if constexpr (W == 64)
+    // sign masks for the backward chain (mlp_bwd_kernel, see there): values are post-ReLU (>= 0), so "> 0" is "the half is
+    // not +0"
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
       unsigned long long mk = 0;
@@ -708,12 +707,13 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_bwd_kernel(TrainArgs a) {
   // forward does, and no full-layer fp32 dA is ever held (the first version kept one: 128 VGPRs at W = 128, 378 spills).
   // relu'(act_l) comes from the forward's sign masks: ONE 8-byte load per column tile and layer instead of W/2 two-byte
   // activation loads (bit 16*rt + e of the lane's word belongs to accumulator element e of row tile rt)
-  // (at W = 128 the mask form makes hipcc spill 165 VGPRs in the layer loop -- 2.6 instead of 2.0 ms per step -- so the
-  // 128-wide kernel still reads the activations themselves; at W = 64 the masks are worth 5 % of the step)
-  constexpr bool kUseMasks = W == 64;
+  // (rounds 1-2: at W = 128 the mask form made hipcc spill 165 VGPRs, so the 128-wide kernel kept reading the activations
+  // themselves.  The spills were 64-bit row ADDRESSES of the dZ stores, which LICM hoisted out of the layer loop once the
+  // activation loads that shared them were gone; with the row stride laundered through an empty asm per call
+  // (mask_pack_store) they are formed where they are used: 168 VGPRs, no scratch, and the kernel no longer reads 2 KB of
+  // activations per sample.  At W = 64 the masks were worth 5 % of the step.)
   unsigned mk[2][2] = {{0, 0}, {0, 0}};   // low / high word of the lane's mask (row tiles 0-1 / 2-3)
   auto load_masks = [&](int l) {
-    if constexpr (!kUseMasks) return;
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
       const uint2 w = *reinterpret_cast<const uint2*>(a.masks + ((long)l * a.Sp + samp[ct]) * 2 + h);
@@ -722,29 +722,21 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_bwd_kernel(TrainArgs a) {
     }
   };
   auto mask_pack_store = [&](int l, int rt, const floatx16 (&acc)[2], half8 (&dst)[KS][2]) {
-    _Float16* dzl = a.dz + (long)l * W * a.Sp;
+    long Sp_l = a.Sp;
+    asm volatile("" : "+s"(Sp_l));          // not loop-invariant to the compiler: row addresses are formed where they are used
+    _Float16* dzl = a.dz + (long)l * W * Sp_l;
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
       floatx16 m;
-      if constexpr (kUseMasks) {
-        const unsigned bits = (mk[ct][rt >> 1] >> (16 * (rt & 1))) & 0xffffu;
+      const unsigned bits = (mk[ct][rt >> 1] >> (16 * (rt & 1))) & 0xffffu;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) m[e] = (bits >> e) & 1u ? acc[ct][e] : 0.0f;
-      } else {
-        const _Float16* act = a.acts + (long)l * W * a.Sp;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int feat0 = 32 * rt + (e & 3) + 8 * (e >> 2);   // + 4h: in lane_off
-          const _Float16 av = *row_elem(act, feat0, a.Sp, lane_off[ct]);
-          m[e] = (float)av > 0.0f ? acc[ct][e] : 0.0f;
-        }
-      }
+      for (int e = 0; e < 16; ++e) m[e] = (bits >> e) & 1u ? acc[ct][e] : 0.0f;
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const half8 v = pack8<false>(m, s2);
         dst[2 * rt + s2][ct] = v;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) *row_elem(dzl, perm_feature(2 * rt + s2, 0, j), a.Sp, lane_dst[ct]) = v[j];
+        for (int j = 0; j < 8; ++j) *row_elem(dzl, perm_feature(2 * rt + s2, 0, j), Sp_l, lane_dst[ct]) = v[j];
       }
     }
   };
