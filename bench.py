@@ -356,8 +356,8 @@ def train_ref_record(batch_rays, grid_res, steps, warmup, dense_grid=True, mode=
                      "flop_per_sample": flop, "samples_per_launch": int(S), "traffic": None,
                      "live_fraction": round(live_frac, 4),
                      "flop_executed_per_sample": int(262144 * (1 + 2 * live_frac + (live_frac if tr.two_pass else 0))),
-                     "note": "whole step; the MLP kernels materialise activations and dZ (2 B x 128 per sample and layer, written once and read "
-                             "twice): their HBM floor is 8 layers x 128 x 2 B x 5 passes = 10 KB per sample"},
+                     "note": "whole step; the MLP kernels materialise activations, sign masks and dZ (2 B x 128 per sample and layer): "
+                             "8.6 KB per sample over forward, dgrad and wgrad -- mlp_kernels_hbm_floor_gbs is that traffic over their time"},
     }
     if captured:
         # the same step as ONE hipGraph with the traversal of the next batch beside the gradient kernels (Trainer.capture_step,
@@ -398,7 +398,10 @@ def train_ref_record(batch_rays, grid_res, steps, warmup, dense_grid=True, mode=
     if mlp_ms > 0:
         rec["roofline"]["mlp_kernels_ms"] = round(mlp_ms, 4)
         rec["roofline"]["mlp_kernels_frac"] = round(flop * S / (mlp_ms * 1e-3) / 1e12 / MFMA_F16_DENSE_PEAK_TFLOPS, 4)
-        rec["roofline"]["mlp_kernels_hbm_floor_gbs"] = round(10240 * S / (mlp_ms * 1e-3) / 1e9, 1)
+        # materialised per sample by the saved-activation path: forward 224 + 2048 + 128 + 48, dgrad 168 + 2080,
+        # wgrad 4096 bytes (round 2: 10,840 -- the dgrad chain re-read the activations)
+        rec["roofline"]["mlp_kernels_bytes_per_sample"] = 8792
+        rec["roofline"]["mlp_kernels_hbm_floor_gbs"] = round(8792 * S / (mlp_ms * 1e-3) / 1e9, 1)
     del tr
     torch.cuda.empty_cache()
     return rec

@@ -77,7 +77,10 @@ def test_data_parallel_equals_single_process(gpu, tmp_path):
     assert np.abs(ga - gb).max() < 2e-2 * np.abs(ga).max()
     assert np.linalg.norm(ga - gb) < 1e-2 * np.linalg.norm(ga)
     # parameters after 5 Adam steps: Adam divides by sqrt(v), so entries whose gradient is ~0 move by +-lr on
-    # rounding noise; the bulk must agree
+    # rounding noise; the bulk must agree.  The fraction bound is 0.95 (0.97 in round 1) because since round 2 the hashed
+    # levels' gradient is summed by packed fp16 atomics, whose last bit depends on arrival order: an entry whose gradient is
+    # noise around zero then gets +lr or -lr per step whichever way it rounds, up to 5 lr = 5e-2 apart between two runs, on
+    # a few percent of this small table (4 levels x 2^12 entries).  The bulk criterion (median < 1e-4) is unchanged.
     pa, pb = a[1], b[1]
     assert np.median(np.abs(pa - pb)) < 1e-4 and (np.abs(pa - pb) < 1e-2).mean() > 0.95
 
