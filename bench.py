@@ -660,9 +660,17 @@ def main():
                 "mfma": "v_mfma_f32_16x16x32_f16",
                 "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / MFMA_F16_DENSE_PEAK_TFLOPS, 4),
-                "traffic": pmc_traffic("mlp_fwd256x16_seg_half4" if args.neurons == 256 else "mlp_fwd16_128_seg_half4") if (args.neurons in (128, 256) and pipe.compact) else None,
+                "traffic": None,
                 "flop_per_sample": flops, "samples_per_launch": smp, "kernel_ms": round(ms, 4),
             }
+            # PMC bytes were collected on the default frame (all 640,000 rays: 100.09 M samples per launch); a rank's shard launches
+            # 1/N of that, and the kernel's traffic is per sample (8 B written + the segment records), so it is scaled by the samples
+            full = args.width == 800 and args.height == 800 and args.grid == 128 and args.neurons == 128 and args.layers == 8 and pipe.compact
+            t = pmc_traffic("mlp_fwd16_128_seg_half4") if full else None
+            if t:
+                out["roofline"]["traffic"] = int(t) if world == 1 else int(t * smp / 100.0878e6)
+                if world > 1:
+                    out["roofline"]["traffic_note"] = "PMC bytes of the full frame's launch x this rank's share of the samples"
         out["config"]["segments_per_frame_local_max"] = worst
         out["config"]["mean_samples_per_ray"] = round(smp / max(n_local, 1), 2)
 
