@@ -1,6 +1,10 @@
 #!/bin/bash
 # Builds timing-only variants of librtxn.so (rtx_nerf_amd/librtxn_<tag>.so) with extra -D flags for mlp.hip:
-#   tools/ablate.sh pipe2="-DRTXN_PIPE=2" noskew="-DRTXN_SKEW=0" ...   (value-preserving knobs only, see mlp.hip)
+#   tools/ablate.sh ring3="-DRTXN_PIPE16=3" noshare="-DRTXN_SHARE_DIR=0" ...
+# Value-preserving knobs that exist today (mlp.hip, mlp_internal.h): RTXN_PIPE16 (A-fragment ring depth of the 16x16x32 pipeline),
+# RTXN_SHARE_DIR (direction encoding shared across a segment), RTXN_STAMPS (diagnostic stamps, tools/probe/stamps.py); RTXN_PIPE is
+# the ring depth of the training forward's 32x32x16 pipeline (train.hip -- not rebuilt by this script).  Gone with the legacy
+# kernels in round 3: RTXN_SKEW, RTXN_ILV16, RTXN_MFMA_SHAPE.
 # then on the GPU:  RTXN_LIB_PATH=rtx_nerf_amd/librtxn_<tag>.so python tools/mlp_bench.py
 set -e
 cd "$(dirname "$0")/.."
