@@ -557,6 +557,38 @@ typedef struct rtxn_train_batch {
 } rtxn_train_batch;
 int rtxn_train_gradients(const rtxn_train_batch* batch, rtxn_stream_t stream);
 
+/* ---- one optimisation step as one call -------------------------------------------------------------------------------
+ * The body of the reference's training loop for one batch of rays (main.cu:619-805): traversal (count -> scan -> write, the
+ * packed layout of main.cu:646-673 written by the device) -> rtxn_train_gradients -> optimizer->step -> training-weight
+ * re-pack, enqueued on ONE stream with no host round trip (the reference synchronises for the segment count, main.cu:632, and
+ * re-packs the segments on the host).  Nothing in it allocates or synchronises: captured once into a hipGraph it is replayed per
+ * step with only the ray and target buffers refreshed.  The optimizer is tiny-cuda-nn's Adam: the MLP with the global step
+ * count (`step`, advanced by the call on the device), the hash table by the non-matrix rule (rtxn_adam_step_sparse); every
+ * gradient buffer is cleared as it is consumed, so they must be zero before the first call.
+ * trace: the batch's rays (explicit or pinhole), grid and the per-ray outputs (num_hits, viewing_direction, sub_hits ...);
+ *   its segment outputs are taken from `batch` (start_points, end_points, seg_view, num_stored, indices, segment_capacity).
+ * batch: as rtxn_train_gradients; total_segments is written by the scan of this call. */
+typedef struct rtxn_train_state {
+  float* mlp_master;            /* float[rtxn_mlp_n_params]: fp32 master copy (main.cu:328-342) */
+  void* mlp_params_fp16;        /* half[n]: the parameters the kernels read */
+  float* mlp_m; float* mlp_v;   /* Adam moments */
+  float* table_master; void* table_params_fp16; float* table_m; float* table_v;   /* hash grid only: the same for the table ... */
+  unsigned* table_steps;        /* ... and its per-entry update counts (uint32[n], zero-initialised) */
+  int* step;                    /* DEVICE int: optimisation steps taken so far; the call increments it */
+  float* effective_lr;          /* DEVICE float scratch: the MLP's bias-corrected rate of this step */
+  float lr, beta1, beta2, eps;  /* main.cu:36-46: 1e-3, 0.9, 0.999, 1e-8 */
+  float table_lr, table_eps;    /* tcnn non_matrix_learning_rate_factor x lr; 1e-15 */
+  float loss_scale_divisor;     /* 1, or the number of ranks whose gradients were summed into the buffers */
+} rtxn_train_state;
+typedef struct rtxn_train_step_args {
+  rtxn_trace_params trace;
+  void* scan_workspace;         /* rtxn_scan_workspace_bytes(batch.n_rays) */
+  size_t scan_workspace_bytes;
+  rtxn_train_batch batch;
+  rtxn_train_state opt;
+} rtxn_train_step_args;
+int rtxn_train_step(const rtxn_train_step_args* args, rtxn_stream_t stream);
+
 /* ---- segments that carry a loss gradient ---------------------------------------------------------------------------
  * In NeRF training most samples lie behind the first surface: their transmittance, and with it dL/d(radiance), is exactly
  * zero, and so is everything the backward pass would add for them.  rtxn_live_segments lists the 32-sample segments with a

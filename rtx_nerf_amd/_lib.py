@@ -95,6 +95,21 @@ class TrainBatch(C.Structure):
                 ("skip_table_backward", C.c_int)]
 
 
+class TrainState(C.Structure):
+    """struct rtxn_train_state (include/rtxn.h)."""
+    _fields_ = [("mlp_master", C.c_void_p), ("mlp_params_fp16", C.c_void_p), ("mlp_m", C.c_void_p), ("mlp_v", C.c_void_p),
+                ("table_master", C.c_void_p), ("table_params_fp16", C.c_void_p), ("table_m", C.c_void_p), ("table_v", C.c_void_p),
+                ("table_steps", C.c_void_p), ("step", C.c_void_p), ("effective_lr", C.c_void_p),
+                ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("table_lr", C.c_float), ("table_eps", C.c_float), ("loss_scale_divisor", C.c_float)]
+
+
+class TrainStepArgs(C.Structure):
+    """struct rtxn_train_step_args (include/rtxn.h)."""
+    _fields_ = [("trace", TraceParams), ("scan_workspace", C.c_void_p), ("scan_workspace_bytes", C.c_size_t),
+                ("batch", TrainBatch), ("opt", TrainState)]
+
+
 class RenderConfig(C.Structure):
     """struct rtxn_render_config (include/rtxn.h)."""
     _fields_ = [("mlp", C.c_void_p), ("grid", C.c_void_p), ("table_fp16", C.c_void_p), ("n_dir_freqs", C.c_int),
@@ -187,6 +202,7 @@ SYMBOLS = {
     "rtxn_adam_step_captured": (_I, [_L, _P, _P, _P, _I, _P, _P, _P, _F, _F, _F, _F, _P]),
     "rtxn_adam_step_sparse": (_I, [_L, _P, _P, _P, _I, _P, _P, _P, _F, _F, _F, _F, _F, _P]),
     "rtxn_train_gradients": (_I, [C.POINTER(TrainBatch), _P]),
+    "rtxn_train_step": (_I, [C.POINTER(TrainStepArgs), _P]),
     "rtxn_live_segments_workspace_bytes": (C.c_size_t, [_L]),
     "rtxn_live_segments": (_I, [_P, _L, _L, _P, _P]),
     "rtxn_mlp_train_backward_recompute_live": (_I, [_P, _P, _P, _P, _L, _P, _P, _P, _P]),

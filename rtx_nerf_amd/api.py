@@ -48,6 +48,17 @@ def trace_grid(look_at=None, focal_length=1.0, aspect_ratio=1.0, width=0, height
                end_points=None, t_start=None, t_end=None, seg_ray=None, seg_view=None, seg_first=None, num_stored=None, segment_capacity=0,
                window_chunk=0, window_stride=0, sub_rays=0, sub_hits=None):
     """optixLaunch(pipeline_ray_march, ..., width, height, 1) with Params (main.cu:481-508)."""
+    p = trace_params(**{k: v for k, v in locals().items()})
+    check(_lib.lib().rtxn_trace_grid(C.byref(p), _stream()), "rtxn_trace_grid")
+
+
+def trace_params(look_at=None, focal_length=1.0, aspect_ratio=1.0, width=0, height=0, *, grid_res,
+                 rays_o=None, rays_d=None, ray_begin=0, ray_count=None, occupancy=None,
+                 occupancy_coarse=None, occupancy_bricks=None, occupancy_super=None, mode=TRACE_COMPAT, ray_origins=None, viewing_direction=None,
+                 num_hits=None, intersection_arr_size=0, indices=None, start_points=None,
+                 end_points=None, t_start=None, t_end=None, seg_ray=None, seg_view=None, seg_first=None, num_stored=None, segment_capacity=0,
+                 window_chunk=0, window_stride=0, sub_rays=0, sub_hits=None):
+    """struct rtxn_trace_params over the given tensors (which the caller keeps alive)."""
     p = TraceParams()
     p.look_at = _ptr(look_at, torch.float32, "look_at")
     p.focal_length, p.aspect_ratio = focal_length, aspect_ratio
@@ -81,7 +92,7 @@ def trace_grid(look_at=None, focal_length=1.0, aspect_ratio=1.0, width=0, height
     p.window_chunk, p.window_stride = window_chunk, window_stride
     p.sub_rays = sub_rays
     p.sub_hits = _ptr(sub_hits, torch.int32, "sub_hits")
-    check(_lib.lib().rtxn_trace_grid(C.byref(p), _stream()), "rtxn_trace_grid")
+    return p
 
 
 def auto_sub_rays(n_rays):
@@ -587,6 +598,15 @@ def train_gradients(net, *, grid=None, n_dir_freqs=0, table=None, start_points, 
                     encT, dencT=None, workspace=None, output_half, radiance, t_vals, radiance_gradients, pixels, loss_gradients,
                     loss_sum=None, dparams, dtable=None, dtable_hashed_half=None, live_ws=None, skip_table_backward=False):
     """rtxn_train_gradients: sampler ... backward of one batch with the segment count taken on the device (main.cu:703-781)."""
+    b = train_batch(**{k: v for k, v in locals().items()})
+    check(_lib.lib().rtxn_train_gradients(C.byref(b), _stream()), "rtxn_train_gradients")
+
+
+def train_batch(net, *, grid=None, n_dir_freqs=0, table=None, start_points, end_points, seg_view, num_stored, indices,
+                total_segments, segment_capacity, n_rays, sample_type, t_scale=1.0, vr_mode, targets, loss_scale,
+                encT, dencT=None, workspace=None, output_half, radiance, t_vals, radiance_gradients, pixels, loss_gradients,
+                loss_sum=None, dparams, dtable=None, dtable_hashed_half=None, live_ws=None, skip_table_backward=False):
+    """struct rtxn_train_batch over the given tensors (which the caller keeps alive), sizes checked against the capacity."""
     b = _lib.TrainBatch()
     b.mlp, b.grid = net._h, (grid._h if grid is not None else None)
     b.n_dir_freqs = int(n_dir_freqs)
@@ -617,7 +637,12 @@ def train_gradients(net, *, grid=None, n_dir_freqs=0, table=None, start_points, 
                         ("targets", targets, 3 * int(n_rays)), ("num_stored", num_stored, int(n_rays)), ("indices", indices, int(n_rays))):
         if t.numel() < need:
             raise _lib.RtxnError(f"train_gradients: {nm} holds {t.numel()} elements, {need} needed for capacity {segment_capacity} / {n_rays} rays")
-    check(_lib.lib().rtxn_train_gradients(C.byref(b), _stream()), "rtxn_train_gradients")
+    return b
+
+
+def train_step(args):
+    """rtxn_train_step(args: _lib.TrainStepArgs): traversal -> gradients -> optimizer of one batch, one call, current stream."""
+    check(_lib.lib().rtxn_train_step(C.byref(args), _stream()), "rtxn_train_step")
 
 
 def half2_workspace(values, block_entries):

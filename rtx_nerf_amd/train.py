@@ -656,6 +656,67 @@ class Trainer:
                 self._graphs["table_bwd"] = [capture(lambda k=k: self._captured_table_bwd(k)) for k in range(len(sets))]
         return self
 
+    # ------------------------------------------------------------------------------------------ the step as ONE C call
+    def entry_args(self, n_rays, launch_segments=None):
+        """struct rtxn_train_step_args over this trainer's buffers: what a C++ host passes to rtxn_train_step (include/rtxn.h)
+        -- traversal, rtxn_train_gradients, optimizer and weight re-pack of one batch in one call.  Inputs are read from
+        graph_rays_o / graph_rays_d / graph_targets (created here if capture_step() has not).  The step counter the call
+        advances lives on the device (entry_step)."""
+        n = int(n_rays)
+        cap = max(1, min(int(launch_segments) if launch_segments else self.max_segments, self.max_segments))
+        d = self.dev
+        if getattr(self, "graph_rays_o", None) is None or self.graph_rays_o.shape[0] != n:
+            self.graph_rays_o = torch.zeros((n, 3), device=d)
+            self.graph_rays_d = torch.zeros((n, 3), device=d)
+            self.graph_rays_d[:, 2] = 1.0
+            self.graph_targets = torch.zeros((n, 3), device=d)
+        self.entry_step = torch.full((1,), self.step_count, dtype=torch.int32, device=d)
+        self._entry_lr = torch.zeros(1, device=d)
+        hash_ = self.encoding == "hash"
+        a = api._lib.TrainStepArgs()
+        a.trace = api.trace_params(grid_res=self.R, rays_o=self.graph_rays_o, rays_d=self.graph_rays_d, width=n, height=1, ray_begin=0,
+                                   ray_count=n, occupancy=self.occ, occupancy_coarse=self.coarse, occupancy_bricks=self.bricks,
+                                   occupancy_super=self.super_mip, mode=api.TRACE_DDA, viewing_direction=self.view_dirs,
+                                   num_hits=self.num_hits, sub_rays=api.auto_sub_rays(n), sub_hits=self.sub_hits)
+        a.scan_workspace = self.scan_ws.data_ptr()
+        a.scan_workspace_bytes = self.scan_ws.numel() * 4
+        a.batch = api.train_batch(self.net, grid=self.hg if hash_ else None, n_dir_freqs=self.hg.n_dir_freqs if hash_ else 0,
+                                  table=self.table if hash_ else None, start_points=self.start, end_points=self.end, seg_view=self.seg_view,
+                                  num_stored=self.num_stored, indices=self.indices, total_segments=self.total, segment_capacity=cap,
+                                  n_rays=n, sample_type=self._stype(), t_scale=self.density_scale if self.mode == "nerf" else 1.0,
+                                  vr_mode=api.VR_NERF if self.mode == "nerf" else api.VR_COMPAT, targets=self.graph_targets,
+                                  loss_scale=self.loss_scale, encT=self.encT, dencT=self.dencT, workspace=self.ws,
+                                  output_half=self.out, radiance=self.radiance, t_vals=self.t_vals, radiance_gradients=self.dout,
+                                  pixels=self.pixels, loss_gradients=self.loss_grads, loss_sum=self.loss, dparams=self.dparams,
+                                  dtable=self.dtable if hash_ else None,
+                                  dtable_hashed_half=self.dtable_h if (hash_ and self.hash_fp16) else None,
+                                  live_ws=self.live_ws if self.live_segments else None)
+        o = a.opt
+        o.mlp_master, o.mlp_params_fp16 = self.master.data_ptr(), self.params.data_ptr()
+        o.mlp_m, o.mlp_v = self.adam_m.data_ptr(), self.adam_v.data_ptr()
+        if hash_:
+            o.table_master, o.table_params_fp16 = self.table_master.data_ptr(), self.table.data_ptr()
+            o.table_m, o.table_v, o.table_steps = self.table_m.data_ptr(), self.table_v.data_ptr(), self.table_steps.data_ptr()
+        o.step, o.effective_lr = self.entry_step.data_ptr(), self._entry_lr.data_ptr()
+        o.lr, o.beta1, o.beta2, o.eps = self.lr, 0.9, 0.999, 1e-8
+        o.table_lr, o.table_eps, o.loss_scale_divisor = self.lr * 10.0, 1e-15, 1.0
+        self._entry_args, self._entry_cap = a, cap
+        self._clear_grads()            # the call's optimizer clears what it consumes; it must start from zeros
+        return a
+
+    def step_entry(self):
+        """One optimisation step on graph_rays_o / graph_rays_d / graph_targets through rtxn_train_step (entry_args() first).
+        Returns the (device) loss scalar; like step_captured() it never reads the segment count on the host."""
+        if not getattr(self, "_grads_clean", False):
+            self._clear_grads()
+        if int(self.step_count) != getattr(self, "_entry_step_host", self.step_count):
+            self.entry_step.fill_(self.step_count)
+        api.train_step(self._entry_args)
+        self._grads_clean = True       # the call's optimizer cleared every gradient it consumed
+        self.step_count += 1
+        self._entry_step_host = self.step_count
+        return self.loss
+
     def _clear_grads(self):
         self.dparams.zero_()
         if self.encoding == "hash":

@@ -44,6 +44,7 @@ def _header_fields(name):
 @pytest.mark.parametrize("c_name,binding", [("rtxn_trace_params", "TraceParams"), ("rtxn_mlp_config", "MlpConfig"),
                                             ("rtxn_hashgrid_config", "HashGridConfig"), ("rtxn_train_batch", "TrainBatch"),
                                             ("rtxn_render_config", "RenderConfig"), ("rtxn_render_stats", "RenderStats"),
+                                            ("rtxn_train_state", "TrainState"), ("rtxn_train_step_args", "TrainStepArgs"),
                                             ("rtxn_image_dataset", "ImageDataset")])
 def test_struct_layouts_match_header_order(c_name, binding):
     """Every struct that crosses the ABI: the ctypes binding lists the header's fields in the header's order."""

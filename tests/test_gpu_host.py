@@ -104,3 +104,29 @@ def test_cpp_host_frame_entry_is_the_python_pipelines_frame(gpu, oracle, tmp_pat
     cfg = oracle.mlp_cfg()
     ref, _ = oracle.render(la, f, W / H, W, H, R, words, 1, cfg, p16.numpy(), ids)
     np.testing.assert_allclose(got[ids], ref, rtol=0, atol=1e-3)
+
+
+def test_cpp_training_host_runs_the_reference_iteration_as_one_call_per_step(gpu, tmp_path):
+    """examples/train_host.cpp: the reference's own training iteration (8x128 + Composite-Frequency, REGULAR sampler, the
+    reference compositor and its backward, L2, Adam 1e-3, 8^3 dense grid) with rtxn_train_step as the whole loop body, captured
+    into a hipGraph after the first step.  The program exits non-zero on a non-finite loss or a device step counter that is not
+    the number of steps; here additionally: with the corrected (NeRF) compositor the loss halves, and the parameters either mode
+    leaves are finite and have moved from the PCG32 initialisation."""
+    torch = gpu
+    from rtx_nerf_amd import api
+    exe = os.path.join(ROOT, "examples", "train_host")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", ROOT, "examples/train_host"])
+    init = api.Network().initialize_params(1337).numpy()
+    for mode in ("compat", "nerf"):
+        out = str(tmp_path / f"master_{mode}.f32")
+        res = subprocess.run([exe, "151", "2048", "8", out, mode], capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stdout + res.stderr
+        losses = [float(line.split("loss")[1].split(",")[0]) for line in res.stdout.splitlines() if line.startswith("step")]
+        assert len(losses) >= 4 and all(np.isfinite(losses)), res.stdout
+        if mode == "nerf":       # the reference's own backward is not the gradient of its forward (SURVEY a10): only this one learns
+            assert losses[-1] < 0.5 * losses[0], res.stdout
+        assert "device step counter 151" in res.stdout and "ms per step" in res.stdout
+        got = np.fromfile(out, np.float32)
+        assert got.shape == init.shape and np.isfinite(got).all()
+        assert 1e-3 < np.abs(got - init).max() < 1.0          # 150 Adam steps of 1e-3

@@ -238,6 +238,62 @@ def test_captured_step_matches_the_eager_step(gpu, encoding, mode, neurons, laye
     assert np.linalg.norm(pa - pb) <= 3e-2 * np.linalg.norm(pa)          # six Adam steps at lr 1e-2 amplify gradient noise
 
 
+@pytest.mark.parametrize("encoding,mode,neurons,layers", [("hash", "nerf", 64, 4), ("freq", "compat", 128, 2), ("freq", "nerf", 128, 3)])
+def test_train_step_entry_matches_the_eager_step(gpu, encoding, mode, neurons, layers):
+    """rtxn_train_step -- traversal, rtxn_train_gradients, tiny-cuda-nn's Adam (device step counter) and the weight re-pack of one
+    batch as ONE C call, what a C++ host uses (examples/train_host.cpp) -- against Trainer.step (per-stage entry points, host
+    step count) on the same batches: same losses, same parameters up to the order of the atomics; then the same call captured
+    into a hipGraph and replayed."""
+    import numpy as np
+    torch = gpu
+    from rtx_nerf_amd import scenes
+    from rtx_nerf_amd.train import camera_rays
+    a = _small_trainer(torch, encoding, mode, neurons, layers)
+    b = _small_trainer(torch, encoding, mode, neurons, layers)
+    B = 900
+    focal = scenes.lego_focal_length(True)
+    rng = np.random.default_rng(5)
+    batches = []
+    for i in range(6):
+        o, d = camera_rays(scenes.pose_spherical(25.0 + 55.0 * i, -28.0 + 4.0 * i, origin_scale=10.0), focal, 30, 30)
+        batches.append((o, d, torch.from_numpy(rng.uniform(0, 1, (B, 3)).astype(np.float32)).cuda()))
+    b.entry_args(B, launch_segments=B * 30)
+    for i, (o, d, t) in enumerate(batches[:4]):
+        la = float(a.step(o, d, t).item())
+        b.graph_rays_o.copy_(o); b.graph_rays_d.copy_(d); b.graph_targets.copy_(t)
+        lb = float(b.step_entry().item())
+        assert int(b.total.item()) == int(a.total.item()) > 0
+        assert abs(la - lb) <= 5e-4 * abs(la), (i, la, lb)
+        assert int(b.entry_step.item()) == i + 1 == b.step_count
+        assert float(b.dparams.abs().max()) == 0.0           # consumed and cleared
+    # the rest of the batches through a captured graph of the same call
+    from rtx_nerf_amd import api
+    g = torch.cuda.CUDAGraph()
+    state = [x.clone() for x in (b.master, b.params, b.adam_m, b.adam_v, b.entry_step)]
+    tstate = [x.clone() for x in (b.table_master, b.table, b.table_m, b.table_v, b.table_steps)] if encoding == "hash" else []
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g):
+        api.train_step(b._entry_args)
+    torch.cuda.synchronize()
+    # (capturing does not execute: nothing to undo)
+    for x, y in zip((b.master, b.params, b.adam_m, b.adam_v, b.entry_step), state):
+        assert torch.equal(x, y)
+    for x, y in zip((b.table_master, b.table, b.table_m, b.table_v, b.table_steps) if encoding == "hash" else (), tstate):
+        assert torch.equal(x, y)
+    for i, (o, d, t) in enumerate(batches[4:]):
+        la = float(a.step(o, d, t).item())
+        b.graph_rays_o.copy_(o); b.graph_rays_d.copy_(d); b.graph_targets.copy_(t)
+        g.replay()
+        lb = float(b.loss.item())
+        assert abs(la - lb) <= 1e-3 * abs(la), (i, la, lb)
+    assert int(b.entry_step.item()) == 6
+    pa, pb = a.master.cpu().numpy(), b.master.cpu().numpy()
+    assert np.linalg.norm(pa - pb) <= 3e-2 * np.linalg.norm(pa)
+    if encoding == "hash":
+        ta, tb = a.table_master.cpu().numpy(), b.table_master.cpu().numpy()
+        assert np.linalg.norm(ta - tb) <= 5e-2 * np.linalg.norm(ta)
+
+
 def test_captured_step_with_the_traversal_one_batch_ahead(gpu):
     """capture_step(prefetch=True): every step_captured() call traverses the batch it is given as a parallel branch beside the
     gradient kernels of the batch given to the previous call.  Same losses as the eager step, one call later; flush_captured()
