@@ -662,6 +662,11 @@ class Trainer:
         -- traversal, rtxn_train_gradients, optimizer and weight re-pack of one batch in one call.  Inputs are read from
         graph_rays_o / graph_rays_d / graph_targets (created here if capture_step() has not).  The step counter the call
         advances lives on the device (entry_step)."""
+        if _world() > 1:
+            raise RuntimeError("entry_args: rtxn_train_step steps the optimizer inside the call; data-parallel training exchanges the "
+                               "gradients between rtxn_train_gradients and the optimizer (step() / capture_step())")
+        if self.encoding == "hash" and not self.table_adam_sparse:
+            raise RuntimeError("entry_args: rtxn_train_step steps the table by tiny-cuda-nn's non-matrix rule (RTXN_TABLE_ADAM=dense is set)")
         n = int(n_rays)
         cap = max(1, min(int(launch_segments) if launch_segments else self.max_segments, self.max_segments))
         d = self.dev
