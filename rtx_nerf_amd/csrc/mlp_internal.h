@@ -295,6 +295,9 @@ __device__ __forceinline__ void pipe_layer(const uint8_t* lds_buf, half8 (&bf)[N
 // A wave owns 64 samples as FOUR 16-column tiles (CT = 4), so a 1-KiB A fragment still feeds 64 kFLOP (4 MFMAs x 16
 // cycles = the 2 x 32 cycles of the other shape) and the LDS traffic per FLOP is unchanged.
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+#ifndef RTXN_PRIO_BANDS
+#define RTXN_PRIO_BANDS 1   // 0: no s_setprio; 1: 3, 2, 1, 0 over a layer's quarters (default); 2: 1, 0 over its halves; 3: rising (the control)
+#endif
 #ifndef RTXN_PIPE16
 #define RTXN_PIPE16 2   // A-fragment ring depth of the 16x16x32 pipeline: a step is 4 MFMAs = 64 cycles, so two steps ahead covers
 #endif                  // the LDS latency, and the third slot's 4 VGPRs are what keeps the 128-wide segment variants from spilling
@@ -411,6 +414,19 @@ struct PipeStep16 {
                                              floatx4 (&acc)[2][CT], const StageJob& sj, int wave_u, int lane) {
     constexpr int rt = I / KS, kk = I % KS, cur = rt & 1;
     constexpr int outstanding = (N - 1 - I) < (D - 1) ? (N - 1 - I) : (D - 1);
+#if RTXN_PRIO_BANDS
+    // Issue priority falls with progress through the layer (3, 2, 1, 0 over its four quarters): of the two waves that share a
+    // SIMD the one that is behind wins the arbitration, so neither runs the end of the stage alone (a lone wave issues its
+    // MFMAs at 75 % of the rate two interleaved waves reach -- the older wave group used to finish a stage at 3,050 cycles and
+    // leave the other until 4,700).
+#if RTXN_PRIO_BANDS == 1
+    if constexpr (kk == 0 && RT >= 4 && rt % (RT / 4) == 0) asm volatile("s_setprio %0" ::"n"(3 - rt / (RT / 4)));
+#elif RTXN_PRIO_BANDS == 2
+    if constexpr (kk == 0 && RT >= 2 && rt % (RT / 2) == 0) asm volatile("s_setprio %0" ::"n"(1 - rt / (RT / 2)));
+#elif RTXN_PRIO_BANDS == 3
+    if constexpr (kk == 0 && RT >= 4 && rt % (RT / 4) == 0) asm volatile("s_setprio %0" ::"n"(rt / (RT / 4)));
+#endif
+#endif
     lds_wait_insn<outstanding>();
     if constexpr (rt > 0) {
       using R = UnitRange16<CT, U, kk>;
