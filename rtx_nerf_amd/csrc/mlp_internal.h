@@ -298,6 +298,9 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 #ifndef RTXN_PRIO_BANDS
 #define RTXN_PRIO_BANDS 1   // 0: no s_setprio; 1: 3, 2, 1, 0 over a layer's quarters (default); 2: 1, 0 over its halves; 3: rising (the control)
 #endif
+#ifndef RTXN_PRIO_BANDS256
+#define RTXN_PRIO_BANDS256 1   // the same over the four row tiles of a chunk of the 256-wide kernel (config5 13.69 -> 13.45 ms); the training
+#endif                         // forward's 32x32x16 pipeline measured no change with it and carries none
 #ifndef RTXN_PIPE16
 #define RTXN_PIPE16 2   // A-fragment ring depth of the 16x16x32 pipeline: a step is 4 MFMAs = 64 cycles, so two steps ahead covers
 #endif                  // the LDS latency, and the third slot's 4 VGPRs are what keeps the 128-wide segment variants from spilling
@@ -489,6 +492,9 @@ struct PipeStep16c {
                                              floatx4 (&acc)[2][CT], const StageJob& sj, int wave_u, int lane) {
     constexpr int r = I / KS, kk = I % KS, cur = r & 1;
     constexpr int outstanding = (N - 1 - I) < (D - 1) ? (N - 1 - I) : (D - 1);
+#if RTXN_PRIO_BANDS256
+    if constexpr (kk == 0 && NR >= 4 && r % (NR / 4) == 0) asm volatile("s_setprio %0" ::"n"(3 - r / (NR / 4)));     // see PipeStep16
+#endif
     lds_wait_insn<outstanding>();
     if constexpr (r > 0 && kk >= 1) {
       using R = UnitRange16<CT, U, kk - 1>;

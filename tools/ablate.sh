@@ -17,3 +17,4 @@ for kv in "$@"; do
       $(ls build/*.o | grep -v "build/mlp") -lz && echo "built $tag" ) &
 done
 wait
+rm -f build/mlp_*.o          # variant objects must not be picked up by a later link of build/*.o
