@@ -421,7 +421,8 @@ struct PipeStep16 {
     // Issue priority falls with progress through the layer (3, 2, 1, 0 over its four quarters): of the two waves that share a
     // SIMD the one that is behind wins the arbitration, so neither runs the end of the stage alone (a lone wave issues its
     // MFMAs at 75 % of the rate two interleaved waves reach -- the older wave group used to finish a stage at 3,050 cycles and
-    // leave the other until 4,700).
+    // leave the other until 4,700; with the bands 4,000 and 4,500, tile 44,400 -> 42,800 cycles.  Giving the trailing group one level more at
+    // equal progress, or eighths against quarters, measured slightly worse than the symmetric form).
 #if RTXN_PRIO_BANDS == 1
     if constexpr (kk == 0 && RT >= 4 && rt % (RT / 4) == 0) asm volatile("s_setprio %0" ::"n"(3 - rt / (RT / 4)));
 #elif RTXN_PRIO_BANDS == 2
