@@ -95,6 +95,87 @@ def closed_form():
     np.savez_compressed(os.path.join(HERE, "kat_closed_form.npz"), **out)
 
 
+def north_star_closed_form():
+    """The north_star model's arithmetic that the reference's config does not use, restated in numpy float64 from the published
+    algorithms, independently of oracle/rtxn_oracle.c: tiny-cuda-nn's multiresolution hash encoding (grid.h: level scale
+    base * s^l - 1, resolution ceil(scale) + 1, pos = x * scale + 0.5, dense index x + y r + z r^2 while r^3 fits the level's
+    parameter count, else (x * 1) ^ (y * 2654435761) ^ (z * 805459861) in 32-bit arithmetic, both modulo the level's parameter
+    count; trilinear weights), and the
+    emission-absorption quadrature of the corrected compositor, w_i = exp(-sum_{j<i} sigma_j d_j) (1 - exp(-sigma_i d_i)), with
+    its gradient taken numerically (central differences in float64) -- not from the closed form the kernels implement."""
+    rng = np.random.default_rng(20261004)
+    out = {}
+    L, F, T, base, s = 6, 2, 10, 4, 1.5
+    pts = rng.uniform(-1, 1, (40, 3)).astype(np.float32)
+    pts[0] = (-1.0, -1.0, -1.0)
+    pts[1] = (1.0, 1.0, 1.0)
+    pts[2] = (0.0, 0.25, -0.5)
+    levels, off = [], 0
+    for l in range(L):
+        scale = np.float32(np.exp2(np.float32(l) * np.log2(np.float32(s))) * np.float32(base) - np.float32(1.0))
+        res = int(np.ceil(scale)) + 1
+        dense = (res ** 3 + 7) // 8 * 8
+        size = min(dense, 1 << T)
+        levels.append((float(scale), res, size, off))
+        off += size
+    n_params = off * F
+    table = (rng.standard_normal(n_params) * 0.5).astype(np.float16)
+    tab = table.astype(np.float64).reshape(-1, F)
+    enc = np.zeros((pts.shape[0], L * F))
+    for i, p in enumerate(pts):
+        x01 = p.astype(np.float64) * 0.5 + 0.5
+        for l, (scale, res, size, o) in enumerate(levels):
+            pos = x01 * scale + 0.5
+            g = np.floor(pos).astype(np.int64)
+            fr = pos - g
+            for c in range(8):
+                w, q = 1.0, []
+                for a in range(3):
+                    hi = (c >> a) & 1
+                    w *= fr[a] if hi else 1.0 - fr[a]
+                    q.append(int(g[a]) + hi)
+                if res ** 3 <= size:
+                    idx = q[0] + q[1] * res + q[2] * res * res       # the +1 corner of a boundary cell runs past the level ...
+                else:
+                    idx = ((q[0] * 1) & 0xffffffff) ^ ((q[1] * 2654435761) & 0xffffffff) ^ ((q[2] * 805459861) & 0xffffffff)
+                idx %= size                                          # ... grid_index() ends in `index % hashmap_size` either way
+                enc[i, l * F:(l + 1) * F] += w * tab[o + idx]
+    out.update(hg_cfg=np.array([L, F, T, base], np.int64), hg_scale=np.array([s], np.float64), hg_points=pts, hg_table=table, hg_enc=enc,
+               hg_level_sizes=np.array([lv[2] for lv in levels], np.int64))
+    # --- corrected compositor on a ragged CSR, K = 32 samples per segment
+    K = 32
+    nh = np.array([2, 0, 1, 3], np.int32)
+    idx = np.concatenate([[0], np.cumsum(nh)[:-1]]).astype(np.int32)
+    P = int(nh.sum())
+    rad = rng.uniform(0, 1, (P * K, 4)).astype(np.float32)
+    rad[:, 3] *= 3.0
+    step = rng.uniform(0.01, 0.08, P * K).astype(np.float32)
+
+    def render(r64):
+        pix = np.zeros((nh.size, 3))
+        for r in range(nh.size):
+            Tacc = 0.0
+            for q in range(idx[r] * K, (idx[r] + nh[r]) * K):
+                x = float(step[q]) * r64[q, 3]
+                pix[r] += np.exp(-Tacc) * (1.0 - np.exp(-x)) * r64[q, :3]
+                Tacc += x
+        return pix
+
+    r64 = rad.astype(np.float64)
+    pix = render(r64)
+    g = rng.standard_normal((nh.size, 3)).astype(np.float16)
+    grads = np.zeros((P * K, 4))
+    eps = 1e-6
+    for q in range(P * K):
+        for ch in range(4):
+            a, b = r64.copy(), r64.copy()
+            a[q, ch] += eps
+            b[q, ch] -= eps
+            grads[q, ch] = ((render(a) - render(b)) * g.astype(np.float64)).sum() / (2 * eps)
+    out.update(nerf_radiance=rad, nerf_step=step, nerf_num_hits=nh, nerf_indices=idx, nerf_pixels=pix, nerf_loss_grads=g, nerf_grads=grads)
+    np.savez_compressed(os.path.join(HERE, "kat_north_star.npz"), **out)
+
+
 def oracle_snapshot():
     import oracle as O
     from rtx_nerf_amd import scenes
@@ -116,5 +197,6 @@ def oracle_snapshot():
 
 if __name__ == "__main__":
     closed_form()
+    north_star_closed_form()
     oracle_snapshot()
     print("wrote", sorted(p for p in os.listdir(HERE) if p.endswith(".npz")))

@@ -2,6 +2,8 @@
 
 kat_closed_form.npz -- expected values derived in numpy float64 from the formulas the reference source spells
 out, independently of the oracle: the oracle (CPU tests) AND the HIP kernels (gpu tests) are both held to them.
+kat_north_star.npz -- the same for the north_star model's own arithmetic (tiny-cuda-nn hash encoding; the corrected
+compositor with a central-difference gradient), restated from the published formulas (round 3).
 oracle_snapshot.npz -- a regression pin of the oracle itself (the reference holds no vectors: parity unpinned).
 """
 import os
@@ -133,3 +135,56 @@ def test_hip_render_against_oracle_snapshot(gpu):
         P = int(pipe.total.item())
         np.testing.assert_array_equal(pipe.start[:P].cpu().numpy(), SNAP[f"m{mode}_start"])
         np.testing.assert_allclose(pix, SNAP[f"m{mode}_pixels"], rtol=0, atol=2e-3)
+
+
+# ------------------------------------------------------------------ the north_star model's own arithmetic (round 3)
+NS = np.load(os.path.join(HERE, "golden", "kat_north_star.npz"))
+
+
+def _ns_in5():
+    p = NS["hg_points"]
+    return np.concatenate([p, np.zeros((p.shape[0], 2), np.float32)], axis=1)
+
+
+def test_oracle_hashgrid_and_nerf_compositor_against_float64_restatements(oracle):
+    """kat_north_star.npz: tiny-cuda-nn's hash encoding and the corrected compositor with a NUMERICAL gradient, both restated
+    in numpy float64 from the published formulas without touching oracle/rtxn_oracle.c."""
+    L, F, T, base = (int(v) for v in NS["hg_cfg"])
+    cfg = oracle.hg_cfg(L, F, T, base, float(NS["hg_scale"][0]))
+    assert oracle.hg_n_params(cfg) == NS["hg_table"].size == int(NS["hg_level_sizes"].sum()) * F
+    enc = oracle.encode_hg(cfg, 0, NS["hg_table"], _ns_in5())[:, :L * F].astype(np.float64)
+    np.testing.assert_allclose(enc, NS["hg_enc"], rtol=0, atol=1.5e-3)          # fp16 outputs of values up to ~2
+    assert np.abs(enc - NS["hg_enc"]).mean() < 2e-4
+    pix = oracle.volrender_fwd_nerf(NS["nerf_radiance"], NS["nerf_num_hits"], NS["nerf_indices"], NS["nerf_step"])
+    np.testing.assert_allclose(pix, NS["nerf_pixels"], rtol=0, atol=3e-6)
+    g = oracle.volrender_bwd_nerf(NS["nerf_loss_grads"], NS["nerf_radiance"], NS["nerf_step"], NS["nerf_num_hits"], NS["nerf_indices"])
+    np.testing.assert_allclose(g.astype(np.float64), NS["nerf_grads"], rtol=2e-3, atol=2e-6)     # fp16 outputs vs central differences
+
+
+@pytest.mark.gpu
+def test_hip_hashgrid_and_nerf_compositor_against_float64_restatements(gpu):
+    torch = gpu
+    from rtx_nerf_amd import api
+
+    def dev(a, dt=None):
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        return (t if dt is None else t.to(dt)).cuda()
+
+    L, F, T, base = (int(v) for v in NS["hg_cfg"])
+    hg = api.HashGrid(n_levels=L, n_features=F, log2_hashmap_size=T, base_resolution=base, per_level_scale=float(NS["hg_scale"][0]),
+                      n_dir_freqs=0)
+    assert hg.n_params() == NS["hg_table"].size
+    n = NS["hg_points"].shape[0]
+    encT = hg.encode(dev(NS["hg_table"]), dev(_ns_in5()))
+    enc = encT.cpu().numpy()[:L * F, :n].T.astype(np.float64)
+    np.testing.assert_allclose(enc, NS["hg_enc"], rtol=0, atol=1.5e-3)
+    assert np.abs(enc - NS["hg_enc"]).mean() < 2e-4
+    nr = NS["nerf_num_hits"].size
+    pix = torch.zeros((nr, 3), device="cuda")
+    api.launch_volrender_cuda(None, dev(NS["nerf_radiance"]), dev(NS["nerf_num_hits"]), dev(NS["nerf_indices"]), dev(NS["nerf_step"]),
+                              nr, 32, pix, mode=api.VR_NERF)
+    np.testing.assert_allclose(pix.cpu().numpy(), NS["nerf_pixels"], rtol=0, atol=1e-5)
+    g = torch.zeros((NS["nerf_step"].size, 4), dtype=torch.float16, device="cuda")
+    api.launch_volrender_backward_cuda(None, dev(NS["nerf_loss_grads"]), dev(NS["nerf_radiance"]), dev(NS["nerf_step"]),
+                                       dev(NS["nerf_num_hits"]), dev(NS["nerf_indices"]), nr, 32, g, mode=api.VR_NERF)
+    np.testing.assert_allclose(g.cpu().numpy().astype(np.float64), NS["nerf_grads"], rtol=2.5e-3, atol=3e-6)
