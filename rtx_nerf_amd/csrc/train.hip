@@ -454,6 +454,27 @@ __device__ __forceinline__ const _Float16* row_elem(const _Float16* X, int f0, l
   return reinterpret_cast<const _Float16*>(reinterpret_cast<const char*>(X + (long)f0 * Sp) + lane_off);
 }
 
+// The eight halves of one B fragment (k-step kk of a lane's sample: features perm_feature(kk, 0, 0..7), +4h folded into
+// lane_off) to their rows of a feature-major tensor, each as ONE instruction: the half leaves its register as it stands
+// (global_store_short / _d16_hi) for saddr = the row (scalar ALU) + voffset = lane_off.  Written as asm because hipcc does not
+// get there by itself: it re-associates the address into (X + lane_off) + row, a 64-bit per-lane base, and pays a 64-bit
+// VALU add (v_lshl_add_u64) per store plus shifts for the odd halves -- 2-3 VALU instructions per stored element in the
+// kernels that materialise 128 elements per sample and layer.  Two-byte data: no VMEM data-hazard wait states apply.
+__device__ __forceinline__ void store_fragment_rows(_Float16* X, int kk, long Sp, unsigned lane_off, const half8& v) {
+  const rtxn::int4v w = __builtin_bit_cast(rtxn::int4v, v);
+  // rows 16 kk + {0, 1, 2, 3, 8, 9, 10, 11}: a running scalar pointer, two scalar adds per store (left to itself hipcc forms
+  // every row's product with Sp ahead of the layer loop and spills scalar registers to hold them)
+  const char* row = reinterpret_cast<const char*>(X + 16L * kk * Sp);
+  const long step = 2 * Sp;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    asm volatile("" : "+s"(row));
+    if (j & 1) asm volatile("global_store_short_d16_hi %0, %1, %2" ::"v"(lane_off), "v"(w[j >> 1]), "s"(row) : "memory");
+    else asm volatile("global_store_short %0, %1, %2" ::"v"(lane_off), "v"(w[j >> 1]), "s"(row) : "memory");
+    row += j == 3 ? 5 * step : step;
+  }
+}
+
 // SAVE = false: outputs only (no activations, no masks): the forward half of the recompute path, whose backward
 // (mlp_bwd_fused64_kernel) rebuilds the activations in registers from the encoded input.
 template <int W, bool SAVE = true>
@@ -523,6 +544,9 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_train_fwd_kernel(TrainArgs a)
         for (int ct = 0; ct < 2; ++ct) bf[2 * rt + s2][ct] = pack8<true>(acc[rt][ct], s2);
     off += (long)KS0 * RT * 1024;
   }
+  // (the stores stay the compiler's: k-step outer, column tile inner, so the two 64-byte halves of a row's 128-byte line leave
+  // the wave close together -- column-tile outer cost 0.5 ms per 4.7 M samples -- and in this kernel neither dropping the
+  // per-store select nor store_fragment_rows' one-instruction stores changed the time: profiles/r03/train_store_paths.txt)
   auto save_acts = [&](int l, const half8 (&v)[KS][2]) {
     if constexpr (!SAVE) return;
     _Float16* dst = a.acts + (long)l * W * a.Sp;
@@ -711,7 +735,8 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_bwd_kernel(TrainArgs a) {
   // themselves.  The spills were 64-bit row ADDRESSES of the dZ stores, which LICM hoisted out of the layer loop once the
   // activation loads that shared them were gone; with the row stride laundered through an empty asm per call
   // (mask_pack_store) they are formed where they are used: 168 VGPRs, no scratch, and the kernel no longer reads 2 KB of
-  // activations per sample.  At W = 64 the masks were worth 5 % of the step.)
+  // activations per sample.  At W = 64 the masks were worth 5 % of the step.  The dZ stores themselves are
+  // store_fragment_rows' one-instruction form: 2.6 -> 2.25 ms per 4.7 M samples at W = 128.)
   unsigned mk[2][2] = {{0, 0}, {0, 0}};   // low / high word of the lane's mask (row tiles 0-1 / 2-3)
   auto load_masks = [&](int l) {
 #pragma unroll
@@ -735,8 +760,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_bwd_kernel(TrainArgs a) {
       for (int s2 = 0; s2 < 2; ++s2) {
         const half8 v = pack8<false>(m, s2);
         dst[2 * rt + s2][ct] = v;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) *row_elem(dzl, perm_feature(2 * rt + s2, 0, j), Sp_l, lane_dst[ct]) = v[j];
+        store_fragment_rows(dzl, 2 * rt + s2, Sp_l, lane_dst[ct], v);
       }
     }
   };
@@ -1293,17 +1317,60 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
 // Layers with more than one 64x64 output tile (M or N up to 128): one BLOCK per sample chunk computes the whole (up to)
 // 128x128 gradient, wave w its 64x64 quadrant (w >> 1, w & 1), from operands staged ONCE in LDS.  The per-wave kernel
 // above reads every dZ / X row from global memory once per tile that uses it -- twice for a 128x128 layer, and it is
-// bound by exactly that traffic (32 FLOP per byte).  Staging is LDS-DMA straight into MFMA fragment order: fragment
-// (k-step kk, row group q: 0-3 dZ rows, 4-7 X rows) = lane (h, r)'s 16 bytes (8 samples 16kk + 8h.. of row 32q + r), so
-// one global_load_lds instruction fills one 1-KiB fragment and every operand read is one conflict-free ds_read_b128.
-constexpr int kWgK = 4;                                  // k-steps (of 16 samples) per stage
-constexpr int kWgStage = kWgK * 8 * 1024;                // bytes per stage: kWgK x 8 fragments
+// bound by exactly that traffic (32 FLOP per byte).
+// A stage is 64 samples of all 256 rows (128 dZ rows, then 128 X rows): one full 128-byte line per row, 32 KiB.  It is
+// filled by LDS-DMA in pieces of 8 rows x 128 B (a wave instruction reads 8 whole lines; the fragment-shaped fill of
+// rounds 2-3, 32 rows x 32 B per instruction, asked the texture path for four times the lines).  LDS-DMA writes lane i at
+// piece + 16 i, so the image is row-major [256][128 B] and the bank swizzle sits on the SOURCE side: lane (row, slot')
+// fetches the row's 16-byte sample group slot' ^ ((row >> 1) & 7), and the fragment read of lane (h, r) for k-step ks --
+// samples 16 ks + 8 h .. + 7 of row 32 q + r -- is one ds_read_b128 at row * 128 + 16 * ((2 ks + h) ^ ((r >> 1) & 7)):
+// conflict-free over ds_read_b128's four 16-lane groups (rows distinct mod 16 in each).
+// The ring holds kWgStages stages with kWgStages - 1 outstanding per block, retired in order by counted
+// `s_waitcnt vmcnt(N)` (LDS-DMA completes in issue order); nothing else inside the loop touches vmcnt -- the chunk's
+// live-tile flags are gathered into a 64-bit mask up front and live-list entries come through the scalar cache.
+#ifndef RTXN_WG_STAGES
+#define RTXN_WG_STAGES 2
+#endif
+#ifndef RTXN_WG_CHUNK
+#define RTXN_WG_CHUNK 0                                  // 0: chosen per launch (wgrad_chunk)
+#endif
+constexpr int kWgK = 4;                                  // k-steps (of 16 samples) per stage: one 128-byte line per row
+constexpr int kWgStages = RTXN_WG_STAGES;                // ring depth; kWgStages - 1 stages in flight
+constexpr int kWgStage = 256 * 128;                      // bytes per stage
+constexpr int kWgLoads = 8;                              // LDS-DMA pieces per wave per stage
+constexpr long kWgMaxChunk = 64L * kTile;                // samples per block: one 64-bit mask of 256-sample tiles
+static_assert(kWgStages >= 2 && (kWgStages - 2) * kWgLoads <= 63, "vmcnt is a 6-bit count");
+static_assert(kWgStages * kWgStage <= 160 * 1024, "LDS");
+static_assert(RTXN_WG_CHUNK % kTile == 0 && RTXN_WG_CHUNK <= kWgMaxChunk, "chunk: whole tiles, at most 64");
+
+// samples per block: long chunks keep the 64 KiB of atomic adds a block ends with rare (4.7 M samples x 9 layers at 2048 per
+// block: 1.4 GB of them), short ones keep a small batch spread over the chip
+static long wgrad_chunk(long Sp, int layers, bool live_list) {
+  if (RTXN_WG_CHUNK) return RTXN_WG_CHUNK;
+  if (live_list) return 2048;                            // the contraction length is on the device and usually short
+  for (long c = 8192; c > 2048; c /= 2)
+    if ((Sp + c - 1) / c * layers >= 4096) return c;
+  return 2048;
+}
+
+template <int N>
+__device__ __forceinline__ void wg_wait_then_barrier() {
+  // own DMA pieces of the oldest stage landed (N newer ones may still fly), own LDS reads of the previous stage done
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+template <int D>
+__device__ __forceinline__ void wg_retire_oldest(int newer) {   // newer: block-uniform number of stages issued after the oldest
+  if constexpr (D == 0) wg_wait_then_barrier<0>();
+  else {
+    if (newer >= D) wg_wait_then_barrier<D * kWgLoads>();
+    else wg_retire_oldest<D - 1>(newer);
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void wgrad_lds_kernel(WgradArgs a) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t wsm[];   // 2 stages
+  extern __shared__ __attribute__((aligned(16))) uint8_t wsm[];   // kWgStages stages
   const WgradLayer& L = a.layer[blockIdx.y];
   if (L.n_tiles < 2) return;                             // single-tile layers: wgrad_kernel
-  const _Float16* __restrict__ dZ = L.dZ;
-  const _Float16* __restrict__ X = L.X;
   const int M = L.M, N = L.N;
   const long Sp = a.Sp;
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
@@ -1315,26 +1382,47 @@ __global__ __launch_bounds__(kThreads) void wgrad_lds_kernel(WgradArgs a) {
   const long s_begin = (long)blockIdx.x * a.chunk;
   const long s_end = s_begin + a.chunk < Send ? s_begin + a.chunk : Send;
   if (s_begin >= Send) return;
-  // this wave's 8 fragments of a stage: (kk, q) = ((wave*8 + i) / 8, (wave*8 + i) % 8) = (wave, i) for kWgK == 4
-  const _Float16* src[8];
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int row = 32 * (q & 3) + r, lim = q < 4 ? M : N;
-    src[q] = (q < 4 ? dZ : X) + (long)(row < lim ? row : 0) * Sp + 16 * wave + 8 * h;   // rows beyond the layer: row 0, masked at the store
+  // 256-sample tiles of this chunk that carry a gradient (dZ != 0: mlp_bwd_kernel's live_tiles), one bit each
+  unsigned long long live_mask = ~0ull;
+  if (a.live_tiles) {
+    const long t = s_begin / kTile + lane;
+    live_mask = __ballot(t * kTile < s_end && a.live_tiles[t] != 0);
   }
-  auto stage = [&](int buf, long s0) {
-    // live list: dZ rows (q < 4) are compact, X rows sit where the forward wrote them -- this wave's k-step is the 16 samples
-    // at compact position s0 + 16 wave, inside ONE segment
-    long x0 = s0;
-    if (a.live_list) {
-      const long sc = s0 + 16 * wave;
-      const int slot = (int)(sc >> 5);
-      x0 = (long)(slot < live_n ? a.live_list[slot] : 0) * 32 + (sc & 31) - 16 * wave;
-    }
+  // stages of dead tiles are stepped over: block-uniform, registers only
+  auto live_from = [&](long s) -> long {
+    if (s >= s_end || (s & (kTile - 1)) != 0) return s;
+    const unsigned long long rest = live_mask >> ((s - s_begin) / kTile);
+    return rest ? s + (long)kTile * __builtin_ctzll(rest) : s_end;
+  };
+  // this wave's pieces: image rows 64 wave + 8 i + (lane >> 3), i = 0..7 -- waves 0, 1 fill the dZ rows, waves 2, 3 the X rows
+  const bool x_rows = wave >= 2;
+  const _Float16* src[kWgLoads];
 #pragma unroll
-    for (int q = 0; q < 8; ++q)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[q] + (q < 4 ? s0 : x0)),
-                                       (__attribute__((address_space(3))) void*)(wsm + buf * kWgStage + (wave * 8 + q) * 1024), 16, 0, 0);
+  for (int i = 0; i < kWgLoads; ++i) {
+    const int row = 64 * (wave & 1) + 8 * i + (lane >> 3), lim = x_rows ? N : M;
+    const int j = (lane & 7) ^ ((row >> 1) & 7);         // the sample group this lane's LDS slot holds
+    src[i] = (x_rows ? L.X : L.dZ) + (long)(row < lim ? row : 0) * Sp + 8 * j;   // rows beyond the layer: row 0, masked at the store
+  }
+  // j >> 2 = ((lane >> 2) & 1) ^ (i & 1): which of the stage's two 32-sample segments the lane reads in pieces of parity i & 1
+  const bool second_even = ((lane >> 2) & 1) != 0;
+  auto stage = [&](int buf, long s0) {
+    // live list: dZ rows are compact, X rows sit where the forward wrote them -- the stage's 64 compact samples are the
+    // segments list[s0 / 32] and list[s0 / 32 + 1]
+    long xa = s0, xb = s0;
+    if (a.live_list && x_rows) {
+      const int slot = (int)(s0 >> 5);
+      int seg0 = 0, seg1 = 0;
+      const int* p = a.live_list + slot;
+      if (slot < live_n) asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(seg0) : "s"(p) : "memory");
+      if (slot + 1 < live_n) asm volatile("s_load_dword %0, %1, 0x4\n\ts_waitcnt lgkmcnt(0)" : "=s"(seg1) : "s"(p) : "memory");
+      xa = (long)seg0 * 32;
+      xb = (long)seg1 * 32 - 32;
+    }
+    const long off_even = second_even ? xb : xa, off_odd = second_even ? xa : xb;
+#pragma unroll
+    for (int i = 0; i < kWgLoads; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + ((i & 1) ? off_odd : off_even)),
+                                       (__attribute__((address_space(3))) void*)(wsm + buf * kWgStage + (wave * kWgLoads + i) * 1024), 16, 0, 0);
   };
   floatx16 acc[2][2];
 #pragma unroll
@@ -1343,34 +1431,44 @@ __global__ __launch_bounds__(kThreads) void wgrad_lds_kernel(WgradArgs a) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-  // stages of dead tiles (dZ == 0: mlp_bwd_kernel's live_tiles) are stepped over: block-uniform
-  auto live_from = [&](long s) -> long {
-    if (a.live_tiles)
-      while (s < s_end && (s & (kTile - 1)) == 0 && !a.live_tiles[s / kTile]) s += kTile;
-    return s;
-  };
-  long s = live_from(s_begin);
-  if (s >= s_end) return;
-  stage(0, s);
-  int buf = 0;
-  while (s < s_end) {
-    rtxn::staged_barrier();                              // this stage landed; everyone is done with the other buffer
-    const long sn = live_from(s + 16 * kWgK);
-    if (sn < s_end) stage(buf ^ 1, sn);
-    const uint8_t* st = wsm + buf * kWgStage + lane * 16;
+  long s_iss = live_from(s_begin);
+  if (s_iss >= s_end) return;
+  int in_flight = 0, ib = 0, cb = 0;                     // stages issued and not yet consumed; ring slots to fill / to read
 #pragma unroll
-    for (int kk = 0; kk < kWgK; ++kk) {
-      const half8 a0 = *reinterpret_cast<const half8*>(st + (kk * 8 + 2 * tm) * 1024);
-      const half8 a1 = *reinterpret_cast<const half8*>(st + (kk * 8 + 2 * tm + 1) * 1024);
-      const half8 b0 = *reinterpret_cast<const half8*>(st + (kk * 8 + 4 + 2 * tn) * 1024);
-      const half8 b1 = *reinterpret_cast<const half8*>(st + (kk * 8 + 4 + 2 * tn + 1) * 1024);
+  for (int d = 0; d < kWgStages - 1; ++d)
+    if (s_iss < s_end) {
+      stage(ib, s_iss);
+      ib = ib + 1 == kWgStages ? 0 : ib + 1;
+      ++in_flight;
+      s_iss = live_from(s_iss + 16 * kWgK);
+    }
+  // fragment (k-step ks, 32-row group q) of lane (h, r): row 32 q + r, 16-byte slot (2 ks + h) ^ ((r >> 1) & 7)
+  int frag_off[kWgK];
+#pragma unroll
+  for (int ks = 0; ks < kWgK; ++ks) frag_off[ks] = r * 128 + 16 * ((2 * ks + h) ^ ((r >> 1) & 7));
+  while (in_flight > 0) {
+    wg_retire_oldest<kWgStages - 2>(in_flight - 1);      // the oldest stage landed; everyone is done with the slot filled next
+    if (s_iss < s_end) {
+      stage(ib, s_iss);
+      ib = ib + 1 == kWgStages ? 0 : ib + 1;
+      s_iss = live_from(s_iss + 16 * kWgK);
+    } else {
+      --in_flight;
+    }
+    const uint8_t* st = wsm + cb * kWgStage;
+#pragma unroll
+    for (int ks = 0; ks < kWgK; ++ks) {
+      const uint8_t* f = st + frag_off[ks];
+      const half8 a0 = *reinterpret_cast<const half8*>(f + (2 * tm) * 4096);
+      const half8 a1 = *reinterpret_cast<const half8*>(f + (2 * tm + 1) * 4096);
+      const half8 b0 = *reinterpret_cast<const half8*>(f + (4 + 2 * tn) * 4096);
+      const half8 b1 = *reinterpret_cast<const half8*>(f + (4 + 2 * tn + 1) * 4096);
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
     }
-    buf ^= 1;
-    s = sn;
+    cb = cb + 1 == kWgStages ? 0 : cb + 1;
   }
   float* __restrict__ dW = L.dW;
 #pragma unroll
@@ -1852,9 +1950,9 @@ static int train_backward_impl(const rtxn_mlp* m, const void* encT, const void* 
   }
   if (wa.lds_path) {
     WgradArgs wl = wa;
-    wl.chunk = 2048;
-    RTXN_HIP(set_lds_once(reinterpret_cast<const void*>(wgrad_lds_kernel), 2 * kWgStage));
-    wgrad_lds_kernel<<<dim3((unsigned)((Sp + wl.chunk - 1) / wl.chunk), (unsigned)(L + 1)), kThreads, 2 * kWgStage, s>>>(wl);
+    wl.chunk = wgrad_chunk(Sp, L + 1, live_list != nullptr);
+    RTXN_HIP(set_lds_once(reinterpret_cast<const void*>(wgrad_lds_kernel), kWgStages * kWgStage));
+    wgrad_lds_kernel<<<dim3((unsigned)((Sp + wl.chunk - 1) / wl.chunk), (unsigned)(L + 1)), kThreads, kWgStages * kWgStage, s>>>(wl);
     RTXN_LAUNCH_CHECK("wgrad_lds_kernel");
   }
   return RTXN_OK;
