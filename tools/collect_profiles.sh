@@ -1,6 +1,7 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence quoted in DESIGN.md / profiles/README.md (run on the GPU box from the repo root):
 #   tools/collect_profiles.sh [outdir] [phases]        default gpurun_out/profiles, phases "bench traces pmc1 pmc2 train finish"
+#   (phase `ref`: the 8x128 reference iteration's counters and trace alone; then `PMC_MERGE=profiles/rNN/pmc_kernels.json ... finish`)
 # (the whole set takes longer than one gpurun call allows: run `... bench traces pmc1` and `... pmc2 train finish` as two calls;
 # `finish` flattens whatever the earlier phases left under <outdir>)
 # Kernel traces/stats and the PMC passes are separate rocprofv3 runs (counters never together with other trace domains; FETCH_SIZE
@@ -40,6 +41,11 @@ if has pmc2; then
 pmc config3 "$repo/tools/pmc_extras.py" config3
 pmc ref8x128 "$repo/tools/pmc_extras.py" ref8x128
 fi
+if has ref; then   # only the 8x128 reference iteration again (after a change to its kernels): counters + kernel trace
+pmc ref8x128 "$repo/tools/pmc_extras.py" ref8x128
+rocprofv3 --kernel-trace --stats --output-format csv -d "$repo/$out/kt_ref8x128" -- python3 "$repo/tools/pmc_extras.py" ref8x128 > "$repo/$out/train_ref8x128.json" 2>/dev/null
+echo "ref8x128 done"
+fi
 if has train; then
 rocprofv3 --kernel-trace --stats --output-format csv -d "$repo/$out/kt_train3" -- python3 "$repo/bench_train.py" --steps 50 > "$repo/$out/train_config3.json" 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d "$repo/$out/kt_train128" -- python3 "$repo/bench_train.py" --steps 50 --encoding freq --neurons 128 --layers 8 --dir-freqs 12 > "$repo/$out/train_8x128_freq.json" 2>/dev/null
@@ -61,7 +67,8 @@ flat "$out/kt_ref8x128/*/*kernel_stats.csv" $out/train_ref8x128_kernel_stats.csv
 flat "$out/pmc_headline_fetch/*/*counter_collection.csv" $out/pmc_fetch_size.csv
 flat "$out/pmc_headline_write/*/*counter_collection.csv" $out/pmc_write_size.csv
 flat "$out/pmc_headline_sq/*/*counter_collection.csv" $out/pmc_sq.csv
-python3 tools/pmc_kernels_json.py $out/pmc_kernels.json "rocprofv3 --pmc, separate passes per counter set (FETCH_SIZE | WRITE_SIZE | SQ group | TCC group) over: bench.py --steps 3 --warmup 1 --no-cpu --no-extras --kernel-steps 2 --serial; tools/pmc_extras.py config5 | config3 | ref8x128" \
+# PMC_MERGE=<earlier pmc_kernels.json>: a partial re-collection (phase `ref`) keeps the earlier entries whose kernels are unchanged
+python3 tools/pmc_kernels_json.py ${PMC_MERGE:+--merge $PMC_MERGE} $out/pmc_kernels.json "${PMC_NOTE:-rocprofv3 --pmc, separate passes per counter set (FETCH_SIZE | WRITE_SIZE | SQ group | TCC group) over: bench.py --steps 3 --warmup 1 --no-cpu --no-extras --kernel-steps 2 --serial; tools/pmc_extras.py config5 | config3 | ref8x128}" \
   $(ls $out/pmc_*/*/*counter_collection.csv) > $out/pmc_kernels_summary.txt
 rm -rf $out/kt_* $out/pmc_*_fetch $out/pmc_*_write $out/pmc_*_sq $out/pmc_*_tcc
 ls -la $out

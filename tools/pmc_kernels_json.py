@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Per-kernel summary of separate rocprofv3 --pmc passes, fingerprinted by the measured kernel's ISA.
-  python tools/pmc_kernels_json.py <out.json> <note> <pass.csv> [<pass.csv> ...]
+  python tools/pmc_kernels_json.py [--merge <earlier.json>] <out.json> <note> <pass.csv> [<pass.csv> ...]
+(--merge: kernels that these passes did not measure are carried over from an earlier summary of the same round, but only while
+the library still holds the code they were measured on -- same isa_sha16 -- and marked `carried_from`; the rest is dropped)
 Every *counter_collection.csv is one pass of the SAME command with its own counter set (counters are never collected together
 with trace domains, and FETCH_SIZE / WRITE_SIZE each get their own pass as MI355X_MICROARCH.md prescribes).  For each kernel
 of interest (KERNELS below: name pattern -> mangled-name substrings for the ISA hash) the output holds the mean of every
@@ -38,7 +40,12 @@ KERNELS = {
 
 
 def main():
-    out, note, files = sys.argv[1], sys.argv[2], sys.argv[3:]
+    argv = sys.argv[1:]
+    earlier = None
+    if argv and argv[0] == "--merge":
+        earlier = json.load(open(argv[1]))
+        argv = argv[2:]
+    out, note, files = argv[0], argv[1], argv[2:]
     acc = {k: defaultdict(list) for k in KERNELS}
     dur = {k: [] for k in KERNELS}
     names = {}
@@ -71,6 +78,15 @@ def main():
         if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c and c["TCC_HIT_sum"] + c["TCC_MISS_sum"] > 0:
             d["l2_hit_rate"] = round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4)
         res["kernels"][key] = d
+    if earlier:
+        merged = {}
+        for key in KERNELS:                            # keep the table's order
+            if key in res["kernels"]:
+                merged[key] = res["kernels"][key]
+            elif key in earlier["kernels"] and earlier["kernels"][key]["isa_sha16"] == kernel_isa_sha16(KERNELS[key][1]):
+                merged[key] = dict(earlier["kernels"][key])
+                merged[key].setdefault("carried_from", earlier["source"])
+        res["kernels"] = merged
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps({k: {x: v[x] for x in v if x in ("isa_sha16", "kernel_ms_under_counters", "hbm_bytes_per_launch_low", "l2_hit_rate", "mfma_busy_frac", "launches_per_pass")}
                       for k, v in res["kernels"].items()}, indent=1))
