@@ -740,3 +740,44 @@ def test_live_segments_with_a_saturated_output_leave_no_stale_gradient(gpu, reco
     assert np.isnan(d[:, 16:].astype(np.float32)).all()       # not listed: never touched (and never read)
     assert torch.isfinite(dp).all() and torch.isfinite(dt).all() and torch.isfinite(dh.float()).all()
     assert float(dt.abs().max()) > 0
+
+
+@pytest.mark.parametrize("S", [2_000_000, 3_800_000])
+def test_weight_gradient_is_additive_over_the_batch_at_full_size(gpu, S):
+    """The reference iteration's batch sizes (millions of samples: the weight-gradient kernel then takes 4096 / 8192 samples per
+    block and walks 16 / 32 tiles by its live-tile mask) are out of the oracle's reach, so the check is the size-independent
+    property: dW of the whole batch == the sum of dW over seven unequal slices of it, each run as its own small batch (the
+    2048-samples-per-block path that the oracle tests and tools/fuzz_train.py cover).  A band of the batch has a zero loss
+    gradient (dead tiles in the middle of blocks).  Tolerance: fp32 summation order only (atomics; fp16 values are identical)."""
+    torch = gpu
+    from rtx_nerf_amd import api
+    W, L, E = 128, 8, 112
+    net = api.Network(n_neurons=W, n_hidden_layers=L)
+    net.set_params(_dev(torch, scenes.xavier_params_fp16(W, L, E, seed=9)))
+    g = torch.Generator(device="cuda").manual_seed(S)
+    enc = (torch.rand((E, S), device="cuda", generator=g) * 2 - 1).half()
+    dout = ((torch.rand((S, 4), device="cuda", generator=g) - 0.5) * 0.02).half()
+    dout[S // 3: S // 3 + 300_001] = 0
+    n_params = E * W + (L - 1) * W * W + 16 * W
+
+    def grads(a, b, dparams):
+        n = b - a
+        Sp = api.padded_samples(n)
+        encT = torch.zeros((E, Sp), dtype=torch.float16, device="cuda")
+        encT[:, :n] = enc[:, a:b]
+        ws = net.train_workspace(n)
+        out = net.train_forward(encT, n, ws)
+        net.train_backward(encT, out, dout[a:b].contiguous(), n, ws, dparams)
+        torch.cuda.synchronize()
+
+    whole = torch.zeros(n_params, dtype=torch.float32, device="cuda")
+    grads(0, S, whole)
+    cuts = [0, 1, 70_001, S // 5, S // 3 + 77, S // 2, S - 300, S]
+    parts = torch.zeros(n_params, dtype=torch.float32, device="cuda")
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        grads(a, b, parts)
+    scale = whole.abs().max().item()
+    assert scale > 0 and torch.isfinite(whole).all()
+    err = (whole - parts).abs().max().item()
+    print(f"additivity: max |whole - parts| = {err:.3e}, largest entry {scale:.3e}")
+    assert err <= 2e-5 * scale, (err, scale)        # measured: 1e-6
