@@ -10,6 +10,7 @@
 // then ldr->hdr  out = (float)pow(v/255.0f, 2.2f)  (stb_image.h v2.28 stbi__ldr_to_hdr).
 // Host-only code; no GPU involvement.
 #include <dirent.h>
+#include <sys/stat.h>
 #include <zlib.h>
 
 #include <cmath>
@@ -140,16 +141,22 @@ struct JParser {
   }
 };
 
+// Regular files only, and of a size a frame or a pose table can have: fopen() also opens a directory (a corrupted
+// file_path can name one), for which ftell() reports LONG_MAX.
+constexpr off_t kMaxFileBytes = (off_t)1 << 30;
 bool read_file(const std::string& path, std::vector<unsigned char>& out) {
   FILE* f = fopen(path.c_str(), "rb");
   if (!f) return false;
-  fseek(f, 0, SEEK_END);
-  long n = ftell(f);
-  fseek(f, 0, SEEK_SET);
-  out.resize(n > 0 ? (size_t)n : 0);
-  size_t got = n > 0 ? fread(out.data(), 1, (size_t)n, f) : 0;
+  struct stat st;
+  if (fstat(fileno(f), &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 0 || st.st_size > kMaxFileBytes) {
+    fclose(f);
+    return false;
+  }
+  const size_t n = (size_t)st.st_size;
+  out.resize(n);
+  const size_t got = n ? fread(out.data(), 1, n, f) : 0;
   fclose(f);
-  return got == out.size();
+  return got == n;
 }
 
 // ------------------------------------------------------------------------- PNG
@@ -161,60 +168,142 @@ inline int paeth(int a, int b, int c) {
   return pb <= pc ? b : c;
 }
 
-// Decodes to 8 bits per channel, `channels` in {1,2,3,4} (palette expanded to RGB or RGBA).
+// The zlib stream of the IDAT chunks, inflated the way stb_image's own inflater treats it: the two header bytes are checked
+// (multiple of 31, method 8, no preset dictionary), the deflate blocks are decoded to the end of the final block, and the
+// Adler-32 that follows is NOT read -- a file with a damaged checksum loads in the reference, so it loads here.  Output beyond
+// `keep` bytes is produced (an error late in the stream still rejects the file) but not stored; `total` is its full length.
+bool inflate_like_stb(const std::vector<unsigned char>& z, bool zlib_header, size_t keep, std::vector<unsigned char>& out, size_t& total,
+                      std::string& err) {
+  size_t off = 0;
+  if (zlib_header) {
+    if (z.size() < 2) { err = "bad zlib header"; return false; }
+    const int cmf = z[0], flg = z[1];
+    if ((cmf * 256 + flg) % 31 != 0) { err = "bad zlib header"; return false; }
+    if (flg & 32) { err = "preset dictionary"; return false; }
+    if ((cmf & 15) != 8) { err = "bad compression"; return false; }
+    off = 2;
+  }
+  z_stream zs;
+  memset(&zs, 0, sizeof(zs));
+  if (inflateInit2(&zs, -15) != Z_OK) { err = "inflate init"; return false; }
+  out.assign(keep, 0);
+  unsigned char spill[16384];
+  zs.next_in = const_cast<unsigned char*>(z.data()) + off;
+  size_t in_left = z.size() - off;
+  total = 0;
+  int rc = Z_OK;
+  while (rc != Z_STREAM_END) {
+    if (zs.avail_in == 0 && in_left) {
+      zs.avail_in = (uInt)std::min<size_t>(in_left, 1u << 30);
+      in_left -= zs.avail_in;
+    }
+    const bool stored = total < keep;
+    const size_t room = stored ? std::min<size_t>(keep - total, 1u << 30) : sizeof(spill);
+    zs.next_out = stored ? out.data() + total : spill;
+    zs.avail_out = (uInt)room;
+    rc = inflate(&zs, Z_NO_FLUSH);
+    total += room - zs.avail_out;
+    if (rc == Z_STREAM_END) break;
+    if (rc != Z_OK || (zs.avail_in == 0 && in_left == 0 && zs.avail_out != 0)) {   // corrupt, or the data ends inside a block
+      inflateEnd(&zs);
+      err = "inflate failed";
+      return false;
+    }
+  }
+  inflateEnd(&zs);
+  return true;
+}
+
+// Decodes to 8 bits per channel, `channels` in {1,2,3,4} (palette expanded to RGB or RGBA; a tRNS colour key becomes an alpha
+// channel).  WHICH files load and which do not follows the reference's decoder, stb_image.h v2.28 (stbi__parse_png_file and
+// stbi__create_png_image_raw, restated): the first chunk must be IHDR (after an optional CgBI), one IHDR only, PLTE at most
+// 256 whole entries, tRNS before the first IDAT / not longer than the palette / exactly one 16-bit value per colour channel /
+// never with an alpha colour type, unknown critical chunks refuse the file and ancillary ones are skipped, chunk CRCs and the
+// zlib checksum are not verified, scanline data may be longer than the image needs but not shorter, and bit depths below 8
+// are unpacked for any colour type (scaled to 0..255 for grey only) -- tests/golden/loader_stb_fuzz.npz holds what the
+// reference's header returned for a few hundred random files of every such kind.
 bool decode_png(const std::vector<unsigned char>& file, int& width, int& height, int& channels,
                 std::vector<unsigned char>& pixels, std::string& err) {
   static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
   if (file.size() < 8 || memcmp(file.data(), sig, 8)) { err = "not a PNG"; return false; }
   size_t pos = 8;
-  int depth = 0, ctype = -1, interlace = 0;
-  std::vector<unsigned char> idat, plte, trns;
-  bool have_ihdr = false, done = false;
-  while (!done && pos + 12 <= file.size()) {
-    uint32_t len = be32(&file[pos]);
+  int depth = 0, ctype = -1, interlace = 0, src_ch = 0;
+  std::vector<unsigned char> idat, trns;
+  unsigned char plte[256 * 3] = {0};
+  size_t pal_len = 0;
+  bool first = true, done = false, iphone = false, idat_seen = false, pal_alpha = false, has_key = false;
+  unsigned key[3] = {0, 0, 0};
+  while (!done) {
+    // a chunk header past the end of the file reads as zeros in the reference: length 0, type 0 = an unknown critical chunk
+    if (pos + 8 > file.size()) { err = "truncated file"; return false; }
+    const uint32_t len = be32(&file[pos]);
     const unsigned char* type = &file[pos + 4];
-    if (pos + 12 + (size_t)len > file.size()) { err = "truncated chunk"; return false; }
-    const unsigned char* data = &file[pos + 8];
-    if (!memcmp(type, "IHDR", 4)) {
-      if (len != 13) { err = "bad IHDR"; return false; }
-      width = (int)be32(data); height = (int)be32(data + 4);
-      depth = data[8]; ctype = data[9]; interlace = data[12];
-      have_ihdr = true;
-    } else if (!memcmp(type, "PLTE", 4)) {
-      plte.assign(data, data + len);
-    } else if (!memcmp(type, "tRNS", 4)) {
-      trns.assign(data, data + len);
-    } else if (!memcmp(type, "IDAT", 4)) {
-      idat.insert(idat.end(), data, data + len);
-    } else if (!memcmp(type, "IEND", 4)) {
+    const size_t body = pos + 8;
+    const auto is = [&](const char* t) { return !memcmp(type, t, 4); };
+    if (is("IEND")) {                                       // its length and CRC are not looked at
+      if (first) { err = "first chunk is not IHDR"; return false; }
       done = true;
+      break;
     }
-    pos += 12 + (size_t)len;
+    if (body + (size_t)len > file.size()) { err = "truncated chunk"; return false; }
+    const unsigned char* data = file.data() + body;
+    if (is("CgBI")) {
+      iphone = true;                                        // Apple's variant: a bare deflate stream (channel order is left alone)
+    } else if (is("IHDR")) {
+      if (!first) { err = "multiple IHDR"; return false; }
+      if (len != 13) { err = "bad IHDR"; return false; }
+      const uint32_t w = be32(data), h = be32(data + 4);
+      // stb_image refuses sides beyond STBI_MAX_DIMENSIONS = 2^24 and images whose samples exceed 2^30
+      if (w > (1u << 24) || h > (1u << 24)) { err = "image too large"; return false; }
+      depth = data[8]; ctype = data[9]; interlace = data[12];
+      if (depth != 1 && depth != 2 && depth != 4 && depth != 8 && depth != 16) { err = "unsupported bit depth"; return false; }
+      if (ctype > 6 || (ctype == 3 && depth == 16) || (ctype != 3 && (ctype & 1))) { err = "bad colour type"; return false; }
+      if (data[10] != 0) { err = "bad compression method"; return false; }
+      if (data[11] != 0) { err = "bad filter method"; return false; }
+      if (interlace > 1) { err = "bad interlace method"; return false; }
+      if (w == 0 || h == 0) { err = "0-pixel image"; return false; }
+      src_ch = ctype == 3 ? 1 : ((ctype & 2) ? 3 : 1) + ((ctype & 4) ? 1 : 0);
+      if ((1u << 30) / w / (uint32_t)(ctype == 3 ? 4 : src_ch) < h) { err = "image too large"; return false; }
+      width = (int)w; height = (int)h;
+    } else if (first) {
+      err = "first chunk is not IHDR";
+      return false;
+    } else if (is("PLTE")) {
+      if (len > 256 * 3 || len % 3) { err = "invalid PLTE"; return false; }
+      pal_len = len / 3;
+      memcpy(plte, data, len);
+    } else if (is("tRNS")) {
+      if (idat_seen) { err = "tRNS after IDAT"; return false; }
+      if (ctype == 3) {
+        if (pal_len == 0) { err = "tRNS before PLTE"; return false; }
+        if (len > pal_len) { err = "bad tRNS length"; return false; }
+        pal_alpha = true;
+        trns.assign(data, data + len);
+      } else {
+        if (!(src_ch & 1)) { err = "tRNS with alpha"; return false; }
+        if (len != (uint32_t)src_ch * 2) { err = "bad tRNS length"; return false; }
+        has_key = true;
+        for (int k = 0; k < src_ch; ++k) {
+          const unsigned v = ((unsigned)data[2 * k] << 8) | data[2 * k + 1];
+          // 16-bit images compare all 16 bits; the others the low byte, scaled by 255 / (2^depth - 1) and kept to 8 bits as stb does
+          key[k] = depth == 16 ? v : ((v & 255) * (255u / ((1u << depth) - 1))) & 255u;
+        }
+      }
+    } else if (is("IDAT")) {
+      if (ctype == 3 && pal_len == 0) { err = "no PLTE"; return false; }
+      if (len > (1u << 30) || idat.size() + (size_t)len > ((size_t)1 << 31)) { err = "IDAT too large"; return false; }
+      idat.insert(idat.end(), data, data + len);
+      if (len) idat_seen = true;
+    } else if (!(type[0] & 0x20)) {                         // an unknown CRITICAL chunk (upper-case first letter)
+      err = "unknown critical chunk";
+      return false;
+    }
+    first = false;
+    pos = body + (size_t)len + 4;                           // the CRC is skipped, not checked
   }
-  if (!have_ihdr || width <= 0 || height <= 0) { err = "missing IHDR"; return false; }
-  if (interlace > 1) { err = "bad interlace method"; return false; }
-  int src_ch;
-  switch (ctype) {
-    case 0: src_ch = 1; break;
-    case 2: src_ch = 3; break;
-    case 3: src_ch = 1; break;
-    case 4: src_ch = 2; break;
-    case 6: src_ch = 4; break;
-    default: err = "bad colour type"; return false;
-  }
-  if (!(depth == 8 || depth == 16 || ((ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4)))) {
-    err = "unsupported bit depth";
-    return false;
-  }
-  // Size guard BEFORE any allocation: IHDR is attacker-controlled (up to 2^31 each way).  stb_image refuses images
-  // beyond STBI_MAX_DIMENSIONS = 2^24 per side; the pixel cap below additionally bounds the float image this loader
-  // builds (1 Gpixel = 12 GB of float RGB).
-  if (width > (1 << 24) || height > (1 << 24) || (uint64_t)width * (uint64_t)height > (1ull << 30)) {
-    err = "image too large";
-    return false;
-  }
+  if (!idat_seen) { err = "no IDAT"; return false; }
   const size_t bpp_bits = (size_t)src_ch * depth;
-  const size_t fbpp = bpp_bits >= 8 ? bpp_bits / 8 : 1;  // filter byte distance
+  const size_t fbpp = depth < 8 ? 1 : bpp_bits / 8;         // filter byte distance
   // Adam7 (interlace method 1): seven reduced images, each filtered as an image of its own and scattered to
   // (x0 + i*dx, y0 + j*dy) -- stb_image.h's stbi__create_png_image does the same
   static const int kX0[7] = {0, 4, 0, 2, 0, 1, 0}, kY0[7] = {0, 0, 4, 0, 2, 0, 1};
@@ -226,13 +315,14 @@ bool decode_png(const std::vector<unsigned char>& file, int& width, int& height,
     const int ph = interlace ? (height - kY0[ps] + kDy[ps] - 1) / kDy[ps] : height;
     if (pw > 0 && ph > 0) raw_size += (((size_t)pw * bpp_bits + 7) / 8 + 1) * (size_t)ph;
   }
-  std::vector<unsigned char> raw(raw_size);
-  uLongf raw_len = (uLongf)raw.size();
-  int zr = uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size());
-  if (zr != Z_OK || raw_len != raw.size()) { err = "inflate failed"; return false; }
+  std::vector<unsigned char> raw;
+  size_t raw_total = 0;
+  if (!inflate_like_stb(idat, !iphone, raw_size, raw, raw_total, err)) return false;
+  if (raw_total < raw_size) { err = "not enough pixels"; return false; }
   const size_t npx = (size_t)width * height;
-  std::vector<unsigned char> s8(npx * src_ch);   // 8-bit samples of the whole image
-  const int maxv = (1 << depth) - 1;
+  std::vector<unsigned char> s8(npx * src_ch), lo8;          // 8-bit samples of the whole image (16-bit: high bytes; low bytes beside
+  if (depth == 16 && has_key) lo8.resize(npx * src_ch);      // them where a colour key has to be compared)
+  const unsigned maxv = (1u << depth) - 1;
   size_t raw_pos = 0;
   std::vector<unsigned char> img;
   for (int ps = 0; ps < n_pass; ++ps) {
@@ -240,6 +330,9 @@ bool decode_png(const std::vector<unsigned char>& file, int& width, int& height,
     const int pw = (width - x0 + dx - 1) / dx, ph = (height - y0 + dy - 1) / dy;
     if (pw <= 0 || ph <= 0) continue;
     const size_t stride = ((size_t)pw * bpp_bits + 7) / 8;
+    // below 8 bits the reference unpacks a row in place inside a buffer of one byte per sample position and refuses rows that
+    // would not fit: more than 8 bits per pixel (RGB / RGBA at depth 4) never load
+    if (depth < 8 && stride > (size_t)pw) { err = "invalid width"; return false; }
     img.assign(stride * (size_t)ph, 0);
     for (int y = 0; y < ph; ++y) {
       const unsigned char* in = &raw[raw_pos + (stride + 1) * (size_t)y];
@@ -247,6 +340,7 @@ bool decode_png(const std::vector<unsigned char>& file, int& width, int& height,
       ++in;
       unsigned char* out = &img[stride * (size_t)y];
       const unsigned char* up = y ? out - stride : nullptr;
+      if (ft > 4) { err = "bad filter"; return false; }
       for (size_t x = 0; x < stride; ++x) {
         const int a = x >= fbpp ? out[x - fbpp] : 0, b = up ? up[x] : 0, c = (up && x >= fbpp) ? up[x - fbpp] : 0;
         int v = in[x];
@@ -255,8 +349,7 @@ bool decode_png(const std::vector<unsigned char>& file, int& width, int& height,
           case 1: v += a; break;
           case 2: v += b; break;
           case 3: v += (a + b) >> 1; break;
-          case 4: v += paeth(a, b, c); break;
-          default: err = "bad filter"; return false;
+          default: v += paeth(a, b, c); break;
         }
         out[x] = (unsigned char)v;
       }
@@ -266,26 +359,44 @@ bool decode_png(const std::vector<unsigned char>& file, int& width, int& height,
     for (int y = 0; y < ph; ++y) {
       const unsigned char* row = &img[stride * (size_t)y];
       for (int x = 0; x < pw; ++x) {
-        unsigned char* dst = &s8[((size_t)(y0 + y * dy) * width + (size_t)(x0 + x * dx)) * src_ch];
+        const size_t at = ((size_t)(y0 + y * dy) * width + (size_t)(x0 + x * dx)) * src_ch;
+        unsigned char* dst = &s8[at];
         if (depth == 8) {
           for (int k = 0; k < src_ch; ++k) dst[k] = row[(size_t)x * src_ch + k];
         } else if (depth == 16) {
-          for (int k = 0; k < src_ch; ++k) dst[k] = row[2 * ((size_t)x * src_ch + k)];   // stb: the high byte
+          for (int k = 0; k < src_ch; ++k) {
+            dst[k] = row[2 * ((size_t)x * src_ch + k)];     // stb: the high byte
+            if (!lo8.empty()) lo8[at + k] = row[2 * ((size_t)x * src_ch + k) + 1];
+          }
         } else {
-          const size_t bit = (size_t)x * depth;
-          const int v = (row[bit / 8] >> (8 - depth - (bit % 8))) & maxv;
-          dst[0] = (unsigned char)(ctype == 3 ? v : v * 255 / maxv);
+          for (int k = 0; k < src_ch; ++k) {                // samples follow one another bit by bit, whatever the colour type
+            const size_t bit = ((size_t)x * src_ch + k) * depth;
+            const unsigned v = (row[bit / 8] >> (8 - depth - (bit % 8))) & maxv;
+            dst[k] = (unsigned char)(ctype == 0 ? v * 255 / maxv : v);
+          }
         }
       }
     }
   }
   if (ctype == 3) {
-    channels = trns.empty() ? 3 : 4;
+    channels = pal_alpha ? 4 : 3;
     pixels.resize(npx * channels);
     for (size_t i = 0; i < npx; ++i) {
-      const size_t idx = s8[i];
-      for (int k = 0; k < 3; ++k) pixels[i * channels + k] = idx * 3 + k < plte.size() ? plte[idx * 3 + k] : 0;
+      const size_t idx = s8[i];                             // an index beyond the palette: black, opaque (the reference reads
+      for (int k = 0; k < 3; ++k) pixels[i * channels + k] = idx < pal_len ? plte[idx * 3 + k] : 0;   // uninitialised memory)
       if (channels == 4) pixels[i * 4 + 3] = idx < trns.size() ? trns[idx] : 255;
+    }
+  } else if (has_key) {
+    channels = src_ch + 1;
+    pixels.resize(npx * channels);
+    for (size_t i = 0; i < npx; ++i) {
+      bool match = true;
+      for (int k = 0; k < src_ch; ++k) {
+        const unsigned v = depth == 16 ? ((unsigned)s8[i * src_ch + k] << 8) | lo8[i * src_ch + k] : s8[i * src_ch + k];
+        match = match && v == key[k];
+        pixels[i * channels + k] = s8[i * src_ch + k];
+      }
+      pixels[i * channels + src_ch] = match ? 0 : 255;
     }
   } else {
     channels = src_ch;
@@ -311,6 +422,12 @@ void to_float_rgb(const std::vector<unsigned char>& px, int channels, size_t npx
       out[i * 3 + k] = v;
     }
   }
+}
+
+bool all_finite(const std::vector<float>& v) {
+  for (float x : v)
+    if (!std::isfinite(x)) return false;
+  return true;
 }
 
 }  // namespace
@@ -390,6 +507,11 @@ static int load_images_json_impl(const char* basename, const char* split, int fl
     }
     to_float_rgb(px, ch, (size_t)W * H, flags, &images[i * (size_t)W * H * 3]);
   }
+  // a pose or field of view that is not a number (a JSON reader accepts "nan" / "1e999") would only surface as garbage rays
+  if (!all_finite(poses) || !std::isfinite(camera_angle_x)) {
+    rtxn::set_error("%s: camera_angle_x or a transform_matrix entry is not finite", json_path.c_str());
+    return RTXN_ERR_IO;
+  }
   out->n_images = (int)n;
   out->image_width = (unsigned)W;
   out->image_height = (unsigned)H;
@@ -419,7 +541,7 @@ static int load_images_json_impl(const char* basename, const char* split, int fl
 // as the synthetic loader: row-major 4x4 camera-to-world, axes (right, up, backwards).
 namespace {
 
-bool parse_npy_f64_2d(const std::vector<unsigned char>& f, size_t& rows, size_t& cols, const double*& data, std::string& err) {
+bool parse_npy_f64_2d(const std::vector<unsigned char>& f, size_t& rows, size_t& cols, std::vector<double>& data, std::string& err) {
   if (f.size() < 10 || memcmp(f.data(), "\x93NUMPY", 6)) { err = "not an .npy file"; return false; }
   const int major = f[6];
   size_t hlen, hoff;
@@ -439,7 +561,10 @@ bool parse_npy_f64_2d(const std::vector<unsigned char>& f, size_t& rows, size_t&
   if (sscanf(hdr.c_str() + lp, "(%llu, %llu", &r, &c) != 2) { err = ".npy array is not 2-D"; return false; }
   if (r > (1ull << 24) || c > 4096 || (hoff + hlen + r * c * 8ull) > f.size()) { err = ".npy data shorter than its shape"; return false; }
   rows = (size_t)r; cols = (size_t)c;
-  data = reinterpret_cast<const double*>(f.data() + hoff + hlen);   // header length keeps the data 16/64-byte aligned
+  // copied out: numpy pads the header so that the data is 64-byte aligned, but nothing obliges a file to (a double read
+  // through a pointer into the byte buffer was a misaligned load then -- found by the UBSan run of tools/san/loader_fuzz.cpp)
+  data.resize(rows * cols);
+  if (!data.empty()) memcpy(data.data(), f.data() + hoff + hlen, data.size() * sizeof(double));
   return true;
 }
 
@@ -451,9 +576,11 @@ int load_llff_impl(const char* basedir, int factor, int flags, rtxn_image_datase
     return RTXN_ERR_IO;
   }
   size_t n = 0, cols = 0;
-  const double* pb = nullptr;
+  std::vector<double> pbv;
   std::string err;
-  if (!parse_npy_f64_2d(npy, n, cols, pb, err) || cols != 17) {
+  const bool parsed = parse_npy_f64_2d(npy, n, cols, pbv, err);
+  const double* pb = pbv.data();
+  if (!parsed || cols != 17) {
     rtxn::set_error("%s/poses_bounds.npy: %s", basedir, err.empty() ? "expected float64[N][17]" : err.c_str());
     return RTXN_ERR_IO;
   }
@@ -506,6 +633,10 @@ int load_llff_impl(const char* basedir, int factor, int flags, rtxn_image_datase
     to_float_rgb(px, ch, (size_t)W * H, flags, &images[i * (size_t)W * H * 3]);
   }
   const double f_full = n ? pb[14] : 0.0, w_full = n ? pb[9] : 0.0;   // hwf column of the first pose: H = [4], W = [9], focal = [14]
+  if (!all_finite(poses) || !all_finite(bounds) || !std::isfinite(f_full) || !std::isfinite(w_full)) {
+    rtxn::set_error("%s/poses_bounds.npy: an entry is not finite", basedir);
+    return RTXN_ERR_IO;
+  }
   out->n_images = (int)n;
   out->image_width = (unsigned)W;
   out->image_height = (unsigned)H;

