@@ -454,23 +454,25 @@ __device__ __forceinline__ const _Float16* row_elem(const _Float16* X, int f0, l
   return reinterpret_cast<const _Float16*>(reinterpret_cast<const char*>(X + (long)f0 * Sp) + lane_off);
 }
 
-// The eight halves of one B fragment (k-step kk of a lane's sample: features perm_feature(kk, 0, 0..7), +4h folded into
-// lane_off) to their rows of a feature-major tensor, each as ONE instruction: the half leaves its register as it stands
-// (global_store_short / _d16_hi) for saddr = the row (scalar ALU) + voffset = lane_off.  Written as asm because hipcc does not
-// get there by itself: it re-associates the address into (X + lane_off) + row, a 64-bit per-lane base, and pays a 64-bit
-// VALU add (v_lshl_add_u64) per store plus shifts for the odd halves -- 2-3 VALU instructions per stored element in the
-// kernels that materialise 128 elements per sample and layer.  Two-byte data: no VMEM data-hazard wait states apply.
-__device__ __forceinline__ void store_fragment_rows(_Float16* X, int kk, long Sp, unsigned lane_off, const half8& v) {
-  const rtxn::int4v w = __builtin_bit_cast(rtxn::int4v, v);
-  // rows 16 kk + {0, 1, 2, 3, 8, 9, 10, 11}: a running scalar pointer, two scalar adds per store (left to itself hipcc forms
-  // every row's product with Sp ahead of the layer loop and spills scalar registers to hold them)
+// One B fragment (k-step kk: features perm_feature(kk, 0, 0..7), +4h folded into lane_off) of BOTH of a lane's samples to the
+// rows of a feature-major tensor.  In mlp_bwd_kernel lane `col` of a wave owns the neighbouring samples 2 col and 2 col + 1 of
+// the wave's 64 (column tile ct = the parity), so its two values of a feature are one aligned dword, the 32 lanes of a
+// lane-half cover a whole 128-byte line, and a layer is 128 store instructions per wave instead of 256 (a wave holds at most 63
+// outstanding memory instructions; tools/probe/store_shapes.hip, profiles/r03/train_store_paths.txt items 10-11).  The saving
+// forward keeps its halves-of-the-tile ownership and two-byte stores: the same change left its time where it was.
+// Each store is ONE instruction, written as asm: saddr = the row (a running scalar pointer, two scalar adds per store) +
+// voffset = lane_off.  Left to itself hipcc re-associates the address into (X + lane_off) + row, a 64-bit per-lane base, pays a
+// 64-bit VALU add per store, and forms every row's product with Sp ahead of the layer loop, spilling scalar registers to hold them.
+__device__ __forceinline__ void store_fragment_rows_pair(_Float16* X, int kk, long Sp, unsigned lane_off, const half8& even, const half8& odd) {
+  const rtxn::int4v w0 = __builtin_bit_cast(rtxn::int4v, even), w1 = __builtin_bit_cast(rtxn::int4v, odd);
   const char* row = reinterpret_cast<const char*>(X + 16L * kk * Sp);
   const long step = 2 * Sp;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
+    // v_perm_b32: bytes 0-3 index the second operand, 4-7 the first: (even.lo | odd.lo << 16) or (even.hi | odd.hi << 16)
+    const unsigned d = __builtin_amdgcn_perm((unsigned)w1[j >> 1], (unsigned)w0[j >> 1], (j & 1) ? 0x07060302u : 0x05040100u);
     asm volatile("" : "+s"(row));
-    if (j & 1) asm volatile("global_store_short_d16_hi %0, %1, %2" ::"v"(lane_off), "v"(w[j >> 1]), "s"(row) : "memory");
-    else asm volatile("global_store_short %0, %1, %2" ::"v"(lane_off), "v"(w[j >> 1]), "s"(row) : "memory");
+    asm volatile("global_store_dword %0, %1, %2" ::"v"(lane_off), "v"(d), "s"(row) : "memory");
     row += j == 3 ? 5 * step : step;
   }
 }
@@ -546,7 +548,8 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_train_fwd_kernel(TrainArgs a)
   }
   // (the stores stay the compiler's: k-step outer, column tile inner, so the two 64-byte halves of a row's 128-byte line leave
   // the wave close together -- column-tile outer cost 0.5 ms per 4.7 M samples -- and in this kernel neither dropping the
-  // per-store select nor store_fragment_rows' one-instruction stores changed the time: profiles/r03/train_store_paths.txt)
+  // per-store select, nor one-instruction stores, nor store_fragment_rows_pair's 4-byte form changed the time:
+  // profiles/r03/train_store_paths.txt)
   auto save_acts = [&](int l, const half8 (&v)[KS][2]) {
     if constexpr (!SAVE) return;
     _Float16* dst = a.acts + (long)l * W * a.Sp;
@@ -657,19 +660,23 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_bwd_kernel(TrainArgs a) {
   const int L = a.n_hidden;
   long off = 0;
   // lane_off: where the lane's sample sits in the tensors the forward wrote (encT, acts, masks; d(encoding) goes there too);
-  // lane_dst: where its dZ goes -- the same place, or with the live list the compact position slot * 32 + col
+  // lane_dst: where its dZ goes -- the same place, or with the live list the compact position (slot * 32 + sample)
   unsigned lane_off[2], lane_dst[2];   // see row_elem
   long samp[2];
   bool ok_s[2];
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct) {
-    long sidx = tile0 + ct * 32 + col;
+    // lane col has the NEIGHBOURING samples 2 col and 2 col + 1 of the wave's 64 (column tile = parity; an MFMA column is a
+    // sample either way, and nothing ties this kernel's ownership to the forward's): see store_fragment_rows_pair.  With the
+    // live list the 64 samples are two listed segments: lanes 0-15 of a lane-half hold the first, 16-31 the second
+    const int q = 2 * col + ct;
+    long sidx = tile0 + q;
     ok_s[ct] = sidx < a.S;
     lane_dst[ct] = (unsigned)((sidx + 4L * h * a.Sp) * 2);
     if (a.live_list) {
-      const int slot = (int)blockIdx.x * 8 + wave * 2 + ct;
+      const int slot = (int)blockIdx.x * 8 + wave * 2 + (q >> 5);
       ok_s[ct] = slot < live_n;
-      sidx = (long)(ok_s[ct] ? a.live_list[slot] : 0) * 32 + col;      // slots past the list read segment 0 and add zeros
+      sidx = (long)(ok_s[ct] ? a.live_list[slot] : 0) * 32 + (q & 31);      // slots past the list read segment 0 and add zeros
     }
     samp[ct] = sidx;
     lane_off[ct] = (unsigned)((sidx + 4L * h * a.Sp) * 2);
@@ -722,10 +729,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_bwd_kernel(TrainArgs a) {
       return;
     }
   }
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) *row_elem(a.dzL, perm_feature(0, 0, j), a.Sp, lane_dst[ct]) = bo[ct][j];
+  store_fragment_rows_pair(a.dzL, 0, a.Sp, lane_dst[0], bo[0], bo[1]);
   // One accumulator pair at a time: row tile rt of dA_{l} = W^T dZ is masked with relu'(act_l), rounded to fp16 and packed
   // straight into the B fragments of the next (earlier) layer's MFMAs -- the backward chain stays in registers exactly as the
   // forward does, and no full-layer fp32 dA is ever held (the first version kept one: 128 VGPRs at W = 128, 378 spills).
@@ -736,7 +740,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_bwd_kernel(TrainArgs a) {
   // activation loads that shared them were gone; with the row stride laundered through an empty asm per call
   // (mask_pack_store) they are formed where they are used: 168 VGPRs, no scratch, and the kernel no longer reads 2 KB of
   // activations per sample.  At W = 64 the masks were worth 5 % of the step.  The dZ stores themselves are
-  // store_fragment_rows' one-instruction form: 2.6 -> 2.25 ms per 4.7 M samples at W = 128.)
+  // store_fragment_rows_pair's one-instruction, two-samples-per-lane form: 2.6 -> 2.25 -> 1.85 ms per 4.7 M samples at W = 128.)
   unsigned mk[2][2] = {{0, 0}, {0, 0}};   // low / high word of the lane's mask (row tiles 0-1 / 2-3)
   auto load_masks = [&](int l) {
 #pragma unroll
@@ -757,12 +761,10 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_bwd_kernel(TrainArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) m[e] = (bits >> e) & 1u ? acc[ct][e] : 0.0f;
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const half8 v = pack8<false>(m, s2);
-        dst[2 * rt + s2][ct] = v;
-        store_fragment_rows(dzl, 2 * rt + s2, Sp_l, lane_dst[ct], v);
-      }
+      for (int s2 = 0; s2 < 2; ++s2) dst[2 * rt + s2][ct] = pack8<false>(m, s2);
     }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) store_fragment_rows_pair(dzl, 2 * rt + s2, Sp_l, lane_dst[0], dst[2 * rt + s2][0], dst[2 * rt + s2][1]);
   };
 
   half8 bz[KS][2], bn[KS][2];

@@ -250,6 +250,7 @@ def test_train_step_entry_matches_the_eager_step(gpu, encoding, mode, neurons, l
     from rtx_nerf_amd.train import camera_rays
     a = _small_trainer(torch, encoding, mode, neurons, layers)
     b = _small_trainer(torch, encoding, mode, neurons, layers)
+    a_table0 = a.table_master.cpu().numpy().copy() if encoding == "hash" else None
     B = 900
     focal = scenes.lego_focal_length(True)
     rng = np.random.default_rng(5)
@@ -290,8 +291,14 @@ def test_train_step_entry_matches_the_eager_step(gpu, encoding, mode, neurons, l
     pa, pb = a.master.cpu().numpy(), b.master.cpu().numpy()
     assert np.linalg.norm(pa - pb) <= 3e-2 * np.linalg.norm(pa)
     if encoding == "hash":
+        # The table's gradient is summed by fp16 atomics in an order that changes from run to run, and Adam turns an ulp of a
+        # near-zero gradient into a whole +-lr step: two IDENTICAL eager trainers on these batches end 0.014-0.067 apart in
+        # relative norm (12 runs on the GPU), with 5-19 % of the moved entries differing by more than 1e-3.  The bar is what
+        # separates that from a wrong optimiser path (a missed step, wrong step counts: relative distance of order 1).
         ta, tb = a.table_master.cpu().numpy(), b.table_master.cpu().numpy()
-        assert np.linalg.norm(ta - tb) <= 5e-2 * np.linalg.norm(ta)
+        assert np.linalg.norm(ta - tb) <= 0.2 * np.linalg.norm(ta)
+        moved = (ta != a_table0) | (tb != a_table0)
+        assert moved.sum() > 1000 and (np.abs(ta - tb)[moved] <= 1e-3).mean() >= 0.6
 
 
 def test_captured_step_with_the_traversal_one_batch_ahead(gpu):
