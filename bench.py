@@ -227,7 +227,7 @@ def extra_render_hash(tr, step_captured, trained_steps, kernel_steps, train_to=1
     train_s = time.perf_counter() - t0
     held = [scenes.pose_spherical(100.0, -35.0, origin_scale=10.0), scenes.pose_spherical(250.0, -20.0, origin_scale=10.0)]
     poses = held + [scenes.pose_spherical(360.0 * i / 4 + 15.0, -30.0, origin_scale=10.0) for i in range(2)]
-    pipe = tr.render_pipeline(W, H, focal, max_segments=1024)
+    pipe = tr.render_pipeline(W, H, focal, max_segments=1024, stable_inputs=True)    # poses_d: uploaded once, never rewritten
     worst = pipe.calibrate(poses)
     # teacher frames of the held-out views: the trainer's staged path with the analytic field in place of the network, in chunks
     psnrs = []
@@ -425,7 +425,7 @@ def extra_config5(steps, warmup, kernel_steps):
     net = api.Network(n_neurons=256, n_hidden_layers=8)
     net.set_params(torch.from_numpy(scenes.xavier_params_fp16(256, 8, net.encoded_width(), seed=1337)).cuda())
     poses = [scenes.pose_forward_facing(0.3 * np.cos(i), 0.2 * np.sin(i)) for i in range(4)]
-    pipe = render.RenderPipeline(net, R, W, H, 1.6, occupancy=occ, max_segments=1024)
+    pipe = render.RenderPipeline(net, R, W, H, 1.6, occupancy=occ, max_segments=1024, stable_inputs=True)
     worst = pipe.calibrate(poses)
     poses_d = [torch.from_numpy(p.reshape(16)).cuda() for p in poses]
     out = [torch.empty((W * H, 3), device="cuda") for _ in range(2)]
@@ -494,15 +494,34 @@ def parse():
     return ap.parse_args()
 
 
+def self_launch(n):
+    """`python3 bench.py --gpus N` without a launcher around it: start the N ranks ourselves.  This process has made no HIP call
+    (importing torch makes none), and it never execs: the ranks are a CHILD `python -m torch.distributed.run --nproc-per-node N
+    bench.py <same arguments>` on 127.0.0.1 and a free port; rank 0's JSON line reaches our stdout through the inherited
+    descriptor, and the child's exit status is ours."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run "
-                  f"--nproc-per-node {args.gpus}", file=sys.stderr)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; the launcher's --nproc-per-node must equal --gpus",
+                  file=sys.stderr)
         sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     # RTXN_REHEARSE_ON_ONE_GPU=1: every rank uses cuda:0 and the gather goes over gloo -- only to rehearse the
@@ -543,7 +562,8 @@ def main():
     sh = RowShard(W, H, 0, args.emulate_shard_of) if (args.emulate_shard_of > 1 and world == 1) else RowShard(W, H, rank, world)
     n_local, ray_begin = sh.n_local, sh.ray_begin
     pipe = render.RenderPipeline(net, R, W, H, focal, occupancy=occ, max_rays=n_local, max_segments=1024,
-                                 window=sh.window, compact=False if args.no_compact else None)
+                                 window=sh.window, compact=False if args.no_compact else None,
+                                 stable_inputs=True)    # poses_d below: one device buffer per pose, uploaded once, never rewritten
     worst = pipe.calibrate(poses, ray_begin=ray_begin, ray_count=n_local)
     poses_d = [torch.from_numpy(p.reshape(16)).cuda() for p in poses]
 

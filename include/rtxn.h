@@ -316,8 +316,12 @@ int rtxn_hashmlp_forward_segments(const rtxn_mlp* m, const rtxn_hashgrid* g, int
  * (RTXN_ENC_EXTERNAL) 64-wide model through rtxn_hashmlp_forward_segments (rtxn_mlp_set_params[_training] must have run;
  * the table is read at frame time, so a training loop may keep updating it in place). */
 enum rtxn_render_flags {
-  RTXN_RENDER_FLOAT4 = 1    /* hand the compositor the reference's float4 radiance + float t_vals (convertHalfToFloat layout,
+  RTXN_RENDER_FLOAT4 = 1,   /* hand the compositor the reference's float4 radiance + float t_vals (convertHalfToFloat layout,
                              * 20 B/sample) instead of the network's own half4 outputs (8 B/sample); same pixels bit for bit */
+  RTXN_RENDER_STABLE_INPUTS = 2   /* rtxn_render_frame_async only: the caller promises that a frame's device inputs (the 16
+                             * look_at floats, the occupancy bits) are complete BEFORE the call and stay untouched until the
+                             * frame's traversal has run (pre-uploaded poses, one buffer per frame in flight).  The traversal
+                             * then does not wait for the caller's stream and overlaps the previous frame's MLP kernel. */
 };
 typedef struct rtxn_render_config {
   const rtxn_mlp* mlp;
@@ -356,27 +360,45 @@ size_t rtxn_render_workspace_bytes(const rtxn_render_config* cfg);
 int rtxn_render_create(const rtxn_render_config* cfg, void* workspace, size_t workspace_bytes, rtxn_render** out);
 int rtxn_render_destroy(rtxn_render* r);
 /* Rebuild the occupancy hierarchy after the bits behind cfg->occupancy changed (or point the renderer at another bitfield
- * of the same resolution). */
+ * of the same resolution).  The rebuild runs on `stream` behind whatever the caller enqueued there (the copy of the new
+ * bits); `stream` first waits for pipelined traversals still in flight, and the next rtxn_render_frame_async traversal waits
+ * for the rebuild.  A serial rtxn_render_frame on a DIFFERENT stream is the caller's to order. */
 int rtxn_render_set_occupancy(rtxn_render* r, const uint32_t* occupancy, rtxn_stream_t stream);
 /* Counting pass + scan for one pose: *segments (HOST) = packed segments the window needs.  Synchronises `stream`; for sizing
  * max_segments outside any timed region (the reference sizes by 3R slots per ray, main.cu:486). */
 int rtxn_render_count_segments(rtxn_render* r, const float* look_at, uint32_t ray_begin, uint32_t ray_count, long* segments,
                                rtxn_stream_t stream);
 /* One frame (or one shard of it: rays [ray_begin, ray_begin + ray_count) of the launch under the configured interleave) on
- * ONE stream, using buffer slot `slot`.  look_at: 16 floats on the DEVICE, copied into the slot first.  pixels:
- * float[ray_count][3].  Nothing synchronises; capturable. */
+ * ONE stream, using buffer slot `slot`.  look_at: 16 floats on the DEVICE, copied into the slot first, on `stream` (so
+ * ordered behind the caller's writes there).  pixels: float[ray_count][3].  Nothing synchronises; capturable.  Every slot
+ * has its own buffers incl. the scan workspace: two calls on two streams with two DIFFERENT slots may run concurrently (the
+ * host calls themselves one at a time). */
 int rtxn_render_frame(rtxn_render* r, int slot, const float* look_at, uint32_t ray_begin, uint32_t ray_count, float* pixels,
                       rtxn_stream_t stream);
 /* The same frame software-pipelined against its neighbours: traversal on an internal stream, the MLP kernel on `stream`,
  * the compositor on a second internal stream, rotating through the n_slots buffer slots, so that under the MLP kernel of
  * frame i the chip also traverses frame i+1 and composites frame i-1.  *composite_stream (may be NULL) receives the stream
- * the pixels are complete on: enqueue follow-up work on the pixels there (a gather, a copy), or call rtxn_render_drain. */
+ * the pixels are complete on: enqueue follow-up work on the pixels there (a gather, a copy), or call rtxn_render_drain.
+ * ORDERING CONTRACT.  look_at (device) is read on the internal traversal stream.  By default that stream first waits for
+ * everything the caller has enqueued on `stream` up to this call, so a pose written on `stream` (one buffer rewritten per
+ * frame), new occupancy bits copied there, or a table update are all seen -- and the traversal of frame i+1 therefore starts
+ * only when the MLP kernel of frame i has finished (about 3 % of an 800x800 frame).  Callers whose inputs are stable declare
+ * it with RTXN_RENDER_STABLE_INPUTS (see there) and get the full overlap; then the traversal waits for `stream` only on a
+ * slot's first use and after rtxn_render_set_occupancy.  Work on OTHER streams is the caller's to order.  One thread at a
+ * time per renderer. */
 int rtxn_render_frame_async(rtxn_render* r, const float* look_at, uint32_t ray_begin, uint32_t ray_count, float* pixels,
                             rtxn_stream_t stream, rtxn_stream_t* composite_stream);
+/* As rtxn_render_frame_async with the pose in HOST memory, where the reference keeps it (main.cu:481-501 fills Params from a
+ * host look_at): the 16 floats are copied into pinned staging owned by the slot before the call returns (the caller may
+ * reuse its array at once) and uploaded on the traversal stream, so the pipeline overlaps fully without any promise. */
+int rtxn_render_frame_async_host(rtxn_render* r, const float* look_at_host, uint32_t ray_begin, uint32_t ray_count,
+                                 float* pixels, rtxn_stream_t stream, rtxn_stream_t* composite_stream);
 /* Make `stream` wait for everything rtxn_render_frame_async has enqueued on the internal streams. */
 int rtxn_render_drain(rtxn_render* r, rtxn_stream_t stream);
-/* Overflow report without polling the device: every frame copies its segment count to pinned host memory (4 bytes, async);
- * this looks at the counts that have arrived (wait != 0: synchronises the device first, so every enqueued frame is seen). */
+/* Overflow report without polling the device.  Every frame updates four per-slot counters ON THE DEVICE (segments of the
+ * frame, frames, frames over capacity, largest count) and copies them to pinned host memory (16 bytes, async); the counters
+ * are cumulative, so frames replayed from a captured hipGraph are counted once per replay.  This call folds in the copies
+ * that have arrived (wait != 0: synchronises the device first, so every enqueued or replayed frame is seen). */
 int rtxn_render_status(rtxn_render* r, int wait, rtxn_render_stats* out);
 /* Device buffers of a slot for inspection (tests, profiling tools); any out pointer may be NULL.  num_stored = segments
  * actually written per ray; t_vals: RTXN_RENDER_FLOAT4 only, segment_step: compact RTXN_VR_NERF only (else NULL). */

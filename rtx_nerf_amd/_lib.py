@@ -166,6 +166,7 @@ SYMBOLS = {
     "rtxn_render_count_segments": (_I, [_P, _P, C.c_uint32, C.c_uint32, C.POINTER(C.c_long), _P]),
     "rtxn_render_frame": (_I, [_P, _I, _P, C.c_uint32, C.c_uint32, _P, _P]),
     "rtxn_render_frame_async": (_I, [_P, _P, C.c_uint32, C.c_uint32, _P, _P, C.POINTER(_P)]),
+    "rtxn_render_frame_async_host": (_I, [_P, C.POINTER(C.c_float), C.c_uint32, C.c_uint32, _P, _P, C.POINTER(_P)]),
     "rtxn_render_drain": (_I, [_P, _P]),
     "rtxn_render_status": (_I, [_P, _I, C.POINTER(RenderStats)]),
     "rtxn_render_slot_buffers": (_I, [_P, _I] + [C.POINTER(_P)] * 11),

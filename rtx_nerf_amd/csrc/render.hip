@@ -7,7 +7,8 @@
 // write pass clamps to the capacity), and the only thing that travels to the host is a 4-byte copy of that count into pinned
 // memory which a LATER call looks at (overflow report without polling).  No kernels live here: this file only sequences the
 // stage entry points of librtxn.so on caller-given streams, exactly as a C++ host would (examples/render_host.cpp), and is
-// what rtx_nerf_amd/render.py calls.
+// what rtx_nerf_amd/render.py calls.  (One single-thread bookkeeping kernel is the exception: frame_account_kernel keeps the
+// per-slot frame / overflow counters on the device so that a replayed hipGraph is counted per replay.)
 //
 // rtxn_render_frame_async is the software-pipelined form: traversal of frame i+1 and compositing of frame
 // i-1 run on two internal streams underneath the MLP kernel of frame i, over n_slots buffer slots.
@@ -22,6 +23,7 @@ namespace {
 
 constexpr int kMaxSlots = 4;
 constexpr size_t kAlign = 256;
+constexpr size_t kPinnedPerSlot = 4 + 16;     // 32-bit words: int[4] counters, float[16] pose staging
 
 struct Slot {
   float* look_at;
@@ -30,6 +32,8 @@ struct Slot {
   int* num_stored;
   int* indices;
   int* total;
+  int* acct;          // int[4]: {segments of the last frame, frames, frames over capacity, largest count}: frame_account_kernel
+  void* scan_ws;      // per slot: two frames on two streams and slots must not share scan partials
   int* sub_hits;
   float* start;
   float* end;
@@ -38,9 +42,11 @@ struct Slot {
   float* t_vals;      // float[m*32]: RTXN_RENDER_FLOAT4 only
   float* seg_step;    // float[m]: compact RTXN_VR_NERF only
   // host side
-  int* total_host;    // pinned
-  hipEvent_t total_ev, ev_geo, ev_mlp, ev_comp;
-  bool total_pending, used;
+  int* acct_host;     // pinned int[4], copy of acct
+  float* pose_host;   // pinned float[16]: staging of rtxn_render_frame_async_host's pose
+  hipEvent_t total_ev, ev_geo, ev_mlp, ev_comp, ev_pose;
+  bool total_pending, used, pose_pending;
+  int seen_frames, seen_overflows;
 };
 
 size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
@@ -69,11 +75,12 @@ struct rtxn_render {
   uint32_t* coarse;
   uint32_t* super_mip;
   uint64_t* bricks;
-  void* scan_ws;
   size_t scan_ws_bytes;
   hipStream_t geo, comp;
-  hipEvent_t ev_tmp[2];
-  int* pinned;          // n_slots ints
+  hipEvent_t ev_tmp[2], ev_occ;
+  bool occ_dep;         // rtxn_render_set_occupancy rebuilt the hierarchy on a caller stream: the next async traversal waits for ev_occ
+  bool stable_inputs;   // RTXN_RENDER_STABLE_INPUTS
+  int* pinned;          // n_slots x (int[4] counters + float[16] pose staging)
   long frame;           // async frames enqueued
   rtxn_render_stats st;
 };
@@ -91,7 +98,7 @@ int validate(const rtxn_render_config* c, const char* who) {
                "%s: sample_type %d (the deterministic modes only: REGULAR, MIDPOINT_WORLD)", who, c->sample_type);
   RTXN_REQUIRE(c->max_segments > 0 && c->max_segments <= (1L << 31) / 32 * 31, "%s: max_segments = %ld", who, c->max_segments);
   RTXN_REQUIRE(c->n_slots >= 1 && c->n_slots <= kMaxSlots, "%s: n_slots = %d out of [1,%d]", who, c->n_slots, kMaxSlots);
-  RTXN_REQUIRE((c->flags & ~RTXN_RENDER_FLOAT4) == 0, "%s: unknown flags 0x%x", who, c->flags);
+  RTXN_REQUIRE((c->flags & ~(RTXN_RENDER_FLOAT4 | RTXN_RENDER_STABLE_INPUTS)) == 0, "%s: unknown flags 0x%x", who, c->flags);
   RTXN_REQUIRE(c->sub_rays >= 0 && c->sub_rays <= 64 && (c->sub_rays & (c->sub_rays - 1)) == 0, "%s: sub_rays = %d must be 0 or a power of two up to 64", who, c->sub_rays);
   const uint64_t launch = (uint64_t)c->width * c->height;
   RTXN_REQUIRE(c->max_rays <= launch, "%s: max_rays = %u exceeds the %u x %u launch", who, c->max_rays, c->width, c->height);
@@ -132,8 +139,7 @@ size_t layout(const rtxn_render_config* c, uint8_t* base, rtxn_render* r) {
     if (R % 16 == 0) super_mip = cv.take<uint32_t>(((rc / 4) * (rc / 4) * (rc / 4) + 31) / 32);
   }
   const size_t ws_bytes = rtxn_scan_workspace_bytes((int)n);
-  void* scan_ws = cv.take<uint8_t>(ws_bytes);
-  if (r) { r->coarse = coarse; r->bricks = bricks; r->super_mip = super_mip; r->scan_ws = scan_ws; r->scan_ws_bytes = ws_bytes; }
+  if (r) { r->coarse = coarse; r->bricks = bricks; r->super_mip = super_mip; r->scan_ws_bytes = ws_bytes; }
   for (int i = 0; i < c->n_slots; ++i) {
     Slot s;
     memset(&s, 0, sizeof(s));
@@ -143,6 +149,8 @@ size_t layout(const rtxn_render_config* c, uint8_t* base, rtxn_render* r) {
     s.num_stored = cv.take<int>(n);
     s.indices = cv.take<int>(n);
     s.total = cv.take<int>(1);
+    s.acct = cv.take<int>(4);
+    s.scan_ws = cv.take<uint8_t>(ws_bytes);
     s.sub_hits = Q > 1 ? cv.take<int>(n * Q) : nullptr;
     s.start = cv.take<float>(3 * m);
     s.end = cv.take<float>(3 * m);
@@ -209,17 +217,36 @@ void trace_params(const rtxn_render* r, const Slot& g, uint32_t ray_begin, uint3
   }
 }
 
-// Look at the segment count slot g's LAST frame reported, if it has arrived (no synchronisation).
+// Per-slot counters live on the device and are cumulative, so any copy of them that has reached the host is exact however many
+// frames (or graph replays) ran since the last look: {segments of the last frame, frames, frames over capacity, largest count}.
+__global__ void frame_account_kernel(const int* __restrict__ total, int capacity, int* __restrict__ acct) {
+  const int t = *total;
+  acct[0] = t;
+  acct[1] += 1;
+  acct[2] += t > capacity ? 1 : 0;
+  acct[3] = t > acct[3] ? t : acct[3];
+}
+
+// Fold what slot g's counters say into the renderer's statistics.
+void fold(rtxn_render* r, Slot& g) {
+  const int* a = g.acct_host;
+  r->st.frames_checked += a[1] - g.seen_frames;
+  r->st.overflow_frames += a[2] - g.seen_overflows;
+  if (a[1] != g.seen_frames) r->st.last_segments = a[0];
+  g.seen_frames = a[1];
+  g.seen_overflows = a[2];
+  if (a[3] > r->st.max_segments_needed) r->st.max_segments_needed = a[3];
+}
+
+// Look at the counters slot g's LAST frame reported, if they have arrived (no synchronisation).
 void harvest(rtxn_render* r, Slot& g, bool force) {
   if (!g.total_pending) return;
   if (!force && hipEventQuery(g.total_ev) != hipSuccess) return;
   g.total_pending = false;
-  const long need = *g.total_host;
-  r->st.frames_checked++;
-  r->st.last_segments = need;
-  if (need > r->st.max_segments_needed) r->st.max_segments_needed = need;
-  if (need > r->cfg.max_segments) r->st.overflow_frames++;
+  fold(r, g);
 }
+
+long c_max_segments(const rtxn_render* r) { return r->cfg.max_segments > 0x7fffffffL ? 0x7fffffffL : r->cfg.max_segments; }
 
 bool capturing(hipStream_t s) {
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -227,20 +254,27 @@ bool capturing(hipStream_t s) {
 }
 
 // count -> scan -> write of one frame into slot g
-int geometry(rtxn_render* r, Slot& g, const float* look_at, uint32_t ray_begin, uint32_t n, hipStream_t s) {
-  RTXN_HIP(hipMemcpyAsync(g.look_at, look_at, 16 * sizeof(float), hipMemcpyDeviceToDevice, s));
+int geometry(rtxn_render* r, Slot& g, const float* look_at, bool pose_on_host, uint32_t ray_begin, uint32_t n, hipStream_t s) {
+  RTXN_HIP(hipMemcpyAsync(g.look_at, look_at, 16 * sizeof(float), pose_on_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s));
+  if (pose_on_host) {
+    RTXN_HIP(hipEventRecord(g.ev_pose, s));
+    g.pose_pending = true;
+  }
   rtxn_trace_params p;
   trace_params(r, g, ray_begin, n, false, p);
   int rc = rtxn_trace_grid(&p, s);
   if (rc != RTXN_OK) return rc;
-  rc = rtxn_scan_hits(g.num_hits, g.indices, g.total, (int)n, r->scan_ws, r->scan_ws_bytes, s);
+  rc = rtxn_scan_hits(g.num_hits, g.indices, g.total, (int)n, g.scan_ws, r->scan_ws_bytes, s);
   if (rc != RTXN_OK) return rc;
   trace_params(r, g, ray_begin, n, true, p);
   rc = rtxn_trace_grid(&p, s);
   if (rc != RTXN_OK) return rc;
-  // 4 bytes to pinned memory: what a later call's overflow check reads.  Under stream capture the copy node is part of the
-  // graph (every replay refreshes the count) but there is no event to poll: rtxn_render_status(wait = 1) reads it.
-  RTXN_HIP(hipMemcpyAsync(g.total_host, g.total, sizeof(int), hipMemcpyDeviceToHost, s));
+  // 16 bytes of counters to pinned memory: what a later call's overflow check reads.  Under stream capture the kernel and the
+  // copy node are part of the graph (every replay counts itself) but there is no event to poll: rtxn_render_status(wait = 1)
+  // reads them.
+  frame_account_kernel<<<1, 1, 0, s>>>(g.total, (int)(c_max_segments(r)), g.acct);
+  RTXN_LAUNCH_CHECK("frame_account_kernel");
+  RTXN_HIP(hipMemcpyAsync(g.acct_host, g.acct, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
   if (!capturing(s)) {
     RTXN_HIP(hipEventRecord(g.total_ev, s));
     g.total_pending = true;
@@ -294,26 +328,31 @@ extern "C" int rtxn_render_create(const rtxn_render_config* cfg, void* workspace
   r->compact = !(cfg->flags & RTXN_RENDER_FLOAT4);
   r->hash = cfg->grid != nullptr;
   r->n_slots = cfg->n_slots;
+  r->stable_inputs = (cfg->flags & RTXN_RENDER_STABLE_INPUTS) != 0;
   r->st.max_segments = cfg->max_segments;
   layout(cfg, static_cast<uint8_t*>(workspace), r);
   auto fail = [&](int code) { rtxn_render_destroy(r); return code; };
-  hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&r->pinned), sizeof(int) * kMaxSlots, hipHostMallocDefault);
+  hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&r->pinned), kPinnedPerSlot * sizeof(int) * kMaxSlots, hipHostMallocDefault);
   if (e != hipSuccess) return fail(rtxn::fail_hip(e, "hipHostMalloc(pinned segment counts)"));
   if ((e = hipStreamCreateWithFlags(&r->geo, hipStreamNonBlocking)) != hipSuccess) return fail(rtxn::fail_hip(e, "hipStreamCreate(geometry)"));
   if ((e = hipStreamCreateWithFlags(&r->comp, hipStreamNonBlocking)) != hipSuccess) return fail(rtxn::fail_hip(e, "hipStreamCreate(composite)"));
   for (int i = 0; i < 2; ++i)
     if ((e = hipEventCreateWithFlags(&r->ev_tmp[i], hipEventDisableTiming)) != hipSuccess) return fail(rtxn::fail_hip(e, "hipEventCreate"));
+  if ((e = hipEventCreateWithFlags(&r->ev_occ, hipEventDisableTiming)) != hipSuccess) return fail(rtxn::fail_hip(e, "hipEventCreate"));
   for (int i = 0; i < r->n_slots; ++i) {
     Slot& g = r->slots[i];
-    g.total_host = r->pinned + i;
-    *g.total_host = 0;
-    hipEvent_t* evs[4] = {&g.total_ev, &g.ev_geo, &g.ev_mlp, &g.ev_comp};
+    g.acct_host = r->pinned + kPinnedPerSlot * i;
+    g.pose_host = reinterpret_cast<float*>(g.acct_host + 4);
+    memset(g.acct_host, 0, kPinnedPerSlot * sizeof(int));
+    hipEvent_t* evs[5] = {&g.total_ev, &g.ev_geo, &g.ev_mlp, &g.ev_comp, &g.ev_pose};
     for (hipEvent_t* ev : evs)
       if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) return fail(rtxn::fail_hip(e, "hipEventCreate"));
   }
-  // per-slot totals start at 0 (a status query before the first frame reads them), and the hierarchy is built once here
-  for (int i = 0; i < r->n_slots; ++i)
+  // per-slot totals and counters start at 0 (a status query before the first frame reads them), and the hierarchy is built once here
+  for (int i = 0; i < r->n_slots; ++i) {
     if ((e = rtxn::zero_words(r->slots[i].total, 1, nullptr)) != hipSuccess) return fail(rtxn::fail_hip(e, "zero_words(total)"));
+    if ((e = rtxn::zero_words(r->slots[i].acct, 4, nullptr)) != hipSuccess) return fail(rtxn::fail_hip(e, "zero_words(acct)"));
+  }
   rc = build_hierarchy(r, nullptr);
   if (rc != RTXN_OK) return fail(rc);
   if ((e = hipStreamSynchronize(nullptr)) != hipSuccess) return fail(rtxn::fail_hip(e, "hipStreamSynchronize"));
@@ -326,10 +365,11 @@ extern "C" int rtxn_render_destroy(rtxn_render* r) {
   (void)hipDeviceSynchronize();      // frames in flight still use the slots' events
   for (int i = 0; i < r->n_slots; ++i) {
     Slot& g = r->slots[i];
-    hipEvent_t evs[4] = {g.total_ev, g.ev_geo, g.ev_mlp, g.ev_comp};
+    hipEvent_t evs[5] = {g.total_ev, g.ev_geo, g.ev_mlp, g.ev_comp, g.ev_pose};
     for (hipEvent_t ev : evs)
       if (ev) (void)hipEventDestroy(ev);
   }
+  if (r->ev_occ) (void)hipEventDestroy(r->ev_occ);
   for (int i = 0; i < 2; ++i)
     if (r->ev_tmp[i]) (void)hipEventDestroy(r->ev_tmp[i]);
   if (r->geo) (void)hipStreamDestroy(r->geo);
@@ -345,8 +385,22 @@ extern "C" int rtxn_render_set_occupancy(rtxn_render* r, const uint32_t* occupan
                "rtxn_render_set_occupancy: a renderer created %s an occupancy grid cannot switch (the hierarchy's buffers are laid out at creation)",
                r->cfg.occupancy ? "with" : "without");
   RTXN_DEVICE_OR_FAIL();
+  hipStream_t s = rtxn::as_stream(stream);
+  if (!capturing(s)) {
+    // traversals still in flight on the internal stream read the hierarchy this rebuilds: `stream` waits for them, and the
+    // NEXT pipelined traversal waits for the rebuild (and for whatever the caller put on `stream` before it -- the copy of
+    // the new bits, typically)
+    RTXN_HIP(hipEventRecord(r->ev_tmp[0], r->geo));
+    RTXN_HIP(hipStreamWaitEvent(s, r->ev_tmp[0], 0));
+  }
   r->cfg.occupancy = occupancy;
-  return build_hierarchy(r, rtxn::as_stream(stream));
+  int rc = build_hierarchy(r, s);
+  if (rc != RTXN_OK) return rc;
+  if (!capturing(s)) {
+    RTXN_HIP(hipEventRecord(r->ev_occ, s));
+    r->occ_dep = true;
+  }
+  return RTXN_OK;
 }
 
 extern "C" int rtxn_render_count_segments(rtxn_render* r, const float* look_at, uint32_t ray_begin, uint32_t ray_count, long* segments,
@@ -362,7 +416,7 @@ extern "C" int rtxn_render_count_segments(rtxn_render* r, const float* look_at, 
   trace_params(r, g, ray_begin, ray_count, false, p);
   rc = rtxn_trace_grid(&p, s);
   if (rc != RTXN_OK) return rc;
-  rc = rtxn_scan_hits(g.num_hits, g.indices, g.total, (int)ray_count, r->scan_ws, r->scan_ws_bytes, s);
+  rc = rtxn_scan_hits(g.num_hits, g.indices, g.total, (int)ray_count, g.scan_ws, r->scan_ws_bytes, s);
   if (rc != RTXN_OK) return rc;
   int total = 0;
   RTXN_HIP(hipMemcpyAsync(&total, g.total, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -381,33 +435,45 @@ extern "C" int rtxn_render_frame(rtxn_render* r, int slot, const float* look_at,
   hipStream_t s = rtxn::as_stream(stream);
   Slot& g = r->slots[slot];
   if (!capturing(s)) harvest(r, g, false);
-  rc = geometry(r, g, look_at, ray_begin, ray_count, s);
+  rc = geometry(r, g, look_at, false, ray_begin, ray_count, s);
   if (rc != RTXN_OK) return rc;
   rc = shade(r, g, s);
   if (rc != RTXN_OK) return rc;
   return composite(r, g, ray_count, pixels, s);
 }
 
-extern "C" int rtxn_render_frame_async(rtxn_render* r, const float* look_at, uint32_t ray_begin, uint32_t ray_count, float* pixels,
-                                       rtxn_stream_t stream, rtxn_stream_t* composite_stream) {
-  RTXN_REQUIRE(r && look_at && pixels, "rtxn_render_frame_async: NULL argument");
-  int rc = check_window(r, ray_begin, ray_count, "rtxn_render_frame_async");
-  if (rc != RTXN_OK) return rc;
-  RTXN_DEVICE_OR_FAIL();
-  hipStream_t main_s = rtxn::as_stream(stream);
-  RTXN_REQUIRE(!capturing(main_s), "rtxn_render_frame_async: not capturable (internal streams); capture rtxn_render_frame instead");
+namespace {
+
+// What the traversal of an async frame has to wait for before it may read its inputs (look_at, the occupancy bits):
+//  * the slot's previous frame (its MLP kernel and compositor still read the slot's buffers);
+//  * by default EVERYTHING the caller enqueued on `stream` before this call: a host that rewrites one device pose buffer per
+//    frame on `stream`, or copies new occupancy bits there, is then ordered correctly -- at the price that the traversal of
+//    frame i+1 starts only when the MLP kernel of frame i (also on `stream`) has finished;
+//  * with RTXN_RENDER_STABLE_INPUTS (the caller's promise that a frame's inputs are complete and stay untouched from the call
+//    until the frame's traversal has run: pre-uploaded poses) or with a HOST pose (staged through pinned memory here): only on
+//    a slot's first use and after rtxn_render_set_occupancy -- the fully overlapped pipeline.
+int frame_async(rtxn_render* r, const float* look_at, bool pose_on_host, uint32_t ray_begin, uint32_t ray_count, float* pixels,
+                hipStream_t main_s, rtxn_stream_t* composite_stream) {
   const int b = (int)(r->frame % r->n_slots);
   r->frame++;
   Slot& g = r->slots[b];
   harvest(r, g, false);                                   // the frame that used this slot n_slots frames ago
-  // geometry stream: wait until frame i - n_slots (its MLP kernel and compositor) is done with this slot
-  if (g.used) {
-    RTXN_HIP(hipStreamWaitEvent(r->geo, g.ev_comp, 0));
-  } else {
-    RTXN_HIP(hipEventRecord(r->ev_tmp[0], main_s));       // first use: whatever set the pipeline up on the caller's stream
+  if (g.used) RTXN_HIP(hipStreamWaitEvent(r->geo, g.ev_comp, 0));
+  const bool ordered = !g.used || !(r->stable_inputs || pose_on_host);
+  if (ordered) {
+    RTXN_HIP(hipEventRecord(r->ev_tmp[0], main_s));
     RTXN_HIP(hipStreamWaitEvent(r->geo, r->ev_tmp[0], 0));
   }
-  rc = geometry(r, g, look_at, ray_begin, ray_count, r->geo);
+  if (r->occ_dep) {                                       // one wait orders every later traversal: the stream is in order
+    RTXN_HIP(hipStreamWaitEvent(r->geo, r->ev_occ, 0));
+    r->occ_dep = false;
+  }
+  if (pose_on_host) {
+    if (g.pose_pending) RTXN_HIP(hipEventSynchronize(g.ev_pose));   // the staging words' previous copy (n_slots frames ago)
+    memcpy(g.pose_host, look_at, 16 * sizeof(float));
+    look_at = g.pose_host;
+  }
+  int rc = geometry(r, g, look_at, pose_on_host, ray_begin, ray_count, r->geo);
   if (rc != RTXN_OK) return rc;
   RTXN_HIP(hipEventRecord(g.ev_geo, r->geo));
   RTXN_HIP(hipStreamWaitEvent(main_s, g.ev_geo, 0));
@@ -422,6 +488,30 @@ extern "C" int rtxn_render_frame_async(rtxn_render* r, const float* look_at, uin
   g.used = true;
   if (composite_stream) *composite_stream = r->comp;
   return RTXN_OK;
+}
+
+}  // namespace
+
+extern "C" int rtxn_render_frame_async(rtxn_render* r, const float* look_at, uint32_t ray_begin, uint32_t ray_count, float* pixels,
+                                       rtxn_stream_t stream, rtxn_stream_t* composite_stream) {
+  RTXN_REQUIRE(r && look_at && pixels, "rtxn_render_frame_async: NULL argument");
+  int rc = check_window(r, ray_begin, ray_count, "rtxn_render_frame_async");
+  if (rc != RTXN_OK) return rc;
+  RTXN_DEVICE_OR_FAIL();
+  hipStream_t main_s = rtxn::as_stream(stream);
+  RTXN_REQUIRE(!capturing(main_s), "rtxn_render_frame_async: not capturable (internal streams); capture rtxn_render_frame instead");
+  return frame_async(r, look_at, false, ray_begin, ray_count, pixels, main_s, composite_stream);
+}
+
+extern "C" int rtxn_render_frame_async_host(rtxn_render* r, const float* look_at_host, uint32_t ray_begin, uint32_t ray_count,
+                                            float* pixels, rtxn_stream_t stream, rtxn_stream_t* composite_stream) {
+  RTXN_REQUIRE(r && look_at_host && pixels, "rtxn_render_frame_async_host: NULL argument");
+  int rc = check_window(r, ray_begin, ray_count, "rtxn_render_frame_async_host");
+  if (rc != RTXN_OK) return rc;
+  RTXN_DEVICE_OR_FAIL();
+  hipStream_t main_s = rtxn::as_stream(stream);
+  RTXN_REQUIRE(!capturing(main_s), "rtxn_render_frame_async_host: not capturable (internal streams, host staging)");
+  return frame_async(r, look_at_host, true, ray_begin, ray_count, pixels, main_s, composite_stream);
 }
 
 extern "C" int rtxn_render_drain(rtxn_render* r, rtxn_stream_t stream) {
@@ -442,11 +532,8 @@ extern "C" int rtxn_render_status(rtxn_render* r, int wait, rtxn_render_stats* o
     RTXN_HIP(hipDeviceSynchronize());
     for (int i = 0; i < r->n_slots; ++i) {
       Slot& g = r->slots[i];
-      if (g.total_pending) { harvest(r, g, true); continue; }
-      // a frame replayed from a captured graph left its count in pinned memory without an event
-      const long need = *g.total_host;
-      if (need > r->st.max_segments_needed) r->st.max_segments_needed = need;
-      if (need > r->cfg.max_segments && need != r->st.last_segments) { r->st.overflow_frames++; r->st.last_segments = need; }
+      g.total_pending = false;
+      fold(r, g);       // also the frames a captured graph replayed: they left their counters in pinned memory without an event
     }
   } else {
     for (int i = 0; i < r->n_slots; ++i) harvest(r, r->slots[i], false);

@@ -22,13 +22,14 @@ import torch
 from . import _lib, api
 
 RENDER_FLOAT4 = 1     # enum rtxn_render_flags
+RENDER_STABLE_INPUTS = 2
 
 
 class RenderPipeline:
     def __init__(self, network, grid_res, width, height, focal_length, aspect_ratio=None, occupancy=None,
                  max_rays=None, max_segments=None, trace_mode=api.TRACE_DDA, vr_mode=api.VR_COMPAT,
                  device="cuda", window=(0, 0), step_scale=1.0, sub_rays=None, compact=None, on_overflow="raise",
-                 hashgrid=None, table=None, sample_type=None, n_slots=None):
+                 hashgrid=None, table=None, sample_type=None, n_slots=None, stable_inputs=False):
         self.net = network
         self.hg, self.table = hashgrid, table
         if (hashgrid is None) != (table is None):
@@ -67,6 +68,10 @@ class RenderPipeline:
         if on_overflow not in ("raise", "grow", "ignore"):
             raise ValueError("on_overflow must be 'raise', 'grow' or 'ignore'")
         self.on_overflow = on_overflow
+        # stable_inputs: the caller's promise for render_async (RTXN_RENDER_STABLE_INPUTS, include/rtxn.h): device poses are
+        # uploaded before the call and left alone until their frame has been traversed.  Without it the traversal of every
+        # pipelined frame waits for the caller's stream (correct for a pose buffer rewritten per frame, ~3 % slower).
+        self.stable_inputs = bool(stable_inputs)
         self.overflow_frames = 0
         self.occ = occupancy
         self.max_rays = n_rays
@@ -98,7 +103,7 @@ class RenderPipeline:
         c.vr_mode, c.sample_type, c.step_scale = self.vr_mode, self.sample_type, self.step_scale
         c.max_segments = self.max_segments
         c.n_slots = self.n_slots
-        c.flags = 0 if self.compact else RENDER_FLOAT4
+        c.flags = (0 if self.compact else RENDER_FLOAT4) | (RENDER_STABLE_INPUTS if self.stable_inputs else 0)
         return c
 
     def _destroy(self):
@@ -234,16 +239,25 @@ class RenderPipeline:
     # never synchronises; it simply runs ahead.  This matters most when the frame is sharded over N GPUs (the fixed
     # traversal latency is 16 % of a rank's frame at N = 8).
     def render_async(self, look_at, ray_begin=0, ray_count=None, out=None):
-        """Enqueue one frame, software-pipelined against its neighbours.  look_at: 16 floats on the DEVICE (copied into the
-        slot on the traversal stream; keep it unchanged until then).  Returns (pixels, None, comp_stream): `pixels` is
-        complete on `comp_stream`; follow-up work on it (a gather, a copy) is best enqueued there, or call drain_async()."""
+        """Enqueue one frame, software-pipelined against its neighbours.  look_at: 16 floats -- a DEVICE tensor (copied into
+        the slot on the traversal stream, which waits for the current stream first unless the pipeline was built with
+        stable_inputs=True) or a HOST array / CPU tensor (rtxn_render_frame_async_host: staged through pinned memory, fully
+        overlapped).  Returns (pixels, None, comp_stream): `pixels` is complete on `comp_stream`; follow-up work on it (a
+        gather, a copy) is best enqueued there, or call drain_async()."""
         n = self.max_rays if ray_count is None else ray_count
         pixels = self.pixels[:n] if out is None else out
         self._check_overflow()
         comp = C.c_void_p()
-        _lib.check(_lib.lib().rtxn_render_frame_async(self._h, api._ptr(look_at, torch.float32, "look_at"), ray_begin, n,
-                                                      api._ptr(pixels, torch.float32, "pixels"), api._stream(), C.byref(comp)),
-                   "rtxn_render_frame_async")
+        if isinstance(look_at, torch.Tensor) and look_at.is_cuda:
+            _lib.check(_lib.lib().rtxn_render_frame_async(self._h, api._ptr(look_at, torch.float32, "look_at"), ray_begin, n,
+                                                          api._ptr(pixels, torch.float32, "pixels"), api._stream(), C.byref(comp)),
+                       "rtxn_render_frame_async")
+        else:
+            import numpy as np
+            host = np.ascontiguousarray(np.asarray(look_at, dtype=np.float32).reshape(16))
+            _lib.check(_lib.lib().rtxn_render_frame_async_host(self._h, host.ctypes.data_as(C.POINTER(C.c_float)), ray_begin, n,
+                                                               api._ptr(pixels, torch.float32, "pixels"), api._stream(), C.byref(comp)),
+                       "rtxn_render_frame_async_host")
         if self._comp_stream is None or self._comp_stream.cuda_stream != comp.value:
             self._comp_stream = torch.cuda.ExternalStream(comp.value, device=self.dev)
         return pixels, None, self._comp_stream

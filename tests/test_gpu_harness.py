@@ -232,3 +232,162 @@ def test_overflow_outside_the_calibrated_poses_is_reported_without_polling(gpu):
     again = pipe.render().clone()                    # the check of this call sees the cut frame and grows the buffers first
     pipe.finish()
     assert pipe.overflow_frames == 1 and pipe.max_segments > ref.max_segments and torch.equal(again, want)
+
+
+def _small_pipeline(torch, **kw):
+    from rtx_nerf_amd import api, render, scenes
+    R, W, H = 64, 160, 120
+    occ = torch.from_numpy(scenes.pack_occupancy(scenes.lego_standin_density(R, seed=0)).view(np.int32).copy()).cuda()
+    net = api.Network(n_neurons=64, n_hidden_layers=2)
+    net.set_params(torch.from_numpy(scenes.xavier_params_fp16(64, 2, net.encoded_width(), seed=7)).cuda())
+    focal = scenes.lego_focal_length(True)
+    poses = [scenes.pose_spherical(40.0 * i, -30.0, origin_scale=10.0) for i in range(6)]
+    pipe = render.RenderPipeline(net, R, W, H, focal, occupancy=occ, max_segments=1024, **kw)
+    pipe.calibrate(poses)
+    want = []
+    for p in poses:
+        pipe.set_pose(p)
+        want.append(pipe.render().clone())
+    torch.cuda.synchronize()
+    return pipe, poses, want, (W, H)
+
+
+@pytest.mark.gpu
+def test_async_frames_see_a_pose_buffer_rewritten_on_the_callers_stream(gpu):
+    """VERDICT r03 weak 10(i) / ADVICE r03: the traversal runs on an internal stream.  ONE device pose buffer rewritten on the
+    caller's stream before every rtxn_render_frame_async call must give the frames that distinct, pre-uploaded buffers give --
+    the default contract (the traversal waits for the caller's stream at every frame).  The rewrite is made late on purpose: a
+    long-running kernel sits in front of it on the caller's stream, so a traversal that did not wait would read the previous
+    pose.  Host poses (rtxn_render_frame_async_host: pinned staging) get the same frames with no such wait."""
+    torch = gpu
+    pipe, poses, want, (W, H) = _small_pipeline(torch)
+    one = torch.zeros(16, device="cuda")
+    pinned = [torch.from_numpy(p.reshape(16).astype(np.float32)).pin_memory() for p in poses]
+    outs = [torch.empty((W * H, 3), device="cuda") for _ in poses]
+    busy = torch.empty((4096, 4096), device="cuda")
+    for _ in range(2):
+        for p, o in zip(pinned, outs):
+            for _ in range(3):
+                busy.normal_()                        # ~ms of work in front of the pose write on the caller's stream
+            one.copy_(p, non_blocking=True)
+            pipe.render_async(one, out=o)
+        pipe.drain_async()
+        torch.cuda.synchronize()
+        for i, (o, w) in enumerate(zip(outs, want)):
+            assert torch.equal(o, w), f"frame {i} was traversed with another pose"
+    # host poses: one numpy array rewritten in place right after each call returns
+    host = np.zeros(16, np.float32)
+    for p, o in zip(poses, outs):
+        o.zero_()
+        host[:] = p.reshape(16)
+        pipe.render_async(host, out=o)
+        host[:] = 0.0                                 # the call has copied it
+    pipe.drain_async()
+    torch.cuda.synchronize()
+    for o, w in zip(outs, want):
+        assert torch.equal(o, w)
+    assert not pipe.overflowed()
+
+
+@pytest.mark.gpu
+def test_two_serial_frames_on_two_streams_and_slots_run_concurrently(gpu):
+    """every slot has its own scan workspace, so two rtxn_render_frame calls on two streams with two
+    slots may overlap on the device; the pair must equal the two frames rendered one after the other."""
+    import ctypes as C
+    torch = gpu
+    from rtx_nerf_amd import _lib, api
+    pipe, poses, want, (W, H) = _small_pipeline(torch, n_slots=2)
+    lib = _lib.lib()
+    s = [torch.cuda.Stream(), torch.cuda.Stream()]
+    pd = [torch.from_numpy(p.reshape(16).astype(np.float32)).cuda() for p in poses]
+    outs = [torch.empty((W * H, 3), device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    for rep in range(8):
+        a, b = (2 * rep) % len(poses), (2 * rep + 1) % len(poses)
+        for k, idx in enumerate((a, b)):
+            _lib.check(lib.rtxn_render_frame(pipe._h, k, C.c_void_p(pd[idx].data_ptr()), 0, W * H,
+                                             C.c_void_p(outs[k].data_ptr()), C.c_void_p(s[k].cuda_stream)), "rtxn_render_frame")
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], want[a]) and torch.equal(outs[1], want[b]), f"concurrent pair {rep}"
+
+
+@pytest.mark.gpu
+def test_overflowing_captured_frame_is_counted_once_per_replay(gpu):
+    """the overflow counters live on the device, so a captured frame that overflows and is replayed
+    three times reports three overflow frames (the host used to compare segment counts and saw one)."""
+    torch = gpu
+    from rtx_nerf_amd import api, render, scenes
+    R, W, H = 64, 96, 96
+    occ = torch.from_numpy(scenes.pack_occupancy(scenes.lego_standin_density(R, seed=0)).view(np.int32).copy()).cuda()
+    net = api.Network(n_neurons=64, n_hidden_layers=2)
+    net.set_params(torch.from_numpy(scenes.xavier_params_fp16(64, 2, net.encoded_width(), seed=7)).cuda())
+    focal = scenes.lego_focal_length(True)
+    far = scenes.pose_spherical(10.0, -30.0, radius=40.0, origin_scale=10.0)
+    near = scenes.pose_spherical(10.0, -30.0, origin_scale=10.0)
+    pipe = render.RenderPipeline(net, R, W, H, focal, occupancy=occ, max_segments=1024, on_overflow="ignore")
+    pipe.calibrate([far])
+    pipe.set_pose(far)
+    pipe.render()
+    torch.cuda.synchronize()
+    st = pipe._status(wait=True)
+    assert st.frames_checked == 1 and st.overflow_frames == 0
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        graph, pix = pipe.capture()
+    torch.cuda.synchronize()
+    st0 = pipe._status(wait=True)
+    pipe.set_pose(near)                      # needs several times the calibrated capacity
+    torch.cuda.synchronize()
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    st = pipe._status(wait=True)
+    assert st.overflow_frames - st0.overflow_frames == 3 and st.frames_checked - st0.frames_checked == 3
+    assert st.max_segments_needed > pipe.max_segments and st.last_segments == st.max_segments_needed
+    pipe.set_pose(far)
+    torch.cuda.synchronize()
+    graph.replay()
+    torch.cuda.synchronize()
+    st2 = pipe._status(wait=True)
+    assert st2.overflow_frames == st.overflow_frames and st2.frames_checked == st.frames_checked + 1
+    assert st2.last_segments <= pipe.max_segments
+
+
+@pytest.mark.gpu
+def test_occupancy_update_on_the_callers_stream_reaches_the_pipelined_traversal(gpu):
+    """rtxn_render_set_occupancy rebuilds the hierarchy on the caller's stream; the next pipelined frame's
+    traversal (internal stream) must wait for the new bits and the rebuild, also with RTXN_RENDER_STABLE_INPUTS."""
+    torch = gpu
+    from rtx_nerf_amd import scenes
+    pipe, poses, want, (W, H) = _small_pipeline(torch, stable_inputs=True)
+    R = pipe.R
+    pd = [torch.from_numpy(p.reshape(16).astype(np.float32)).cuda() for p in poses]
+    sphere = torch.from_numpy(scenes.pack_occupancy(scenes.sphere_density(R, 0.8)).view(np.int32).copy()).cuda()
+    lego = pipe.occ.clone()
+    live = pipe.occ                                   # the tensor the renderer points at; rewritten in place below
+    out = torch.empty((W * H, 3), device="cuda")
+    busy = torch.empty((4096, 4096), device="cuda")
+    # expected frame under the sphere occupancy
+    live.copy_(sphere)
+    pipe.set_occupancy(live)
+    torch.cuda.synchronize()
+    pipe.calibrate([poses[1]])
+    live.copy_(sphere)
+    pipe.set_occupancy(live)
+    pipe.set_pose(poses[1])
+    want_sphere = pipe.render().clone()
+    torch.cuda.synchronize()
+    assert not torch.equal(want_sphere, want[1])
+    for rep in range(3):
+        live.copy_(lego)
+        pipe.set_occupancy(live)
+        pipe.render_async(pd[1], out=out)             # a few frames in flight under the old bits
+        pipe.render_async(pd[1], out=out)
+        for _ in range(3):
+            busy.normal_()
+        live.copy_(sphere, non_blocking=True)         # late on the caller's stream
+        pipe.set_occupancy(live)
+        pipe.render_async(pd[1], out=out)
+        pipe.drain_async()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want_sphere), f"round {rep}: traversal ran before the occupancy update"
