@@ -130,7 +130,9 @@ int main(int argc, char** argv) {
   void* scan_ws = dev_alloc<char>(scan_bytes);
   float *start = dev_alloc<float>(3 * capacity), *end = dev_alloc<float>(3 * capacity), *seg_view = dev_alloc<float>(2 * capacity);
   __half* encT = dev_alloc<__half>((size_t)E * Sp);
-  void* workspace = dev_alloc<char>(rtxn_mlp_train_workspace_bytes(net, 32 * capacity));
+  // the reference's 8 x 128 model takes the lean path: no saved activations, half the workspace (rtxn.h: rtxn_mlp_train_forward_lean)
+  const bool lean = rtxn_mlp_train_lean_supported(net) && !(std::getenv("RTXN_TRAIN_LEAN") && std::atoi(std::getenv("RTXN_TRAIN_LEAN")) == 0);
+  void* workspace = dev_alloc<char>(lean ? rtxn_mlp_train_lean_workspace_bytes(net, 32 * capacity) : rtxn_mlp_train_workspace_bytes(net, 32 * capacity));
   __half* out_half = dev_alloc<__half>(32 * capacity * 16);
   float *radiance = dev_alloc<float>(32 * capacity * 4), *t_vals = dev_alloc<float>(32 * capacity);
   __half* dout = dev_alloc<__half>(32 * capacity * 4);
@@ -162,6 +164,7 @@ int main(int argc, char** argv) {
   b.encT = encT; b.workspace = workspace; b.output_half = out_half; b.radiance = radiance; b.t_vals = t_vals;
   b.radiance_gradients = dout; b.pixels = pixels; b.loss_gradients_half = loss_grads; b.loss_sum = loss; b.dparams = dparams;
   b.live_ws = live_ws;
+  b.workspace_lean = lean ? 1 : 0;
   a.opt.mlp_master = master; a.opt.mlp_params_fp16 = params; a.opt.mlp_m = adam_m; a.opt.mlp_v = adam_v;
   a.opt.step = step_dev; a.opt.effective_lr = lr_dev;
   a.opt.lr = 1e-3f; a.opt.beta1 = 0.9f; a.opt.beta2 = 0.999f; a.opt.eps = 1e-8f;

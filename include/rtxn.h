@@ -489,6 +489,24 @@ int rtxn_mlp_train_forward_outputs(const rtxn_mlp* m, const void* encT, long n_s
 int rtxn_mlp_train_backward_recompute(const rtxn_mlp* m, const void* encT, const void* output_half, const void* dout_half4,
                                       long n_samples, float* dparams, void* dencT, rtxn_stream_t stream);
 
+/* Lean path for the reference's own model (128 wide, 8 hidden layers, 112 encoded features: main.cu:35-69), where the whole
+ * gradient does not fit on the chip.  The saved-activation pair above moves 8.8 KB per sample through device memory (2 KB of
+ * activations out of the forward, 2 KB of dZ out of the backward chain, both back into the weight-gradient GEMM) and needs a
+ * workspace of 4.3 KB per sample -- 40 GB at the reference's batch (main.cu:186).  Here the forward keeps only the 16-byte
+ * sign masks per sample and layer (all the backward chain needs of the activations), the chain writes dZ as before, and the
+ * weight gradient RECOMPUTES the activations from the encoded input in three passes (layers 0-2, 3-5, 6-7 + output) with the
+ * gradients accumulated on chip: 5.4 KB moved and 2.2 KB of workspace per sample.  Same results as the pair above up to the
+ * summation order of the fp32 atomics.
+ *   rtxn_mlp_train_lean_supported: 1 if the model has this path;
+ *   workspace_lean: rtxn_mlp_train_lean_workspace_bytes(m, n_samples) bytes, written by _forward_lean, read by _backward_lean;
+ *   live_ws (may be NULL): as rtxn_mlp_train_backward_live -- only the listed segments are visited. */
+int rtxn_mlp_train_lean_supported(const rtxn_mlp* m);
+size_t rtxn_mlp_train_lean_workspace_bytes(const rtxn_mlp* m, long n_samples);
+int rtxn_mlp_train_forward_lean(const rtxn_mlp* m, const void* encT, long n_samples, void* workspace_lean, void* output_half,
+                                float* radiance, rtxn_stream_t stream);
+int rtxn_mlp_train_backward_lean(const rtxn_mlp* m, const void* encT, const void* output_half, const void* dout_half4,
+                                 long n_samples, void* workspace_lean, const void* live_ws, float* dparams, rtxn_stream_t stream);
+
 /* loss->evaluate (tcnn "L2", main.cu:36-38,759): values[i] = d^2/n, grads[i] = loss_scale*2d/n (half),
  * *loss_sum (device float) = sum of values.  values/grads/loss_sum may each be NULL. */
 int rtxn_l2_loss(const float* pred, const float* target, long n, float loss_scale, float* values, void* grads_half,
@@ -576,6 +594,8 @@ typedef struct rtxn_train_batch {
   int skip_table_backward;          /* hash grid: != 0 stops after network->backward (dparams and dencT complete): the caller
                                        runs rtxn_hashgrid_backward_segments[_live] itself -- data parallel: after handing the MLP
                                        gradient to its all-reduce, which then runs beside the scatter */
+  int workspace_lean;               /* != 0: `workspace` is a LEAN workspace (rtxn_mlp_train_lean_workspace_bytes; models with
+                                       rtxn_mlp_train_lean_supported): no activations are saved, the weight gradient recomputes them */
 } rtxn_train_batch;
 int rtxn_train_gradients(const rtxn_train_batch* batch, rtxn_stream_t stream);
 

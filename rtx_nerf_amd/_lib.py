@@ -92,7 +92,7 @@ class TrainBatch(C.Structure):
                 ("radiance", C.c_void_p), ("t_vals", C.c_void_p), ("radiance_gradients", C.c_void_p),
                 ("pixels", C.c_void_p), ("loss_gradients_half", C.c_void_p), ("loss_sum", C.c_void_p),
                 ("dparams", C.c_void_p), ("dtable", C.c_void_p), ("dtable_hashed_half", C.c_void_p), ("live_ws", C.c_void_p),
-                ("skip_table_backward", C.c_int)]
+                ("skip_table_backward", C.c_int), ("workspace_lean", C.c_int)]
 
 
 class TrainState(C.Structure):
@@ -202,6 +202,10 @@ SYMBOLS = {
     "rtxn_adam_effective_lr": (_F, [_F, _F, _F, _I]),
     "rtxn_adam_step_captured": (_I, [_L, _P, _P, _P, _I, _P, _P, _P, _F, _F, _F, _F, _P]),
     "rtxn_adam_step_sparse": (_I, [_L, _P, _P, _P, _I, _P, _P, _P, _F, _F, _F, _F, _F, _P]),
+    "rtxn_mlp_train_lean_supported": (_I, [_P]),
+    "rtxn_mlp_train_lean_workspace_bytes": (C.c_size_t, [_P, _L]),
+    "rtxn_mlp_train_forward_lean": (_I, [_P, _P, _L, _P, _P, _P, _P]),
+    "rtxn_mlp_train_backward_lean": (_I, [_P, _P, _P, _P, _L, _P, _P, _P, _P]),
     "rtxn_train_gradients": (_I, [C.POINTER(TrainBatch), _P]),
     "rtxn_train_step": (_I, [C.POINTER(TrainStepArgs), _P]),
     "rtxn_live_segments_workspace_bytes": (C.c_size_t, [_L]),

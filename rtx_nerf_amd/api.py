@@ -526,6 +526,42 @@ def _net_train_forward_live(self, encT, n, workspace, live_ws):
                                                  _ptr(live_ws, None, "live_ws"), _stream()), "rtxn_mlp_train_forward_live")
 
 
+def _net_lean_supported(self):
+    """True for models with the lean training path (the reference's 8 x 128 model): no saved activations, the weight gradient
+    recomputes them (rtxn_mlp_train_lean_supported)."""
+    return bool(_lib.lib().rtxn_mlp_train_lean_supported(self._h))
+
+
+def _net_train_lean_workspace(self, n, device="cuda"):
+    nbytes = _lib.lib().rtxn_mlp_train_lean_workspace_bytes(self._h, n)
+    if nbytes == 0:
+        raise _lib.RtxnError("train_lean_workspace: this model has no lean path")
+    return torch.empty(nbytes // 2, dtype=torch.float16, device=device)
+
+
+def _net_train_forward_lean(self, encT, n, workspace, output=None, radiance=None):
+    """network->forward keeping outputs + sign masks only (rtxn_mlp_train_forward_lean)."""
+    if output is None:
+        output = torch.empty((n, 16), dtype=torch.float16, device=encT.device)
+    check(_lib.lib().rtxn_mlp_train_forward_lean(self._h, _ptr(encT, torch.float16, "encT"), n, _ptr(workspace, torch.float16, "workspace"),
+                                                 _ptr(output, torch.float16), _ptr(radiance, torch.float32, "radiance"), _stream()),
+          "rtxn_mlp_train_forward_lean")
+    return output
+
+
+def _net_train_backward_lean(self, encT, output, dout, n, workspace, dparams, live_ws=None):
+    """network->backward on the lean workspace: dgrad chain + weight gradient with recomputed activations."""
+    check(_lib.lib().rtxn_mlp_train_backward_lean(self._h, _ptr(encT, torch.float16, "encT"), _ptr(output, torch.float16, "output"),
+                                                  _ptr(dout, torch.float16, "dout"), n, _ptr(workspace, torch.float16, "workspace"),
+                                                  _ptr(live_ws, None, "live_ws"), _ptr(dparams, torch.float32, "dparams"), _stream()),
+          "rtxn_mlp_train_backward_lean")
+    return dparams
+
+
+Network.lean_supported = _net_lean_supported
+Network.train_lean_workspace = _net_train_lean_workspace
+Network.train_forward_lean = _net_train_forward_lean
+Network.train_backward_lean = _net_train_backward_lean
 Network.train_forward_live = _net_train_forward_live
 Network.train_backward_recompute_live = _net_train_backward_recompute_live
 Network.train_backward_live = _net_train_backward_live
@@ -596,7 +632,8 @@ def adam_step_sparse(master, params_fp16, grads, m, v, param_steps, lr=1e-3, bet
 def train_gradients(net, *, grid=None, n_dir_freqs=0, table=None, start_points, end_points, seg_view, num_stored, indices,
                     total_segments, segment_capacity, n_rays, sample_type, t_scale=1.0, vr_mode, targets, loss_scale,
                     encT, dencT=None, workspace=None, output_half, radiance, t_vals, radiance_gradients, pixels, loss_gradients,
-                    loss_sum=None, dparams, dtable=None, dtable_hashed_half=None, live_ws=None, skip_table_backward=False):
+                    loss_sum=None, dparams, dtable=None, dtable_hashed_half=None, live_ws=None, skip_table_backward=False,
+                    workspace_lean=False):
     """rtxn_train_gradients: sampler ... backward of one batch with the segment count taken on the device (main.cu:703-781)."""
     b = train_batch(**{k: v for k, v in locals().items()})
     check(_lib.lib().rtxn_train_gradients(C.byref(b), _stream()), "rtxn_train_gradients")
@@ -605,7 +642,8 @@ def train_gradients(net, *, grid=None, n_dir_freqs=0, table=None, start_points, 
 def train_batch(net, *, grid=None, n_dir_freqs=0, table=None, start_points, end_points, seg_view, num_stored, indices,
                 total_segments, segment_capacity, n_rays, sample_type, t_scale=1.0, vr_mode, targets, loss_scale,
                 encT, dencT=None, workspace=None, output_half, radiance, t_vals, radiance_gradients, pixels, loss_gradients,
-                loss_sum=None, dparams, dtable=None, dtable_hashed_half=None, live_ws=None, skip_table_backward=False):
+                loss_sum=None, dparams, dtable=None, dtable_hashed_half=None, live_ws=None, skip_table_backward=False,
+                workspace_lean=False):
     """struct rtxn_train_batch over the given tensors (which the caller keeps alive), sizes checked against the capacity."""
     b = _lib.TrainBatch()
     b.mlp, b.grid = net._h, (grid._h if grid is not None else None)
@@ -629,6 +667,7 @@ def train_batch(net, *, grid=None, n_dir_freqs=0, table=None, start_points, end_
         raise _lib.RtxnError("train_gradients: live_ws smaller than live_segments_workspace_bytes(segment_capacity)")
     b.live_ws = _ptr(live_ws, None, "live_ws")
     b.skip_table_backward = 1 if skip_table_backward else 0
+    b.workspace_lean = 1 if workspace_lean else 0
     for nm, t, need in (("encT", encT, net.encoded_width() * padded_samples(32 * int(segment_capacity))),
                         ("output_half", output_half, 32 * int(segment_capacity) * 16), ("radiance", radiance, 32 * int(segment_capacity) * 4),
                         ("t_vals", t_vals, 32 * int(segment_capacity)), ("radiance_gradients", radiance_gradients, 32 * int(segment_capacity) * 4),

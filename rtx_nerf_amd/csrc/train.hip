@@ -31,6 +31,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 
@@ -477,9 +478,12 @@ __device__ __forceinline__ void store_fragment_rows_pair(_Float16* X, int kk, lo
   }
 }
 
-// SAVE = false: outputs only (no activations, no masks): the forward half of the recompute path, whose backward
-// (mlp_bwd_fused64_kernel) rebuilds the activations in registers from the encoded input.
-template <int W, bool SAVE = true>
+// SAVE = kSaveNone: outputs only (no activations, no masks): the forward half of the recompute path, whose backward
+// (mlp_bwd_fused64_kernel) rebuilds the activations in registers from the encoded input.  kSaveMasks: outputs + the 16-byte
+// sign masks per sample and layer and nothing else -- the forward of the LEAN 128-wide path (below: the dgrad chain needs
+// only the masks, the weight-gradient kernel recomputes the activations): 160 instead of 2,208 bytes written per sample.
+constexpr int kSaveNone = 0, kSaveAll = 1, kSaveMasks = 2;
+template <int W, int SAVE = kSaveAll>
 __global__ __launch_bounds__(kThreads, 2) void mlp_train_fwd_kernel(TrainArgs a) {
   constexpr int RT = W / 32, KS = W / 16;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -551,15 +555,17 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_train_fwd_kernel(TrainArgs a)
   // per-store select, nor one-instruction stores, nor store_fragment_rows_pair's 4-byte form changed the time:
   // profiles/r03/train_store_paths.txt)
   auto save_acts = [&](int l, const half8 (&v)[KS][2]) {
-    if constexpr (!SAVE) return;
-    _Float16* dst = a.acts + (long)l * W * a.Sp;
+    if constexpr (SAVE == kSaveNone) return;
+    if constexpr (SAVE == kSaveAll) {
+      _Float16* dst = a.acts + (long)l * W * a.Sp;
 #pragma unroll
-    for (int kk = 0; kk < KS; ++kk)
+      for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
+        for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (store_s[ct]) *row_elem(dst, perm_feature(kk, 0, j), a.Sp, lane_off[ct]) = ok_s[ct] ? v[kk][ct][j] : (_Float16)0.0f;
+          for (int j = 0; j < 8; ++j)
+            if (store_s[ct]) *row_elem(dst, perm_feature(kk, 0, j), a.Sp, lane_off[ct]) = ok_s[ct] ? v[kk][ct][j] : (_Float16)0.0f;
+    }
     // sign masks for the backward chain (mlp_bwd_kernel, see there): values are post-ReLU (>= 0), so "> 0" is "the half is
     // not +0"
 #pragma unroll
@@ -1485,6 +1491,377 @@ __global__ __launch_bounds__(kThreads) void wgrad_lds_kernel(WgradArgs a) {
       }
 }
 
+// ------------------------------------------------------------------------- lean path (128 wide): weight gradient, activations recomputed
+// The saved-activation path above moves 8.8 KB per sample through HBM (forward: 2 KB of activations out; dgrad: 2 KB of dZ
+// out; weight gradient: both back in) and its three kernels run at the streaming rate of those bytes.  The lean
+// path keeps dZ and drops the activations: the forward writes outputs + sign masks only (mlp_train_fwd_kernel<128, kSaveMasks>),
+// the dgrad chain is mlp_bwd_kernel as it stands (it reads the masks, writes dZ), and THIS kernel forms
+//   dW_l += dZ_l A_{l-1}^T
+// from dZ streamed out of HBM once and A_{l-1} RECOMPUTED from the encoded input, layer by layer in forward order, so that no
+// activation is ever stored: 5.4 KB per sample instead of 8.8 (the encoding is read once per pass), a workspace of 2.2 instead
+// of 4.3 KB per sample.
+//   * One persistent block of four waves per CU (one wave per SIMD, 512 registers); a block tile is 256 samples, a wave owns 64
+//     of them through the forward chain exactly as in the other training kernels (two 32-column tiles, activations in
+//     registers as the next layer's B fragments).
+//   * dW_l = 128 x 128 fp32 = 64 KiB; wave w owns quadrant (w >> 1, w & 1) of every layer of the pass in AGPRs (4 tiles x 16
+//     registers per layer).  The model's gradient therefore takes several passes of this kernel, each recomputing the forward as
+//     far as its layers need: as shipped THREE -- layers 0-2 (forward through layer 1), 3-5 (through 4), 6-7 + the output
+//     layer (through 7): 15 layer-forwards = 1.9 forward passes of recompute, 192 AGPRs.  Four layers per pass (two passes, 1.4
+//     forward passes) fill all 256 AGPRs and hipcc then spills accumulator tiles around the tile loop (-DRTXN_LEAN_TWO_PASS).
+//     The output layer's 16 x 128 gradient is accumulated in 8 KiB of LDS (ds_add_f32, 8 per thread and tile).
+//   * The contraction runs over samples -- the LANE index of the chain's fragments -- so each wave drops A_{l-1} into a
+//     [sample][feature] LDS image (rows of 328 bytes: conflict-free ds_write_b64, the transposing ds_read_b64_tr_b16 two-way on 3
+//     of 32 lanes) and the B operands come back through the transposing read (as mlp_bwd_fused64_kernel); only two images fit, so
+//     a layer's contraction runs in two halves (waves 0, 1 write, all contract; waves 2, 3 write, all contract).
+//   * dZ_l arrives by LDS-DMA in stages of 64 samples x 128 rows (whole 128-byte lines, source-side bank swizzle: the layout of
+//     wgrad_lds_kernel) through a ring of four 16-KiB slots, three stages in flight; a stage is retired by a counted
+//     `s_waitcnt vmcnt(K)` + barrier.  The order of every wave's vector-memory operations is static, so each K is a constant:
+//     the operations issued after the awaited stage -- the two younger stages (8) and, where it was issued in between, the next
+//     layer's weight fetch (8; 7 for layer 0).  At a tile boundary more has been issued than K assumes, which only waits longer.
+//     A block with no further tile issues its look-ahead stages anyway (re-reading its last tile) so that the count holds.
+//   * Tiles whose loss gradients are all zero (mlp_bwd_kernel's live_tiles: it writes no dZ for them) are stepped over.
+constexpr int kLnStr = 328;                   // bytes per sample row of an X image: 256 + 72 (72 = 8 x 9: rows land 9 bank pairs apart)
+constexpr int kLnImg = 64 * kLnStr;           // one wave's 64 samples
+constexpr int kLnStage = 16 * 1024;           // 128 rows x 128 B
+constexpr int kLnOffW = 0;                    // one layer's forward weights (32 KiB)
+constexpr int kLnOffRing = 32 * 1024;
+constexpr int kLnOffX = kLnOffRing + 4 * kLnStage;
+constexpr int kLnOffOL = kLnOffX + 2 * kLnImg;   // dZ of the output layer, 16 rows x 256 samples
+constexpr int kLnOffAcc = kLnOffOL + 8192;       // fp32 [16][128]: the output layer's gradient of this block
+constexpr int kLnLds = kLnOffAcc + 8192;
+static_assert(kLnLds <= 160 * 1024, "LDS");
+static_assert(kLnStr % 8 == 0 && kLnOffX % 16 == 0 && kLnOffOL % 16 == 0, "alignment of the transposing and 16-byte reads");
+
+struct LeanArgs {
+  const uint8_t* packed_fwd;   // packed_train
+  int out_act;
+  long S, Sp;
+  DevCount dc;
+  int n_tiles;
+  const _Float16* encT;        // [E][Sp]
+  const _Float16* dz;          // [L][128][Sp]   (COMPACT with the live list, as mlp_bwd_kernel writes it)
+  const _Float16* dzL;         // [16][Sp]
+  float* dparams;              // tcnn layout, accumulated into
+  const uint8_t* live_tiles;   // [tiles]: mlp_bwd_kernel's; a tile with 0 has no dZ
+  const int* live_list;
+  const int* live_count;
+};
+
+template <int N>
+__device__ __forceinline__ void ln_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// L0 <= l < L1: the layers whose gradient this pass accumulates (at most 4); OUT: also the output layer (then L1 == LTOT)
+template <int KS0, int L0, int L1, bool OUT, int LTOT>
+__global__ __launch_bounds__(kThreads, 1) void wgrad_recompute_kernel(LeanArgs a) {
+  constexpr int W = 128, RT = 4, KS = 8, NL = L1 - L0;
+  constexpr int FWD_END = OUT ? LTOT : L1 - 1;            // forward layers 0 .. FWD_END-1 are recomputed
+  static_assert(NL >= 1 && NL <= 4 && L0 >= 0 && L1 <= LTOT && (!OUT || L1 == LTOT), "pass layout");
+  static_assert(KS0 >= 1 && KS0 <= KS, "encoded width");
+  constexpr int W0_OPS = (KS0 * RT + 3) / 4;              // stage_rt's LDS-DMA instructions per wave for layer 0; 8 for a hidden layer
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tm = wave >> 1, tn = wave & 1;
+  if (a.dc.total_segments) {
+    a.S = live_samples(a.dc, a.S);
+    a.n_tiles = (int)(padded_dev(a.S) / kTile);
+  }
+  const int live_n = a.live_list ? *a.live_count : 0;
+  if (a.live_list) a.n_tiles = (live_n + 7) / 8;
+  // tiles blockIdx.x, + gridDim.x, ...; dead ones stepped over (scalar loads: nothing of this may enter the vector-memory queue)
+  auto next_live = [&](int t) -> int {
+    while (t < a.n_tiles) {
+      int word;
+      const uint8_t* p = a.live_tiles + (t & ~3);
+      asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(word) : "s"(p) : "memory");
+      if ((word >> (8 * (t & 3))) & 0xff) break;
+      t += (int)gridDim.x;
+    }
+    return t;
+  };
+  int tile = next_live((int)blockIdx.x);
+  if (tile >= a.n_tiles) return;
+
+  uint8_t* const ring = smem + kLnOffRing;
+  uint8_t* const ximg = smem + kLnOffX;
+  float* const oacc = reinterpret_cast<float*>(smem + kLnOffAcc);
+  if (OUT) {
+    for (int i = tid; i < 16 * W; i += kThreads) oacc[i] = 0.0f;
+  }
+  // ---- fixed per-lane address parts ----
+  // dZ stage fill: this wave's pieces are image rows 32 wave + 8 i + (lane >> 3), i = 0..3; lane slot (lane & 7) of a row holds
+  // the 16-byte sample group (lane & 7) ^ ((row >> 1) & 7)
+  // The address of a piece is split into a wave-uniform part (layer, tile, the piece's first row: scalar registers) and ONE
+  // 32-bit per-lane byte offset per piece parity (row (lane >> 3) of the piece, sample group): the saddr + voffset form.  Formed
+  // as 64-bit per-lane pointers they are loop-invariant per (layer, piece), and hipcc hoisted a hundred of them out of the tile
+  // loop (see mlp_bwd_kernel's mask_pack_store): the row stride is laundered through an empty asm per call.
+  const unsigned fill_off[2] = {(unsigned)(((long)(lane >> 3) * a.Sp + 8 * ((lane & 7) ^ (lane >> 4))) * 2),
+                                (unsigned)(((long)(lane >> 3) * a.Sp + 8 * ((lane & 7) ^ (4 + (lane >> 4)))) * 2)};
+  auto issue_stage = [&](int slot, int layer, long s0) {
+    long Sp_l = a.Sp;
+    asm volatile("" : "+s"(Sp_l));
+    const _Float16* dz_l = a.dz;
+    asm volatile("" : "+s"(dz_l));
+    const char* base = reinterpret_cast<const char*>(dz_l + ((long)layer * W + 32 * wave) * Sp_l + s0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + fill_off[i & 1]),
+                                       (__attribute__((address_space(3))) void*)(ring + slot * kLnStage + (wave * 4 + i) * 1024), 16, 0, 0);
+      base += 16 * Sp_l;                                  // 8 rows on
+    }
+  };
+  // output layer's dZ: wave w fetches its own 64 samples, rows 0-7 and 8-15, into sub-image w (2 KiB, same row-major swizzle)
+  auto issue_ol = [&](long s0) {
+    long Sp_l = a.Sp;
+    asm volatile("" : "+s"(Sp_l));
+    const _Float16* dz_l = a.dzL;
+    asm volatile("" : "+s"(dz_l));
+    const char* base = reinterpret_cast<const char*>(dz_l + s0 + 64 * wave);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + fill_off[i]),
+                                       (__attribute__((address_space(3))) void*)(smem + kLnOffOL + wave * 2048 + i * 1024), 16, 0, 0);
+      base += 16 * Sp_l;
+    }
+  };
+  // fragment (k-step ks) of lane (h, r = col): row 32 q + r, 16-byte slot (2 ks + h) ^ ((r >> 1) & 7); row group q at + q * 4096
+  int frag_off[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) frag_off[ks] = col * 128 + 16 * ((2 * ks + h) ^ ((col >> 1) & 7));
+  // X images: see mlp_bwd_fused64_kernel (tr_operand / write_frag), row stride kLnStr
+  const unsigned lane_tr = (unsigned)((8 * h + ((lane & 15) >> 2)) * kLnStr + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2);
+  const unsigned lane_wr = (unsigned)(col * kLnStr + 8 * h);
+  auto write_image = [&](uint8_t* image, const half8 (&v)[KS][2]) {
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        uint8_t* p = image + lane_wr + ct * 32 * kLnStr + kk * 32;
+        *reinterpret_cast<half4v*>(p) = __builtin_shufflevector(v[kk][ct], v[kk][ct], 0, 1, 2, 3);
+        *reinterpret_cast<half4v*>(p + 16) = __builtin_shufflevector(v[kk][ct], v[kk][ct], 4, 5, 6, 7);
+      }
+  };
+  auto x_operand = [&](const uint8_t* image, int t, int ks) -> half8 {
+    const uint8_t* p = image + lane_tr + (16 * ks) * kLnStr + 64 * t;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * kLnStr));
+    const half4v l4 = __builtin_bit_cast(half4v, lo), h4 = __builtin_bit_cast(half4v, hi);
+    return __builtin_shufflevector(l4, h4, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+
+  // the gradient quadrants: AGPRs for the whole kernel, touched only by the asm MFMAs below and the final atomics
+  floatx16 acc[NL][4];
+#pragma unroll
+  for (int i = 0; i < NL; ++i)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][t][e] = 0.0f;
+
+  // 64 samples of the contraction: dZ stage in ring slot `slot`, X image `image`
+  auto contract = [&](floatx16 (&q)[4], int slot, const uint8_t* image) {
+    const uint8_t* st = ring + slot * kLnStage;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const half8 a0 = *reinterpret_cast<const half8*>(st + frag_off[ks] + (2 * tm) * 4096);
+      const half8 a1 = *reinterpret_cast<const half8*>(st + frag_off[ks] + (2 * tm + 1) * 4096);
+      const half8 b0 = x_operand(image, 2 * tn, ks);
+      const half8 b1 = x_operand(image, 2 * tn + 1, ks);
+      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(q[0]) : "v"(a0), "v"(b0));
+      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(q[1]) : "v"(a0), "v"(b1));
+      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(q[2]) : "v"(a1), "v"(b0));
+      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(q[3]) : "v"(a1), "v"(b1));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // ---- ring prologue: the first three stages of the first tile ----
+#pragma unroll
+  for (int v = 0; v < 3; ++v) issue_stage(v, L0, (long)tile * kTile + 64 * v);
+
+  while (tile < a.n_tiles) {
+    const int nxt_tile = next_live(tile + (int)gridDim.x);
+    const int look = nxt_tile < a.n_tiles ? nxt_tile : tile;       // no further tile: the look-ahead stages re-read this one (unused)
+    const long tile0 = (long)tile * kTile + wave * 64;
+    unsigned lane_off[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      long sidx = tile0 + ct * 32 + col;
+      if (a.live_list) {
+        const int slot = tile * 8 + wave * 2 + ct;
+        sidx = (long)(slot < live_n ? a.live_list[slot] : 0) * 32 + col;     // slots past the list read segment 0; their dZ is zero
+      }
+      lane_off[ct] = (unsigned)((sidx + 4L * h * a.Sp) * 2);
+    }
+    // ---- encoded input as B fragments (k-steps >= KS0: zeros, the padding columns of dW_0's operand) ----
+    // (pointers and the row stride are laundered once per tile: as loop invariants of this persistent loop hipcc formed every
+    // row address of the encoding and every per-lane source address of the weight fetches ahead of it -- 330 spilled registers)
+    long Sp_t = a.Sp;
+    const _Float16* enc_t = a.encT;
+    asm volatile("" : "+s"(Sp_t), "+s"(enc_t));
+    half8 cur[KS][2], nxt[KS][2];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        half8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.0f;
+        if (kk < KS0) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = *row_elem(enc_t, perm_feature(kk, 0, j), Sp_t, lane_off[ct]);
+        }
+        cur[kk][ct] = v;
+      }
+    // one layer: [weight gradient of layer l from A_{l-1} = cur] then [forward: cur = relu(W_l cur)]; l is a compile-time constant
+    auto layer_step = [&](auto LC) {
+      constexpr int l = decltype(LC)::value;
+      constexpr bool has_w = l >= L0 && l < L1, has_f = l < FWD_END;
+      if constexpr (has_w || has_f) {
+        constexpr int wbytes = (l == 0 ? KS0 : KS) * RT * 1024;
+        constexpr long woff = l == 0 ? 0 : (long)(KS0 + (l - 1) * KS) * RT * 1024;
+        __syncthreads();                                  // everyone is done with the weights of layer l-1 and with the X images
+        if constexpr (has_f) {
+          const uint8_t* pf = a.packed_fwd;
+          asm volatile("" : "+s"(pf));
+          stage_rt(pf + woff, smem + kLnOffW, wbytes, tid);
+        }
+        if constexpr (has_w) {
+          constexpr int li = l - L0;
+          // what has entered this wave's vector-memory queue behind the stage being retired: the two younger stages and, for v = 0..2,
+          // this layer's weight fetch (v = 3's stage was issued behind it: that wait also lands the weights)
+          constexpr int K012 = 8 + (has_f ? (l == 0 ? W0_OPS : 8) : 0);
+          // stage issued three ahead of the one being retired: (l, 3) at v = 0, then layer l + 1's -- or the next tile's first layer's -- v - 1
+          auto look_ahead = [&](int v) {
+            if (v == 0) issue_stage(3, l, (long)tile * kTile + 64 * 3);
+            else if (l + 1 < L1) issue_stage(v - 1, l + 1, (long)tile * kTile + 64 * (v - 1));
+            else issue_stage(v - 1, L0, (long)look * kTile + 64 * (v - 1));
+          };
+          if (wave < 2) write_image(ximg + wave * kLnImg, cur);
+          ln_wait_vm<K012>();
+          __syncthreads();                                // stage (l, 0) and the images of waves 0, 1 are everyone's
+          look_ahead(0);
+          if constexpr (OUT && l == LTOT - 1) issue_ol((long)tile * kTile);
+          contract(acc[li], 0, ximg);
+          ln_wait_vm<K012>();
+          __syncthreads();
+          look_ahead(1);
+          contract(acc[li], 1, ximg + kLnImg);
+          __syncthreads();                                // both images have been read by everyone
+          if (wave >= 2) write_image(ximg + (wave - 2) * kLnImg, cur);
+          ln_wait_vm<K012>();
+          __syncthreads();
+          look_ahead(2);
+          contract(acc[li], 2, ximg);
+          ln_wait_vm<8>();
+          __syncthreads();
+          look_ahead(3);
+          contract(acc[li], 3, ximg + kLnImg);
+        } else {
+          rtxn::staged_barrier();
+        }
+        if constexpr (has_f) {
+          const uint8_t* wl = smem + kLnOffW;
+          if constexpr (l == 0) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+              floatx16 f[2];
+#pragma unroll
+              for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) f[ct][e] = 0.0f;
+#pragma unroll
+              for (int kk = 0; kk < KS0; ++kk) {
+                const half8 af = *reinterpret_cast<const half8*>(wl + ((rt * KS0 + kk) * 64 + lane) * 16);
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) f[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, cur[kk][ct], f[ct], 0, 0, 0);
+              }
+#pragma unroll
+              for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) nxt[2 * rt + s2][ct] = pack8<true>(f[ct], s2);
+            }
+          } else {
+            floatx16 acc2[2][2];
+            rtxn::pipe_layer<RT, KS, KS>(wl, cur, nxt, acc2, lane);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+              for (int ct = 0; ct < 2; ++ct) nxt[2 * (RT - 1) + s2][ct] = rtxn::relu_pack(acc2[1][ct], s2);
+          }
+#pragma unroll
+          for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) cur[kk][ct] = nxt[kk][ct];
+        }
+      }
+    };
+    layer_step(std::integral_constant<int, 0>{});
+    layer_step(std::integral_constant<int, 1>{});
+    layer_step(std::integral_constant<int, 2>{});
+    layer_step(std::integral_constant<int, 3>{});
+    layer_step(std::integral_constant<int, 4>{});
+    layer_step(std::integral_constant<int, 5>{});
+    layer_step(std::integral_constant<int, 6>{});
+    layer_step(std::integral_constant<int, 7>{});
+    static_assert(LTOT <= 8, "layer_step is spelled out for eight layers");
+    if (OUT) {
+      // ---- output layer: dW_L[16 x 128] += dZ_L A_{L-1}^T; wave w: columns 32 w .. 32 w + 31, rows 0-15 of a 32-row tile ----
+      floatx16 o;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[e] = 0.0f;
+      auto contract_ol = [&](int v, const uint8_t* image) {
+        const uint8_t* st = smem + kLnOffOL + v * 2048;   // lanes with col >= 16 read past the 16 rows: rows 16-31 of the product, never stored
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const half8 a0 = *reinterpret_cast<const half8*>(st + frag_off[ks]);
+          const half8 b0 = x_operand(image, wave, ks);
+          o = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, o, 0, 0, 0);
+        }
+      };
+      __syncthreads();
+      if (wave < 2) write_image(ximg + wave * kLnImg, cur);
+      ln_wait_vm<12>();                                   // behind the output layer's dZ: the three look-ahead stages of the last layer
+      __syncthreads();
+      contract_ol(0, ximg);
+      contract_ol(1, ximg + kLnImg);
+      __syncthreads();
+      if (wave >= 2) write_image(ximg + (wave - 2) * kLnImg, cur);
+      __syncthreads();
+      contract_ol(2, ximg);
+      contract_ol(3, ximg + kLnImg);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int orow = (e & 3) + 8 * (e >> 2) + 4 * h;  // < 16
+        atomicAdd(&oacc[orow * W + 32 * wave + col], o[e]);
+      }
+    }
+    tile = nxt_tile;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the last look-ahead stages land in LDS this block still owns
+  __syncthreads();
+  // ---- one pass of atomics per wave: its quadrant of every layer of the pass ----
+  const int E = KS0 * 16;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int l = L0 + i;
+    const int N = l == 0 ? E : W;
+    float* dW = a.dparams + (l == 0 ? 0L : (long)W * E + (long)(l - 1) * W * W);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int orow = 64 * tm + 32 * (t >> 1) + (e & 3) + 8 * (e >> 2) + 4 * h, c = 64 * tn + 32 * (t & 1) + col;
+        if (c < N && acc[i][t][e] != 0.0f) atomicAdd(&dW[(long)orow * N + c], acc[i][t][e]);
+      }
+  }
+  if (OUT) {
+    float* dW = a.dparams + (long)W * E + (long)(LTOT - 1) * W * W;
+    for (int i = tid; i < 16 * W; i += kThreads)
+      if (oacc[i] != 0.0f) atomicAdd(&dW[i], oacc[i]);
+  }
+}
+
 // ------------------------------------------------------------------------- segments that carry a loss gradient
 // In NeRF training most samples lie behind the first surface, where the transmittance and with it dL/d(radiance) is exactly
 // zero (configs[2] batch: 12 % of the samples, 30 % of the 64-sample waves carry a gradient).  The backward kernels do not
@@ -1813,9 +2190,10 @@ static hipError_t set_lds_once(const void* fn, int bytes) {
 }
 
 // workspace == NULL: outputs only (the forward half of the recompute path)
+// lean: `workspace` is the lean workspace (rtxn_mlp_train_lean_workspace_bytes): outputs + sign masks, no activations
 static int train_forward_impl(const rtxn_mlp* m, const void* encT, long n_samples, void* workspace, void* output_half,
                               float* radiance, DevCount dc, rtxn_stream_t stream, const int* live_list = nullptr,
-                              const int* live_count = nullptr) {
+                              const int* live_count = nullptr, bool lean = false) {
   const int W = m->cfg.n_neurons;
   const long Sp = padded(n_samples);
   // outputs only, 64 wide: the all-asm 16x16x32 kernel with the weights resident in LDS (hashmlp.hip) -- the same layer stack
@@ -1834,7 +2212,9 @@ static int train_forward_impl(const rtxn_mlp* m, const void* encT, long n_sample
   a.Sp = Sp;
   a.dc = dc;
   a.encT = static_cast<const _Float16*>(encT);
-  if (workspace) {
+  if (workspace && lean) {
+    a.masks = reinterpret_cast<unsigned long long*>(static_cast<_Float16*>(workspace) + ((long)m->cfg.n_hidden_layers * W + 16) * Sp);
+  } else if (workspace) {
     a.acts = static_cast<_Float16*>(workspace);
     a.masks = reinterpret_cast<unsigned long long*>(static_cast<_Float16*>(workspace) + (2L * m->cfg.n_hidden_layers * W + 16) * Sp);
   }
@@ -1851,8 +2231,9 @@ static int train_forward_impl(const rtxn_mlp* m, const void* encT, long n_sample
     RTXN_HIP(set_lds_once(reinterpret_cast<const void*>(mlp_train_fwd_kernel<WW, SAVE>), (int)lds));      \
     hipLaunchKernelGGL((mlp_train_fwd_kernel<WW, SAVE>), grid, block, lds, s, a);                         \
   } while (0)
-  if (W == 64) { if (workspace) RTXN_FWD_LAUNCH(64, true); else RTXN_FWD_LAUNCH(64, false); }
-  else         { if (workspace) RTXN_FWD_LAUNCH(128, true); else RTXN_FWD_LAUNCH(128, false); }
+  if (W == 64) { if (workspace) RTXN_FWD_LAUNCH(64, kSaveAll); else RTXN_FWD_LAUNCH(64, kSaveNone); }
+  else if (lean) RTXN_FWD_LAUNCH(128, kSaveMasks);
+  else         { if (workspace) RTXN_FWD_LAUNCH(128, kSaveAll); else RTXN_FWD_LAUNCH(128, kSaveNone); }
 #undef RTXN_FWD_LAUNCH
   RTXN_LAUNCH_CHECK(workspace ? "mlp_train_fwd_kernel" : "mlp_train_fwd_kernel<outputs only>");
   return RTXN_OK;
@@ -1970,6 +2351,126 @@ extern "C" int rtxn_mlp_train_backward(const rtxn_mlp* m, const void* encT, cons
   if (n_samples == 0) return RTXN_OK;
   RTXN_REQUIRE(encT && output_half && dout_half4 && workspace && dparams, "rtxn_mlp_train_backward: NULL buffer");
   return train_backward_impl(m, encT, output_half, dout_half4, n_samples, workspace, dparams, dencT, DevCount{nullptr, 0}, stream);
+}
+
+// ---- lean path (128-wide models): forward with sign masks only, dgrad chain, weight gradient with recomputed activations ----
+// Workspace (halfs): dz [L][128][Sp] | dzL [16][Sp] | sign masks [L][Sp] x 16 B | one live flag per 256-sample tile.
+extern "C" int rtxn_mlp_train_lean_supported(const rtxn_mlp* m) {
+  if (!m) return 0;
+  return m->cfg.n_neurons == 128 && m->cfg.n_hidden_layers == 8 && m->enc_padded == 112;
+}
+
+extern "C" size_t rtxn_mlp_train_lean_workspace_bytes(const rtxn_mlp* m, long n_samples) {
+  if (!rtxn_mlp_train_lean_supported(m) || n_samples < 0) return 0;
+  const long Sp = padded(n_samples), W = m->cfg.n_neurons, L = m->cfg.n_hidden_layers;
+  return (size_t)((L * W + 16 + 8 * L) * Sp) * sizeof(_Float16) + (size_t)((Sp / kTile + 15) / 16 * 16);
+}
+
+static int train_backward_lean_impl(const rtxn_mlp* m, const void* encT, const void* output_half, const void* dout_half4,
+                                    long n_samples, void* workspace, float* dparams, DevCount dc, rtxn_stream_t stream,
+                                    const int* live_list = nullptr, const int* live_count = nullptr) {
+  const int W = 128, L = m->cfg.n_hidden_layers, E = m->enc_padded;
+  const long Sp = padded(n_samples);
+  _Float16* ws = static_cast<_Float16*>(workspace);
+  TrainArgs a;
+  memset(&a, 0, sizeof(a));
+  a.packed = static_cast<const uint8_t*>(m->packed_t);
+  a.n_hidden = L;
+  a.out_act = m->cfg.output_activation;
+  a.E = E;
+  a.S = n_samples;
+  a.Sp = Sp;
+  a.dc = dc;
+  a.encT = static_cast<const _Float16*>(encT);
+  a.dz = ws;
+  a.dzL = ws + (long)L * W * Sp;
+  a.masks = reinterpret_cast<unsigned long long*>(ws + ((long)L * W + 16) * Sp);
+  a.live_tiles = reinterpret_cast<uint8_t*>(ws + ((long)L * W + 16 + 8L * L) * Sp);
+  a.live_list = live_list;
+  a.live_count = live_count;
+  a.out_half = const_cast<_Float16*>(static_cast<const _Float16*>(output_half));
+  a.dout = static_cast<const _Float16*>(dout_half4);
+  const int RT = W / 32, KS = W / 16;
+  const size_t lds = (size_t)RT * KS * 1024;
+  hipStream_t s = rtxn::as_stream(stream);
+  RTXN_HIP(set_lds_once(reinterpret_cast<const void*>(mlp_bwd_kernel<128>), (int)lds));
+  hipLaunchKernelGGL(mlp_bwd_kernel<128>, dim3((unsigned)(Sp / kTile)), dim3(kThreads), lds, s, a);
+  RTXN_LAUNCH_CHECK("mlp_bwd_kernel");
+  LeanArgs la;
+  memset(&la, 0, sizeof(la));
+  la.packed_fwd = static_cast<const uint8_t*>(m->packed_train);
+  la.out_act = a.out_act;
+  la.S = n_samples;
+  la.Sp = Sp;
+  la.dc = dc;
+  la.n_tiles = (int)(Sp / kTile);
+  la.encT = a.encT;
+  la.dz = a.dz;
+  la.dzL = a.dzL;
+  la.dparams = dparams;
+  la.live_tiles = a.live_tiles;
+  la.live_list = live_list;
+  la.live_count = live_count;
+  int dev = 0, n_cu = 0;
+  RTXN_HIP(hipGetDevice(&dev));
+  RTXN_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  if (n_cu <= 0) n_cu = 256;
+  const int grid = la.n_tiles < n_cu ? la.n_tiles : n_cu;   // persistent: one block per CU (registers and LDS)
+  typedef void (*lean_fn)(LeanArgs);
+  // Three passes: layers 0-2 | 3-5 | 6-7 + output -- 192 accumulator registers per wave, 1.9 forward passes of recompute.  Two
+  // passes (0-3 | 4-7 + output: 1.4 passes of recompute) need all 256 AGPRs for the accumulators, and with none to spare hipcc
+  // spills three accumulator tiles to scratch around the tile loop's back edge (build with -DRTXN_LEAN_TWO_PASS for the A/B;
+  // tests/test_build_quality.py keeps the shipped kernels free of scratch).
+#ifdef RTXN_LEAN_TWO_PASS
+  constexpr int n_pass = 2;
+  static const lean_fn pass[2] = {wgrad_recompute_kernel<7, 0, 4, false, 8>, wgrad_recompute_kernel<7, 4, 8, true, 8>};
+#else
+  constexpr int n_pass = 3;
+  static const lean_fn pass[3] = {wgrad_recompute_kernel<7, 0, 3, false, 8>, wgrad_recompute_kernel<7, 3, 6, false, 8>,
+                                  wgrad_recompute_kernel<7, 6, 8, true, 8>};
+#endif
+  for (int i = 0; i < n_pass; ++i) {
+    RTXN_HIP(set_lds_once(reinterpret_cast<const void*>(pass[i]), kLnLds));
+    hipLaunchKernelGGL(pass[i], dim3((unsigned)grid), dim3(kThreads), kLnLds, s, la);
+    RTXN_LAUNCH_CHECK("wgrad_recompute_kernel");
+  }
+  return RTXN_OK;
+}
+
+static int check_lean(const rtxn_mlp* m, const char* who, long n_samples, bool whole_segments) {
+  int rc = check_train(m, who);
+  if (rc != RTXN_OK) return rc;
+  if (!rtxn_mlp_train_lean_supported(m)) {
+    rtxn::set_error("%s: the lean path is built for the reference's model (128 wide, 8 hidden layers, 112 encoded features); this model: "
+                    "%d wide, %d layers, %d features -- use rtxn_mlp_train_forward + rtxn_mlp_train_backward", who, m->cfg.n_neurons,
+                    m->cfg.n_hidden_layers, m->enc_padded);
+    return RTXN_ERR_UNSUPPORTED;
+  }
+  RTXN_REQUIRE(n_samples >= 0 && n_samples <= kMaxTrainSamples && (!whole_segments || n_samples % 32 == 0),
+               "%s: n_samples = %ld out of [0, %ld]%s", who, n_samples, kMaxTrainSamples, whole_segments ? " or not whole segments" : "");
+  return RTXN_OK;
+}
+
+extern "C" int rtxn_mlp_train_forward_lean(const rtxn_mlp* m, const void* encT, long n_samples, void* workspace_lean,
+                                           void* output_half, float* radiance, rtxn_stream_t stream) {
+  int rc = check_lean(m, "rtxn_mlp_train_forward_lean", n_samples, false);
+  if (rc != RTXN_OK) return rc;
+  RTXN_DEVICE_OR_FAIL();
+  if (n_samples == 0) return RTXN_OK;
+  RTXN_REQUIRE(encT && workspace_lean && output_half, "rtxn_mlp_train_forward_lean: NULL buffer");
+  return train_forward_impl(m, encT, n_samples, workspace_lean, output_half, radiance, DevCount{nullptr, 0}, stream, nullptr, nullptr, true);
+}
+
+extern "C" int rtxn_mlp_train_backward_lean(const rtxn_mlp* m, const void* encT, const void* output_half, const void* dout_half4,
+                                            long n_samples, void* workspace_lean, const void* live_ws, float* dparams,
+                                            rtxn_stream_t stream) {
+  int rc = check_lean(m, "rtxn_mlp_train_backward_lean", n_samples, live_ws != nullptr);
+  if (rc != RTXN_OK) return rc;
+  RTXN_DEVICE_OR_FAIL();
+  if (n_samples == 0) return RTXN_OK;
+  RTXN_REQUIRE(encT && output_half && dout_half4 && workspace_lean && dparams, "rtxn_mlp_train_backward_lean: NULL buffer");
+  return train_backward_lean_impl(m, encT, output_half, dout_half4, n_samples, workspace_lean, dparams, DevCount{nullptr, 0}, stream,
+                                  live_ws ? live_list_of(live_ws) : nullptr, live_ws ? live_count_of(live_ws) : nullptr);
 }
 
 // ---- recompute path (64-wide models): forward without saved activations + fused backward ----
@@ -2623,6 +3124,11 @@ extern "C" int rtxn_train_gradients(const rtxn_train_batch* b, rtxn_stream_t str
     RTXN_REQUIRE(m->cfg.encoding == RTXN_ENC_FREQUENCY && m->cfg.n_pos_dims == 3 && m->cfg.n_dir_dims == 2,
                  "rtxn_train_gradients: without a grid the model must carry the 3 + 2 frequency encoding");
   }
+  const bool lean = b->workspace_lean != 0;
+  if (lean) {
+    RTXN_REQUIRE(b->workspace && !hash && rtxn_mlp_train_lean_supported(m), "rtxn_train_gradients: workspace_lean needs a lean workspace and a "
+                 "model with the lean path (rtxn_mlp_train_lean_supported; frequency encoding)");
+  }
   const bool recompute = b->workspace == nullptr;
   if (recompute)
     RTXN_REQUIRE(rtxn_mlp_train_recompute_supported(m), "rtxn_train_gradients: workspace == NULL selects the recompute path, which this model "
@@ -2637,8 +3143,9 @@ extern "C" int rtxn_train_gradients(const rtxn_train_batch* b, rtxn_stream_t str
   if (rc != RTXN_OK) return rc;
   // network->forward (main.cu:721).  Saved-activation models with a live list and the NeRF compositor (whose gradient vanishes
   // behind the first surface): outputs only here, the activations of the live segments are saved after the compositor.
-  const bool two_pass = !recompute && b->live_ws != nullptr && b->vr_mode == RTXN_VR_NERF;
-  rc = train_forward_impl(m, b->encT, cap_samples, two_pass ? nullptr : b->workspace, b->output_half, b->radiance, dc, stream);
+  // (lean: the forward saves 16 bytes of sign masks per sample and layer for EVERY sample -- cheap enough that no second pass is needed)
+  const bool two_pass = !recompute && !lean && b->live_ws != nullptr && b->vr_mode == RTXN_VR_NERF;
+  rc = train_forward_impl(m, b->encT, cap_samples, two_pass ? nullptr : b->workspace, b->output_half, b->radiance, dc, stream, nullptr, nullptr, lean);
   if (rc != RTXN_OK) return rc;
   // launch_volrender_cuda, loss->evaluate, launch_volrender_backward_cuda (main.cu:737-767): per ray, no sample count needed
   if (b->vr_mode == RTXN_VR_NERF) {
@@ -2667,7 +3174,8 @@ extern "C" int rtxn_train_gradients(const rtxn_train_batch* b, rtxn_stream_t str
     rc = train_forward_impl(m, b->encT, cap_samples, b->workspace, nullptr, nullptr, dc, stream, ll, lc);
     if (rc != RTXN_OK) return rc;
   }
-  rc = recompute ? train_backward_recompute_impl(m, b->encT, b->output_half, b->radiance_gradients, cap_samples, b->dparams, b->dencT, dc, stream, ll, lc)
+  rc = lean      ? train_backward_lean_impl(m, b->encT, b->output_half, b->radiance_gradients, cap_samples, b->workspace, b->dparams, dc, stream, ll, lc)
+     : recompute ? train_backward_recompute_impl(m, b->encT, b->output_half, b->radiance_gradients, cap_samples, b->dparams, b->dencT, dc, stream, ll, lc)
                  : train_backward_impl(m, b->encT, b->output_half, b->radiance_gradients, cap_samples, b->workspace, b->dparams,
                                        hash ? b->dencT : nullptr, dc, stream, ll, lc);
   if (rc != RTXN_OK) return rc;

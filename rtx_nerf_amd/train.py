@@ -126,7 +126,12 @@ class Trainer:
         # the full saving forward is HBM-bound on activations of which 70-90 % are never read.  ("compat" mode: the reference's
         # backward has no transmittance factor, every segment is live, one saving pass is the cheaper form.)
         # RTXN_TRAIN_TWO_PASS=0: one saving pass over everything.
-        self.two_pass = (not self.recompute and self.live_segments and mode == "nerf"
+        # The reference's own model (8 x 128, 112 encoded features): the LEAN path (librtxn: rtxn_mlp_train_forward_lean /
+        # _backward_lean) -- the forward keeps outputs + sign masks only, the weight gradient recomputes the activations from the
+        # encoding: 5.1 instead of 8.8 KB moved per sample and half the workspace.  RTXN_TRAIN_LEAN=0: the saved-activation path (A/B).
+        self.lean = (not self.recompute and encoding != "hash" and self.net.lean_supported()
+                     and os.environ.get("RTXN_TRAIN_LEAN", "1") != "0")
+        self.two_pass = (not self.recompute and not self.lean and self.live_segments and mode == "nerf"
                          and os.environ.get("RTXN_TRAIN_TWO_PASS", "1") != "0")
         # ---- per-step buffers at capacity ---------------------------------------------------------
         B = batch_rays
@@ -151,7 +156,12 @@ class Trainer:
         Sp = api.padded_samples(M * K)
         self.encT = torch.empty((E, Sp), dtype=torch.float16, device=d)
         self.dencT = torch.empty((E, Sp), dtype=torch.float16, device=d) if encoding == "hash" else None
-        self.ws = None if self.recompute else self.net.train_workspace(M * K, device=d)   # saved activations | dZ | masks
+        if self.recompute:
+            self.ws = None
+        elif self.lean:
+            self.ws = self.net.train_lean_workspace(M * K, device=d)                        # dZ | masks
+        else:
+            self.ws = self.net.train_workspace(M * K, device=d)                             # saved activations | dZ | masks
         self.out = torch.empty((M * K, 16), dtype=torch.float16, device=d)
         self.radiance = torch.empty((M * K, 4), device=d)
         self.dout = torch.empty((M * K, 4), dtype=torch.float16, device=d)
@@ -225,7 +235,9 @@ class Trainer:
             else:
                 self.net.encode_frequency(self.samples[:S], self.encT)
         with _Stage(self, "mlp_fwd"):
-            if self.recompute or not save:
+            if self.lean:
+                self.net.train_forward_lean(self.encT, S, self.ws, self.out, self.radiance)
+            elif self.recompute or not save:
                 self.net.train_forward_outputs(self.encT, S, self.out, self.radiance)
             else:
                 self.net.train_forward(self.encT, S, self.ws, self.out, self.radiance)
@@ -320,7 +332,10 @@ class Trainer:
             with _Stage(self, "mlp_fwd_live"):       # the activations of the segments the backward is about to visit
                 self.net.train_forward_live(self.encT, S, self.ws, self.live_ws)
         with _Stage(self, "mlp_bwd+wgrad"):
-            if self.live_segments and self.recompute:
+            if self.lean:
+                self.net.train_backward_lean(self.encT, self.out, self.dout, S, self.ws, self.dparams,
+                                             live_ws=self.live_ws if self.live_segments else None)
+            elif self.live_segments and self.recompute:
                 self.net.train_backward_recompute_live(self.encT, self.out, self.dout, S, self.live_ws, self.dparams, self.dencT)
             elif self.live_segments:
                 self.net.train_backward_live(self.encT, self.out, self.dout, S, self.ws, self.live_ws, self.dparams, self.dencT)
@@ -695,7 +710,7 @@ class Trainer:
                                   pixels=self.pixels, loss_gradients=self.loss_grads, loss_sum=self.loss, dparams=self.dparams,
                                   dtable=self.dtable if hash_ else None,
                                   dtable_hashed_half=self.dtable_h if (hash_ and self.hash_fp16) else None,
-                                  live_ws=self.live_ws if self.live_segments else None)
+                                  live_ws=self.live_ws if self.live_segments else None, workspace_lean=self.lean)
         o = a.opt
         o.mlp_master, o.mlp_params_fp16 = self.master.data_ptr(), self.params.data_ptr()
         o.mlp_m, o.mlp_v = self.adam_m.data_ptr(), self.adam_v.data_ptr()
@@ -756,7 +771,8 @@ class Trainer:
                             output_half=self.out, radiance=self.radiance, t_vals=self.t_vals, radiance_gradients=self.dout,
                             pixels=self.pixels, loss_gradients=self.loss_grads, loss_sum=self.loss, dparams=self.dparams,
                             dtable=self.dtable if hash_ else None, dtable_hashed_half=self.dtable_h if (hash_ and self.hash_fp16) else None,
-                            live_ws=self.live_ws if self.live_segments else None, skip_table_backward=self._g_split)
+                            live_ws=self.live_ws if self.live_segments else None, skip_table_backward=self._g_split,
+                            workspace_lean=self.lean)
 
     def _captured_table_bwd(self, k):
         """the hash scatter of set k's batch over the live list the gradient graph left (its count is on the device)"""

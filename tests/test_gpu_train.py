@@ -781,3 +781,124 @@ def test_weight_gradient_is_additive_over_the_batch_at_full_size(gpu, S):
     err = (whole - parts).abs().max().item()
     print(f"additivity: max |whole - parts| = {err:.3e}, largest entry {scale:.3e}")
     assert err <= 2e-5 * scale, (err, scale)        # measured: 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------- lean path (8 x 128)
+def _lean_case(torch, api, n, seed=3, passes=None):
+    rng = np.random.default_rng(seed)
+    W, L, E = 128, 8, 112
+    net = api.Network(n_neurons=W, n_hidden_layers=L, n_encoded_features=E)
+    net.set_params(_dev(torch, scenes.xavier_params_fp16(W, L, E, seed=seed)))
+    Sp = api.padded_samples(n)
+    encT = torch.zeros((E, Sp), dtype=torch.float16, device="cuda")
+    encT[:, :n] = _dev(torch, rng.uniform(-1, 1, (E, n)).astype(np.float16))
+    return net, encT, Sp, rng
+
+
+@pytest.mark.parametrize("n", [256, 700, 5000, 66_000])
+def test_lean_path_equals_the_saved_activation_path(gpu, oracle, n):
+    """the 8 x 128 training backward WITHOUT materialised activations (rtxn_mlp_train_forward_lean: outputs
+    + sign masks; rtxn_mlp_train_backward_lean: dgrad chain + weight gradient with the activations recomputed from the encoding
+    in passes of three layers) against the saved-activation pair on the same inputs: identical outputs and masks (bit for bit: the same
+    forward kernel), identical dZ (the same chain kernel on the same masks), weight gradients equal up to the summation order
+    of fp32 accumulation -- the recomputed activations are the saved ones bit for bit, so the only difference is WHERE partial
+    sums are rounded (per-block register accumulators + one atomic pass against per-chunk atomics): 2e-5 of the gradient's
+    norm and 1e-4 of its largest element.  And against the oracle with the usual training tolerances.  The workspace is half the size."""
+    torch = gpu
+    from rtx_nerf_amd import api
+    net, encT, Sp, rng = _lean_case(torch, api, n)
+    assert net.lean_supported()
+    W, L, E = 128, 8, 112
+    ws = net.train_workspace(n)
+    wl = net.train_lean_workspace(n)
+    assert wl.numel() * 2 < 0.52 * ws.numel() * 2 and wl.numel() * 2 <= (L * W + 16 + 8 * L) * 2 * Sp + Sp // 256 + 64
+    out = net.train_forward(encT, n, ws)
+    out_l = net.train_forward_lean(encT, n, wl)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out_l)
+    masks = ws[(2 * L * W + 16) * Sp:(2 * L * W + 16 + 8 * L) * Sp]
+    masks_l = wl[(L * W + 16) * Sp:(L * W + 16 + 8 * L) * Sp]
+    assert torch.equal(masks.view(torch.int16), masks_l.view(torch.int16))
+    dout = _dev(torch, (rng.standard_normal((n, 4)) * 0.05).astype(np.float16))
+    dp = torch.zeros(net.n_params(), device="cuda")
+    net.train_backward(encT, out, dout, n, ws, dp, None)
+    dpl = torch.zeros(net.n_params(), device="cuda")
+    net.train_backward_lean(encT, out_l, dout, n, wl, dpl)
+    torch.cuda.synchronize()
+    dz = ws[L * W * Sp:(2 * L * W + 16) * Sp]
+    dz_l = wl[:(L * W + 16) * Sp]
+    assert torch.equal(dz.view(torch.int16), dz_l.view(torch.int16))
+    a, b = dp.cpu().numpy(), dpl.cpu().numpy()
+    assert np.isfinite(b).all() and np.abs(a).max() > 0
+    # per layer: a defect confined to one layer must not hide in the norm of the whole gradient
+    off = 0
+    for l in range(L + 1):
+        M, N = (16 if l == L else W), (E if l == 0 else W)
+        ga, gb = a[off:off + M * N], b[off:off + M * N]
+        assert np.linalg.norm(ga) > 0
+        assert np.linalg.norm(ga - gb) <= 2e-5 * np.linalg.norm(ga), f"layer {l}"
+        assert np.abs(ga - gb).max() <= 1e-4 * np.abs(ga).max(), f"layer {l}"
+        off += M * N
+    assert off == a.size and np.all(b[-16 * W:].reshape(16, W)[4:] == 0)
+    # the oracle, from the GPU's own forward state (as test_mlp_train_forward_and_backward)
+    if n <= 5000:
+        params = net.get_params().cpu().numpy() if hasattr(net, "get_params") else scenes.xavier_params_fp16(W, L, E, seed=3)
+        enc = encT[:, :n].T.contiguous().cpu().numpy()
+        acts = ws[:L * W * Sp].reshape(L, W, Sp).cpu().numpy()
+        acts_sm = np.ascontiguousarray(np.transpose(acts[:, :, :n], (0, 2, 1)))
+        want_dp, _ = oracle.mlpe_backward(W, L, 1, params, enc, acts_sm, out.cpu().numpy(), dout.cpu().numpy())
+        assert np.linalg.norm(b - want_dp) < 2e-2 * np.linalg.norm(want_dp)
+        assert np.abs(b - want_dp).max() < 3e-2 * np.abs(want_dp).max()
+    # accumulate semantics
+    net.train_backward_lean(encT, out_l, dout, n, wl, dpl)
+    np.testing.assert_allclose(dpl.cpu().numpy(), 2 * b, rtol=1e-3, atol=1e-6 * np.abs(b).max() + 1e-9)
+
+
+def test_lean_path_over_live_segments_and_dead_tiles(gpu):
+    """The lean backward with a live list (only the listed segments are visited; dZ compact) and with tiles whose loss gradient
+    is all zero (mlp_bwd_kernel writes no dZ for them: the weight-gradient kernel must step over them, also with no list)."""
+    torch = gpu
+    from rtx_nerf_amd import api
+    P, K = 700, 32
+    S = P * K
+    net, encT, Sp, rng = _lean_case(torch, api, S, seed=5)
+    wl = net.train_lean_workspace(S)
+    wl.fill_(float("nan"))                       # whatever the kernels do not write must not be read
+    out = net.train_forward_lean(encT, S, wl)
+    ws = net.train_workspace(S)
+    net.train_forward(encT, S, ws)
+    live = np.zeros(P, bool)
+    live[rng.choice(P, 90, replace=False)] = True
+    live[[0, P - 1]] = True
+    live[8:40] = False                           # four whole dead 256-sample tiles in the list-free run
+    dout = np.zeros((P, K, 4), np.float16)
+    dout[live] = (rng.standard_normal((int(live.sum()), K, 4)) * 0.05).astype(np.float16)
+    dout_d = _dev(torch, dout.reshape(S, 4))
+    want = torch.zeros(net.n_params(), device="cuda")
+    net.train_backward(encT, out, dout_d, S, ws, want, None)
+    got = torch.zeros(net.n_params(), device="cuda")
+    net.train_backward_lean(encT, out, dout_d, S, wl, got)                 # no list: dead tiles skipped by their flags
+    lws = api.live_segments_workspace(P)
+    api.live_segments(dout_d, P, P, lws)
+    assert int(lws[0].item()) == int(live.sum())
+    wl2 = net.train_lean_workspace(S)
+    wl2.fill_(float("nan"))
+    out2 = net.train_forward_lean(encT, S, wl2)
+    got_live = torch.zeros(net.n_params(), device="cuda")
+    net.train_backward_lean(encT, out2, dout_d, S, wl2, got_live, live_ws=lws)
+    torch.cuda.synchronize()
+    for g in (got, got_live):
+        assert bool(torch.isfinite(g).all()) and float(want.norm()) > 0
+        assert float((g - want).norm()) <= 2e-5 * float(want.norm())
+
+
+def test_lean_path_is_refused_for_other_models(gpu):
+    torch = gpu
+    from rtx_nerf_amd import api, _lib
+    net = api.Network(n_neurons=128, n_hidden_layers=3, n_encoded_features=48)
+    net.set_params(_dev(torch, scenes.xavier_params_fp16(128, 3, 48, seed=1)))
+    assert not net.lean_supported()
+    assert _lib.lib().rtxn_mlp_train_lean_workspace_bytes(net._h, 1000) == 0
+    encT = torch.zeros((48, 1024), dtype=torch.float16, device="cuda")
+    with pytest.raises(_lib.RtxnError, match="lean path"):
+        net.train_forward_lean(encT, 1000, torch.zeros(16, dtype=torch.float16, device="cuda"))
