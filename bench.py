@@ -342,22 +342,39 @@ def train_ref_record(batch_rays, grid_res, steps, warmup, dense_grid=True, mode=
     stages = tr.time_stages(*batch(), steps=3)
     live_frac = (float(tr.live_ws[0].item()) * 32 / max(float(tr.total.item()) * 32, 1.0)) if tr.live_segments else 1.0   # of the last batch
     ms = 1e3 * dt / steps
-    flop = 3 * 262144
-    tf = flop * S / (ms * 1e-3) / 1e12
+    # Matrix work and bytes of the MLP kernels AS EXECUTED (per sample of the batch; lf = fraction of segments with a loss gradient):
+    #  lean path (8 x 128: Trainer.lean): forward (all samples) 1 x 262,144 FLOP, 224 B of encoding in, 32 B out, 128 B of sign masks;
+    #    dgrad chain (live) 1 x, 168 B in (masks, dout, outputs), 2,080 B of dZ out; weight gradient (live) 1 x + 15 recomputed
+    #    layer-forwards of 8 (three passes: 2 + 5 + 8) = 2.875 x, 2,080 B of dZ + 3 x 224 B of encoding in;
+    #  saved-activation path: forward 224 + 2,048 + 128 + 32 B (all samples, or outputs-only for all + saving pass for the live
+    #    ones when two_pass), dgrad 168 + 2,080 B, weight gradient 4,096 + 224 + 32 B (live).
+    nominal = 3 * 262144
+    if getattr(tr, "lean", False):
+        path = "lean: sign masks only, weight gradient recomputes the activations (three passes)"
+        flop_exec = 262144 * (1.0 + live_frac * (1.0 + 1.0 + 15.0 / 8.0))
+        bytes_exec = 384 + live_frac * (2248 + 2080 + 3 * 224)
+    else:
+        path = "saved activations" + (" (outputs-only forward + saving pass over the live segments)" if tr.two_pass else "")
+        flop_exec = 262144 * (1.0 + 2.0 * live_frac + (live_frac if tr.two_pass else 0.0))
+        bytes_exec = ((256 + live_frac * 2400) if tr.two_pass else 2432) + live_frac * (2248 + 4352)
+    tf = flop_exec * S / (ms * 1e-3) / 1e12
     rec = {
         "workload": f"{B} rays/batch, 8x128 ReLU MLP + Composite-Frequency(10, 12), REGULAR sampler, "
                     f"{'the reference compositor fwd/bwd (RTXN_VR_COMPAT)' if mode == 'compat' else 'NeRF compositor'}, L2, Adam 1e-3; "
                     f"{R}^3 grid ({'dense, as main.cu:394' if dense_grid else f'Lego stand-in, {100 * occ_frac:.1f}% cells'}), K=32; random targets",
         "ms_per_step": round(ms, 4), "mrays_s": round(B * steps / dt / 1e6, 4), "steps": steps, "warmup": warmup, "samples_per_step": int(S),
         "segment_capacity": cap, "truncated_steps": tr.truncated_steps, "loss_last": float(loss.item()), "step_form": "eager (segment count on the host, as main.cu:632)",
+        "mlp_path": path, "mlp_workspace_gib": round(tr.ws.numel() * 2 / 2 ** 30, 3) if tr.ws is not None else 0.0,
         "stage_ms": {k: round(v, 4) for k, v in stages.items()},
-        "roofline": {"kernels": "mlp_train_fwd_kernel<128> + mlp_bwd_kernel<128> + wgrad_lds_kernel", "bound": "mfma", "achieved": round(tf, 1),
+        "roofline": {"kernels": ("mlp_train_fwd_kernel<128, masks> + mlp_bwd_kernel<128> + wgrad_recompute_all_kernel" if getattr(tr, "lean", False)
+                                 else "mlp_train_fwd_kernel<128> + mlp_bwd_kernel<128> + wgrad_lds_kernel"),
+                     "bound": "mfma", "achieved": round(tf, 1),
                      "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_F16_DENSE_PEAK_TFLOPS, 4),
-                     "flop_per_sample": flop, "samples_per_launch": int(S), "traffic": None,
+                     "flop_executed_per_sample": int(flop_exec), "flop_nominal_per_sample": nominal, "samples_per_launch": int(S), "traffic": None,
                      "live_fraction": round(live_frac, 4),
-                     "flop_executed_per_sample": int(262144 * (1 + 2 * live_frac + (live_frac if tr.two_pass else 0))),
-                     "note": "whole step; the MLP kernels materialise activations, sign masks and dZ (2 B x 128 per sample and layer): "
-                             "8.6 KB per sample over forward, dgrad and wgrad -- mlp_kernels_hbm_floor_gbs is that traffic over their time"},
+                     "note": "whole step; achieved / frac count the matrix work EXECUTED (forward for every sample; dgrad, weight gradient and "
+                             "its recomputed forward layers for the segments that carry a loss gradient); frac_nominal = the asked "
+                             "3 x 262,144 FLOP for every sample whether visited or not"},
     }
     if captured:
         # the same step as ONE hipGraph with the traversal of the next batch beside the gradient kernels (Trainer.capture_step,
@@ -387,21 +404,18 @@ def train_ref_record(batch_rays, grid_res, steps, warmup, dense_grid=True, mode=
         rec["step_form"] = "one hipGraph per step, traversal of the next batch beside the gradient kernels (segment count on the device)"
         rec["truncated_steps"] = tr.truncated_steps
         rec["loss_last_captured"] = float(loss_c.item())
-        tf = flop * S / (ms_c * 1e-3) / 1e12
+        tf = flop_exec * S / (ms_c * 1e-3) / 1e12
         rec["roofline"]["achieved"], rec["roofline"]["frac"] = round(tf, 1), round(tf / MFMA_F16_DENSE_PEAK_TFLOPS, 4)
-    # "frac" is the formula the record was asked for (forward + dgrad + wgrad for EVERY sample); the backward visits only the
-    # segments that carry a loss gradient (and the two-pass forward re-runs those), so the matrix work actually executed is
-    # flop_executed_per_sample -- quoted beside it, never instead
-    rec["roofline"]["frac_executed"] = round(rec["roofline"]["flop_executed_per_sample"] * S / (rec["ms_per_step"] * 1e-3) / 1e12
-                                             / MFMA_F16_DENSE_PEAK_TFLOPS, 4)
+    rec["roofline"]["frac_nominal"] = round(nominal * S / (rec["ms_per_step"] * 1e-3) / 1e12 / MFMA_F16_DENSE_PEAK_TFLOPS, 4)
     mlp_ms = sum(stages.get(k, 0.0) for k in ("mlp_fwd", "mlp_fwd_live", "mlp_bwd+wgrad"))
     if mlp_ms > 0:
+        # the three MLP kernels alone (HIP events around each stage of one more batch): executed FLOP and executed bytes over their time
         rec["roofline"]["mlp_kernels_ms"] = round(mlp_ms, 4)
-        rec["roofline"]["mlp_kernels_frac"] = round(flop * S / (mlp_ms * 1e-3) / 1e12 / MFMA_F16_DENSE_PEAK_TFLOPS, 4)
-        # materialised per sample by the saved-activation path: forward 224 + 2048 + 128 + 48, dgrad 168 + 2080,
-        # wgrad 4096 bytes (round 2: 10,840 -- the dgrad chain re-read the activations)
-        rec["roofline"]["mlp_kernels_bytes_per_sample"] = 8792
-        rec["roofline"]["mlp_kernels_hbm_floor_gbs"] = round(8792 * S / (mlp_ms * 1e-3) / 1e9, 1)
+        rec["roofline"]["mlp_kernels_frac"] = round(flop_exec * S / (mlp_ms * 1e-3) / 1e12 / MFMA_F16_DENSE_PEAK_TFLOPS, 4)
+        rec["roofline"]["mlp_kernels_bytes_per_sample"] = int(bytes_exec)
+        gbs = bytes_exec * S / (mlp_ms * 1e-3) / 1e9
+        rec["roofline"]["mlp_kernels_hbm_gbs"] = round(gbs, 1) if gbs <= HBM_PEAK_GBS else None      # above the peak the byte model is wrong: say nothing
+        rec["roofline"]["mlp_kernels_hbm_frac"] = round(gbs / HBM_PEAK_GBS, 4) if gbs <= HBM_PEAK_GBS else None
     del tr
     torch.cuda.empty_cache()
     return rec

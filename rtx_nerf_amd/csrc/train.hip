@@ -28,6 +28,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -1547,12 +1548,42 @@ struct LeanArgs {
   const int* live_count;
 };
 
+// (timing-only ablations, results wrong: -DRTXN_LN_NO_WAIT no wait for the dZ stages / weights, -DRTXN_LN_NO_CONTRACT no contraction,
+// -DRTXN_LN_NO_FWD no recomputed forward: tools/ablate.sh with ABLATE_SRC=train)
 template <int N>
-__device__ __forceinline__ void ln_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void ln_wait_vm() {
+#ifndef RTXN_LN_NO_WAIT
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+// The workgroup barrier of this kernel, as a bare instruction.  __syncthreads() is a release fence + s_barrier, and with LDS-DMA
+// in flight hipcc makes the fence `s_waitcnt vmcnt(0)`: every barrier would drain the dZ ring (first build: 25 % MFMA busy).
+// What a wave must have finished before it arrives is said explicitly: its LDS writes (lgkmcnt) -- the DMA pieces by the
+// counted ln_wait_vm in front of it.
+__device__ __forceinline__ void ln_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// LDS reads of the contraction as asm: hipcc treats the transposing-read builtin as aliasing every LDS-DMA in flight and puts
+// `s_waitcnt vmcnt(0)` in front of the first one of each stage (same drain).  The waits for their results are then ours too
+// (ln_operands_ready takes the operands THROUGH the wait, see rtxn::mfma_results_settle for why).
+template <int OFF>
+__device__ __forceinline__ void ln_read_b128(half8& dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+__device__ __forceinline__ void ln_read_tr(half8& dst, unsigned addr, int off_lo, int off_hi) {
+  s16x4 lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(addr + (unsigned)off_lo));
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(addr + (unsigned)off_hi));
+  const half4v l4 = __builtin_bit_cast(half4v, lo), h4 = __builtin_bit_cast(half4v, hi);
+  dst = __builtin_shufflevector(l4, h4, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+template <int N>
+__device__ __forceinline__ void ln_operands_ready(half8& a0, half8& a1, half8& b0, half8& b1) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1) : "n"(N));
+}
 
 // L0 <= l < L1: the layers whose gradient this pass accumulates (at most 4); OUT: also the output layer (then L1 == LTOT)
+// sub_block of sub_grid: this block's place among the blocks that run THIS pass (see wgrad_recompute_kernel)
 template <int KS0, int L0, int L1, bool OUT, int LTOT>
-__global__ __launch_bounds__(kThreads, 1) void wgrad_recompute_kernel(LeanArgs a) {
+__device__ __forceinline__ void wgrad_recompute_pass(LeanArgs a, const int sub_block, const int sub_grid) {
   constexpr int W = 128, RT = 4, KS = 8, NL = L1 - L0;
   constexpr int FWD_END = OUT ? LTOT : L1 - 1;            // forward layers 0 .. FWD_END-1 are recomputed
   static_assert(NL >= 1 && NL <= 4 && L0 >= 0 && L1 <= LTOT && (!OUT || L1 == LTOT), "pass layout");
@@ -1568,18 +1599,18 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_recompute_kernel(LeanArgs a
   }
   const int live_n = a.live_list ? *a.live_count : 0;
   if (a.live_list) a.n_tiles = (live_n + 7) / 8;
-  // tiles blockIdx.x, + gridDim.x, ...; dead ones stepped over (scalar loads: nothing of this may enter the vector-memory queue)
+  // tiles sub_block, + sub_grid, ...; dead ones stepped over (scalar loads: nothing of this may enter the vector-memory queue)
   auto next_live = [&](int t) -> int {
     while (t < a.n_tiles) {
       int word;
       const uint8_t* p = a.live_tiles + (t & ~3);
       asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(word) : "s"(p) : "memory");
       if ((word >> (8 * (t & 3))) & 0xff) break;
-      t += (int)gridDim.x;
+      t += sub_grid;
     }
     return t;
   };
-  int tile = next_live((int)blockIdx.x);
+  int tile = next_live(sub_block);
   if (tile >= a.n_tiles) return;
 
   uint8_t* const ring = smem + kLnOffRing;
@@ -1641,14 +1672,6 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_recompute_kernel(LeanArgs a
         *reinterpret_cast<half4v*>(p + 16) = __builtin_shufflevector(v[kk][ct], v[kk][ct], 4, 5, 6, 7);
       }
   };
-  auto x_operand = [&](const uint8_t* image, int t, int ks) -> half8 {
-    const uint8_t* p = image + lane_tr + (16 * ks) * kLnStr + 64 * t;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * kLnStr));
-    const half4v l4 = __builtin_bit_cast(half4v, lo), h4 = __builtin_bit_cast(half4v, hi);
-    return __builtin_shufflevector(l4, h4, 0, 1, 2, 3, 4, 5, 6, 7);
-  };
-
   // the gradient quadrants: AGPRs for the whole kernel, touched only by the asm MFMAs below and the final atomics
   floatx16 acc[NL][4];
 #pragma unroll
@@ -1658,109 +1681,162 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_recompute_kernel(LeanArgs a
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][t][e] = 0.0f;
 
-  // 64 samples of the contraction: dZ stage in ring slot `slot`, X image `image`
-  auto contract = [&](floatx16 (&q)[4], int slot, const uint8_t* image) {
-    const uint8_t* st = ring + slot * kLnStage;
+  // 64 samples of the contraction: dZ stage in ring slot `slot`, X image at LDS address `image`.  Operands double-buffered by
+  // k-step: the six reads of k-step ks + 1 are in flight while the four MFMAs of ks run (one wave per SIMD: nothing else hides them)
+  const unsigned ring_addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) uint8_t*)ring;
+  const unsigned ximg_addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) uint8_t*)ximg;
+  auto contract = [&](floatx16 (&q)[4], int slot, int img) {
+#ifdef RTXN_LN_NO_CONTRACT
+    return;
+#endif
+    // (laundered: as loop invariants of the tile loop hipcc computed every stage's sixteen operand addresses ahead of it and
+    // parked them in AGPRs -- 52 of them, and then spilled an accumulator tile to scratch)
+    unsigned st = ring_addr + slot * kLnStage + (2 * tm) * 4096;
+    unsigned xi = ximg_addr + img * kLnImg + lane_tr + 64 * (2 * tn);
+    asm volatile("" : "+s"(st), "+v"(xi));
+    half8 a0[2], a1[2], b0[2], b1[2];
+    auto fetch = [&](int ks, int s) {
+      ln_read_b128<0>(a0[s], st + frag_off[ks]);
+      ln_read_b128<4096>(a1[s], st + frag_off[ks]);
+      ln_read_tr(b0[s], xi, (16 * ks) * kLnStr, (16 * ks + 4) * kLnStr);
+      ln_read_tr(b1[s], xi, (16 * ks) * kLnStr + 64, (16 * ks + 4) * kLnStr + 64);
+    };
+    fetch(0, 0);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const half8 a0 = *reinterpret_cast<const half8*>(st + frag_off[ks] + (2 * tm) * 4096);
-      const half8 a1 = *reinterpret_cast<const half8*>(st + frag_off[ks] + (2 * tm + 1) * 4096);
-      const half8 b0 = x_operand(image, 2 * tn, ks);
-      const half8 b1 = x_operand(image, 2 * tn + 1, ks);
-      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(q[0]) : "v"(a0), "v"(b0));
-      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(q[1]) : "v"(a0), "v"(b1));
-      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(q[2]) : "v"(a1), "v"(b0));
-      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(q[3]) : "v"(a1), "v"(b1));
+      const int s = ks & 1;
+      if (ks + 1 < 4) {
+        fetch(ks + 1, s ^ 1);
+        ln_operands_ready<6>(a0[s], a1[s], b0[s], b1[s]);
+      } else {
+        ln_operands_ready<0>(a0[s], a1[s], b0[s], b1[s]);
+      }
+      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(q[0]) : "v"(a0[s]), "v"(b0[s]));
+      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(q[1]) : "v"(a0[s]), "v"(b1[s]));
+      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(q[2]) : "v"(a1[s]), "v"(b0[s]));
+      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(q[3]) : "v"(a1[s]), "v"(b1[s]));
       __builtin_amdgcn_sched_barrier(0);
     }
   };
 
-  // ---- ring prologue: the first three stages of the first tile ----
+  // ---- prologue: layer 0's weights (from then on every forward fetches the next one's) and the first three stages of the first tile ----
+  if (FWD_END > 0) stage_rt(a.packed_fwd, smem + kLnOffW, KS0 * RT * 1024, tid);
 #pragma unroll
   for (int v = 0; v < 3; ++v) issue_stage(v, L0, (long)tile * kTile + 64 * v);
 
   while (tile < a.n_tiles) {
-    const int nxt_tile = next_live(tile + (int)gridDim.x);
+    const int nxt_tile = next_live(tile + sub_grid);
     const int look = nxt_tile < a.n_tiles ? nxt_tile : tile;       // no further tile: the look-ahead stages re-read this one (unused)
     const long tile0 = (long)tile * kTile + wave * 64;
-    unsigned lane_off[2];
+    // where the wave's two 32-sample column tiles sit in encT: consecutive, or with the live list two listed segments
+    long col0[2];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
-      long sidx = tile0 + ct * 32 + col;
+      col0[ct] = tile0 + ct * 32;
       if (a.live_list) {
+        // the list entry through the scalar cache (the slot is wave-uniform): a vector load here would enter the vector-memory
+        // queue, and hipcc's wait for it would drain the dZ ring
         const int slot = tile * 8 + wave * 2 + ct;
-        sidx = (long)(slot < live_n ? a.live_list[slot] : 0) * 32 + col;     // slots past the list read segment 0; their dZ is zero
+        int seg = 0;
+        const int* p = a.live_list + slot;
+        if (slot < live_n) asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(seg) : "s"(p) : "memory");
+        col0[ct] = (long)seg * 32;                        // slots past the list read segment 0; their dZ is zero
       }
-      lane_off[ct] = (unsigned)((sidx + 4L * h * a.Sp) * 2);
     }
     // ---- encoded input as B fragments (k-steps >= KS0: zeros, the padding columns of dW_0's operand) ----
-    // (pointers and the row stride are laundered once per tile: as loop invariants of this persistent loop hipcc formed every
-    // row address of the encoding and every per-lane source address of the weight fetches ahead of it -- 330 spilled registers)
+    // A lane of the chain owns ONE sample and needs 56 of its 112 features: as two-byte loads that is 112 wave instructions of 128
+    // useful bytes each, and the texture path takes an instruction's 64 addresses at the same pace whatever their width -- 14,000
+    // cycles per tile and CU, 2.4 of the first build's 4.4 ms (ablation: profiles/r04/lean_ablation.txt).  Instead each wave
+    // fetches its 64 samples x 112 rows as 14 sixteen-byte loads per lane (8 rows x 128 B per instruction, whole lines), drops them
+    // row-major into a 7-KiB scratch of its own in the X-image region (free between tiles) in two halves of 56 rows, and picks its
+    // fragments out with two-byte LDS reads.  (pointers are not laundered: a laundered pointer loses its address space -- flat loads)
     long Sp_t = a.Sp;
-    const _Float16* enc_t = a.encT;
-    asm volatile("" : "+s"(Sp_t), "+s"(enc_t));
-    half8 cur[KS][2], nxt[KS][2];
+    asm volatile("" : "+s"(Sp_t));
+    half8 act[2][KS][2];                                // ping-pong: layer l reads act[l & 1], its forward writes act[(l + 1) & 1]
+    {
+      static_assert(KS0 == 7, "the encoding's two halves of 56 rows are spelled for 112 features");
+      ln_barrier();                                     // everyone has left the previous tile's last contraction: the X images are free
+      uint8_t* scratch = ximg + wave * 7168;
+      const int r8 = lane >> 3, jg = lane & 7;          // row of a piece, 16-byte sample group of the wave's 64 samples
+      const _Float16* src = a.encT + (jg < 4 ? col0[0] : col0[1]) + 8 * (jg & 3) + (long)r8 * Sp_t;
+      rtxn::int4v piece[2][7];
 #pragma unroll
-    for (int kk = 0; kk < KS; ++kk)
+      for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
-        half8 v;
+        for (int p = 0; p < 7; ++p) piece[hf][p] = *reinterpret_cast<const rtxn::int4v*>(src + (long)(56 * hf + 8 * p) * Sp_t);
+      rtxn::int4v w[KS][2];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.0f;
-        if (kk < KS0) {
+      for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = *row_elem(enc_t, perm_feature(kk, 0, j), Sp_t, lane_off[ct]);
-        }
-        cur[kk][ct] = v;
+        for (int ct = 0; ct < 2; ++ct) w[kk][ct] = rtxn::int4v{0, 0, 0, 0};
+      const uint8_t* mine = scratch + (4 * h) * 128 + col * 2;     // + feature row (mod 56) * 128 + ct * 64
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+        for (int p = 0; p < 7; ++p) *reinterpret_cast<rtxn::int4v*>(scratch + (8 * p + r8) * 128 + jg * 16) = piece[hf][p];
+#pragma unroll
+        for (int kk = 0; kk < KS0; ++kk)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int f0 = perm_feature(kk, 0, j);      // + 4 h: the same group of eight rows, so the same half
+            if (f0 / 56 != hf) continue;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+              const unsigned v = *reinterpret_cast<const unsigned short*>(mine + (f0 - 56 * hf) * 128 + ct * 64);
+              w[kk][ct][j >> 1] |= (int)(v << (16 * (j & 1)));
+            }
+          }
       }
-    // one layer: [weight gradient of layer l from A_{l-1} = cur] then [forward: cur = relu(W_l cur)]; l is a compile-time constant
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) act[0][kk][ct] = __builtin_bit_cast(half8, w[kk][ct]);
+      // (the first barrier of step 0 stands between these reads and the first image written over the scratch)
+    }
+    // One layer, l a compile-time constant: [forward: nxt = relu(W_l cur)] THEN [weight gradient of layer l from A_{l-1} = cur],
+    // then cur = nxt.  Forward first, so that the four dZ stages of the layer -- issued one by one as the previous layer's
+    // contraction freed their slots -- have the forward's ~3,000 cycles to arrive: with the contraction first, the fourth stage
+    // was issued when the layer began and every layer paid one memory latency (first build: 14.5 us per tile of layers 0-2).
+    // Vector-memory order of a wave, which the counted waits below rely on (all static):
+    //   [W+T] wait W_l, barrier (also: everyone is done with the previous layer's X images and ring slot 3) -> issue stage (l', 3) of
+    //         the NEXT layer with a gradient, if the step before this one had one (its slot 3 has just come free)
+    //   forward_l; waves 0, 1 write X
+    //   [v0]  wait stage (l, 0): behind it (l, 1), (l, 2), (l, 3) = 12; barrier (also: everyone is done with W_l) -> issue W of the
+    //         next forward layer (the next tile's layer 0 after the last one); contract
+    //   [v1..v3] wait stage (l, v): behind it two stages and the weights = 8 + w; barrier -> issue stage (l', v - 1); contract
+    // W_l therefore has behind it the three look-ahead stages of the previous step's contraction (12) if that step had one.
+    // Where more has been issued than a count assumes (tile boundaries, the output layer's dZ) the wait is only longer.
     auto layer_step = [&](auto LC) {
       constexpr int l = decltype(LC)::value;
       constexpr bool has_w = l >= L0 && l < L1, has_f = l < FWD_END;
+      half8 (&cur)[KS][2] = act[l & 1];
+      half8 (&nxt)[KS][2] = act[(l + 1) & 1];
       if constexpr (has_w || has_f) {
-        constexpr int wbytes = (l == 0 ? KS0 : KS) * RT * 1024;
-        constexpr long woff = l == 0 ? 0 : (long)(KS0 + (l - 1) * KS) * RT * 1024;
-        __syncthreads();                                  // everyone is done with the weights of layer l-1 and with the X images
-        if constexpr (has_f) {
-          const uint8_t* pf = a.packed_fwd;
-          asm volatile("" : "+s"(pf));
-          stage_rt(pf + woff, smem + kLnOffW, wbytes, tid);
+        // the step before this one in program order (cyclically: the last step of the previous tile) and whether it contracted
+        constexpr int first_step = 0, last_step = OUT ? LTOT - 1 : L1 - 1;        // steps are layers 0 .. last_step (all of them forward, contract or both)
+        constexpr int prev = l == first_step ? last_step : l - 1;
+        constexpr bool prev_w = prev >= L0 && prev < L1;
+        // the next layer with a forward, cyclically, and its LDS-DMA instructions per wave
+        constexpr int next_f = l + 1 < FWD_END ? l + 1 : 0;
+        constexpr int w_next = has_f ? (next_f == 0 ? W0_OPS : 8) : 0;           // issued by this step only if it runs a forward (see [v0])
+        constexpr int next_w = l + 1 < L1 && l + 1 >= L0 ? l + 1 : L0;            // the next layer with a gradient (cyclically)
+        constexpr bool next_w_same_tile = has_w && l + 1 < L1;
+        // ---- [W+T] ----
+        if constexpr (has_f) ln_wait_vm<(prev_w ? 12 : 0)>();
+        ln_barrier();
+        if constexpr (prev_w) {
+          // slot 3: stage 3 of the layer whose stages 0-2 the previous step's contraction looked ahead to -- this tile's
+          // layer `l` if it has a gradient (then prev was l - 1 or the previous tile's last layer), else this tile's first such layer
+          constexpr int lw = has_w ? l : L0;
+          issue_stage(3, lw, (long)tile * kTile + 64 * 3);
+          if constexpr (OUT && has_w && l == LTOT - 1) issue_ol((long)tile * kTile);
         }
-        if constexpr (has_w) {
-          constexpr int li = l - L0;
-          // what has entered this wave's vector-memory queue behind the stage being retired: the two younger stages and, for v = 0..2,
-          // this layer's weight fetch (v = 3's stage was issued behind it: that wait also lands the weights)
-          constexpr int K012 = 8 + (has_f ? (l == 0 ? W0_OPS : 8) : 0);
-          // stage issued three ahead of the one being retired: (l, 3) at v = 0, then layer l + 1's -- or the next tile's first layer's -- v - 1
-          auto look_ahead = [&](int v) {
-            if (v == 0) issue_stage(3, l, (long)tile * kTile + 64 * 3);
-            else if (l + 1 < L1) issue_stage(v - 1, l + 1, (long)tile * kTile + 64 * (v - 1));
-            else issue_stage(v - 1, L0, (long)look * kTile + 64 * (v - 1));
-          };
-          if (wave < 2) write_image(ximg + wave * kLnImg, cur);
-          ln_wait_vm<K012>();
-          __syncthreads();                                // stage (l, 0) and the images of waves 0, 1 are everyone's
-          look_ahead(0);
-          if constexpr (OUT && l == LTOT - 1) issue_ol((long)tile * kTile);
-          contract(acc[li], 0, ximg);
-          ln_wait_vm<K012>();
-          __syncthreads();
-          look_ahead(1);
-          contract(acc[li], 1, ximg + kLnImg);
-          __syncthreads();                                // both images have been read by everyone
-          if (wave >= 2) write_image(ximg + (wave - 2) * kLnImg, cur);
-          ln_wait_vm<K012>();
-          __syncthreads();
-          look_ahead(2);
-          contract(acc[li], 2, ximg);
-          ln_wait_vm<8>();
-          __syncthreads();
-          look_ahead(3);
-          contract(acc[li], 3, ximg + kLnImg);
-        } else {
-          rtxn::staged_barrier();
-        }
+        // ---- forward ----
+#ifdef RTXN_LN_NO_FWD
+        if constexpr (false) {
+#else
         if constexpr (has_f) {
+#endif
           const uint8_t* wl = smem + kLnOffW;
           if constexpr (l == 0) {
 #pragma unroll
@@ -1789,10 +1865,45 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_recompute_kernel(LeanArgs a
 #pragma unroll
               for (int ct = 0; ct < 2; ++ct) nxt[2 * (RT - 1) + s2][ct] = rtxn::relu_pack(acc2[1][ct], s2);
           }
-#pragma unroll
-          for (int kk = 0; kk < KS; ++kk)
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) cur[kk][ct] = nxt[kk][ct];
+        }
+        auto issue_next_weights = [&]() {
+          if constexpr (has_f) {
+            constexpr int wbytes = (next_f == 0 ? KS0 : KS) * RT * 1024;
+            constexpr long woff = next_f == 0 ? 0 : (long)(KS0 + (next_f - 1) * KS) * RT * 1024;
+            const uint8_t* pf = a.packed_fwd;
+            asm volatile("" : "+s"(pf));
+            stage_rt(pf + woff, smem + kLnOffW, wbytes, tid);
+          }
+        };
+        if constexpr (has_w) {
+          constexpr int li = l - L0;
+          // stage issued as slot v - 1 comes free: the next gradient layer's v - 1 (this tile's, or the next tile's first)
+          auto look_ahead = [&](int v) {
+            if (next_w_same_tile) issue_stage(v - 1, next_w, (long)tile * kTile + 64 * (v - 1));
+            else issue_stage(v - 1, L0, (long)look * kTile + 64 * (v - 1));
+          };
+          if (wave < 2) write_image(ximg + wave * kLnImg, cur);
+          ln_wait_vm<12>();
+          ln_barrier();                                   // stage (l, 0), the images of waves 0, 1; everyone has left the forward
+          issue_next_weights();
+          contract(acc[li], 0, 0);
+          ln_wait_vm<8 + w_next>();
+          ln_barrier();
+          look_ahead(1);
+          contract(acc[li], 1, 1);
+          ln_barrier();                                   // both images have been read by everyone
+          if (wave >= 2) write_image(ximg + (wave - 2) * kLnImg, cur);
+          ln_wait_vm<8 + w_next>();
+          ln_barrier();
+          look_ahead(2);
+          contract(acc[li], 2, 0);
+          ln_wait_vm<8 + w_next>();
+          ln_barrier();
+          look_ahead(3);
+          contract(acc[li], 3, 1);
+        } else {
+          ln_barrier();                                   // everyone has left the forward: its weights may be overwritten
+          issue_next_weights();
         }
       }
     };
@@ -1807,29 +1918,35 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_recompute_kernel(LeanArgs a
     static_assert(LTOT <= 8, "layer_step is spelled out for eight layers");
     if (OUT) {
       // ---- output layer: dW_L[16 x 128] += dZ_L A_{L-1}^T; wave w: columns 32 w .. 32 w + 31, rows 0-15 of a 32-row tile ----
+      half8 (&cur)[KS][2] = act[LTOT & 1];
       floatx16 o;
 #pragma unroll
       for (int e = 0; e < 16; ++e) o[e] = 0.0f;
-      auto contract_ol = [&](int v, const uint8_t* image) {
-        const uint8_t* st = smem + kLnOffOL + v * 2048;   // lanes with col >= 16 read past the 16 rows: rows 16-31 of the product, never stored
+      const unsigned ol_addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) uint8_t*)(smem + kLnOffOL);
+      auto contract_ol = [&](int v, int img) {
+        // lanes with col >= 16 read past the 16 rows: rows 16-31 of the product, never stored
+        unsigned st = ol_addr + v * 2048, xi = ximg_addr + img * kLnImg + lane_tr + 64 * wave;
+        asm volatile("" : "+s"(st), "+v"(xi));
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-          const half8 a0 = *reinterpret_cast<const half8*>(st + frag_off[ks]);
-          const half8 b0 = x_operand(image, wave, ks);
+          half8 a0, b0;
+          ln_read_b128<0>(a0, st + frag_off[ks]);
+          ln_read_tr(b0, xi, (16 * ks) * kLnStr, (16 * ks + 4) * kLnStr);
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(b0));
           o = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, o, 0, 0, 0);
         }
       };
-      __syncthreads();
+      ln_barrier();
       if (wave < 2) write_image(ximg + wave * kLnImg, cur);
       ln_wait_vm<12>();                                   // behind the output layer's dZ: the three look-ahead stages of the last layer
-      __syncthreads();
-      contract_ol(0, ximg);
-      contract_ol(1, ximg + kLnImg);
-      __syncthreads();
+      ln_barrier();
+      contract_ol(0, 0);
+      contract_ol(1, 1);
+      ln_barrier();
       if (wave >= 2) write_image(ximg + (wave - 2) * kLnImg, cur);
-      __syncthreads();
-      contract_ol(2, ximg);
-      contract_ol(3, ximg + kLnImg);
+      ln_barrier();
+      contract_ol(2, 0);
+      contract_ol(3, 1);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int orow = (e & 3) + 8 * (e >> 2) + 4 * h;  // < 16
@@ -1860,6 +1977,27 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_recompute_kernel(LeanArgs a
     for (int i = tid; i < 16 * W; i += kThreads)
       if (oacc[i] != 0.0f) atomicAdd(&dW[i], oacc[i]);
   }
+}
+
+// One pass as a launch of its own (small batches: fewer tiles than CUs).
+template <int KS0, int L0, int L1, bool OUT, int LTOT>
+__global__ __launch_bounds__(kThreads, 1) void wgrad_recompute_kernel(LeanArgs a) {
+  wgrad_recompute_pass<KS0, L0, L1, OUT, LTOT>(a, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// All three passes of the 8-layer model in ONE launch, side by side on disjoint CUs.  Run one after the other they alternate
+// between two bounds: a layer's contraction streams 256 B of dZ per sample (HBM: every block of the chip at once), the
+// recomputed forward layers in front of it stream nothing (matrix core) -- pass 0-2 is mostly the first, pass 6-7 + output
+// mostly the second, and measured back to back they took 1.04 + 1.37 + 1.78 ms per 4.7 M samples for 2.0 ms of HBM time.
+// Side by side the chip's memory pipe serves fewer blocks at a time and is not idle while others recompute.
+// Workgroups are dealt round-robin to the 8 XCDs, so block b sits in slot b / 8 of XCD b % 8: slots [0, s1) run layers 0-2,
+// [s1, s2) layers 3-5, the rest 6-7 + output -- every XCD gets the same mix.  gridDim.x is a multiple of 8.
+template <int KS0>
+__global__ __launch_bounds__(kThreads, 1) void wgrad_recompute_all_kernel(LeanArgs a, int s1, int s2) {
+  const int b = (int)blockIdx.x, slot = b >> 3, xcd = b & 7, slots = (int)gridDim.x >> 3;
+  if (slot < s1) wgrad_recompute_pass<KS0, 0, 3, false, 8>(a, slot * 8 + xcd, s1 * 8);
+  else if (slot < s2) wgrad_recompute_pass<KS0, 3, 6, false, 8>(a, (slot - s1) * 8 + xcd, (s2 - s1) * 8);
+  else wgrad_recompute_pass<KS0, 6, 8, true, 8>(a, (slot - s2) * 8 + xcd, (slots - s2) * 8);
 }
 
 // ------------------------------------------------------------------------- segments that carry a loss gradient
@@ -2428,6 +2566,26 @@ static int train_backward_lean_impl(const rtxn_mlp* m, const void* encT, const v
   constexpr int n_pass = 3;
   static const lean_fn pass[3] = {wgrad_recompute_kernel<7, 0, 3, false, 8>, wgrad_recompute_kernel<7, 3, 6, false, 8>,
                                   wgrad_recompute_kernel<7, 6, 8, true, 8>};
+#endif
+#ifndef RTXN_LEAN_TWO_PASS
+  // large batches: the three passes side by side in one launch (wgrad_recompute_all_kernel); the CU split follows the passes'
+  // measured cost (RTXN_LEAN_SPLIT="s1,s2" of 32 slots per XCD for experiments; RTXN_LEAN_SPLIT=0: one launch per pass)
+  static int split[2] = {-1, -1};
+  if (split[0] < 0) {
+    int s1 = 8, s2 = 18;
+    if (const char* e = getenv("RTXN_LEAN_SPLIT")) {
+      if (sscanf(e, "%d,%d", &s1, &s2) != 2) s1 = s2 = 0;
+    }
+    split[1] = s2;
+    split[0] = s1;
+  }
+  const int slots = n_cu / 8;
+  if (split[0] > 0 && split[0] < split[1] && split[1] < slots && la.n_tiles >= 4 * n_cu) {
+    RTXN_HIP(set_lds_once(reinterpret_cast<const void*>(wgrad_recompute_all_kernel<7>), kLnLds));
+    hipLaunchKernelGGL(wgrad_recompute_all_kernel<7>, dim3((unsigned)(slots * 8)), dim3(kThreads), kLnLds, s, la, split[0] * slots / 32, split[1] * slots / 32);
+    RTXN_LAUNCH_CHECK("wgrad_recompute_all_kernel");
+    return RTXN_OK;
+  }
 #endif
   for (int i = 0; i < n_pass; ++i) {
     RTXN_HIP(set_lds_once(reinterpret_cast<const void*>(pass[i]), kLnLds));

@@ -130,3 +130,37 @@ def test_cpp_training_host_runs_the_reference_iteration_as_one_call_per_step(gpu
         got = np.fromfile(out, np.float32)
         assert got.shape == init.shape and np.isfinite(got).all()
         assert 1e-3 < np.abs(got - init).max() < 1.0          # 150 Adam steps of 1e-3
+
+
+@pytest.mark.parametrize("W,H,R,occupied,devices", [(320, 203, 64, True, "0,0"), (320, 203, 64, True, "0,0,0"), (96, 64, 8, False, "0,0,0,0,0")])
+def test_cpp_multi_gpu_host_shards_rehearsed_on_one_gpu(gpu, tmp_path, W, H, R, occupied, devices):
+    """examples/render_host_mgpu.cpp: ONE C++ process, one rtxn_render + stream per shard, rows dealt
+    round-robin (window_chunk = W, window_stride = N W), each shard's rows copied to the root behind its compositor and
+    interleaved there.  With every shard on device 0 ("0,0": the one-GPU rehearsal; H is not a multiple of N: ragged shards) the
+    assembled frame must be the single-device frame of examples/render_host bit for bit.  Unmeasured on more than one GPU."""
+    from rtx_nerf_amd import scenes
+    exe = os.path.join(ROOT, "examples", "render_host_mgpu")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", ROOT, "examples/render_host_mgpu"])
+    la = scenes.pose_spherical(15.0, -30.0, origin_scale=10.0).astype(np.float32).reshape(16)
+    occ_path = "-"
+    if occupied:
+        occ_path = str(tmp_path / "occ.u32")
+        scenes.pack_occupancy(scenes.lego_standin_density(R, seed=0)).astype("<u4").tofile(occ_path)
+    f = float(np.float32(1.0) / np.tan(np.float32(0.5) * np.float32(0.6911112)))
+    pose = ",".join(f"{v:.9g}" for v in la)
+    one, one_raw = str(tmp_path / "one.ppm"), str(tmp_path / "one.f32")
+    res = subprocess.run([_exe(), "frame", str(W), str(H), str(R), one, one_raw, occ_path, "1", pose, f"{f:.9g}"],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    out, raw = str(tmp_path / "mgpu.ppm"), str(tmp_path / "mgpu.f32")
+    res = subprocess.run([exe, str(W), str(H), str(R), out, raw, occ_path, devices, "3", pose, f"{f:.9g}"],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    n = devices.count(",") + 1
+    assert f"over {n} shards" in res.stdout and "0 overflowed frames" in res.stdout and "ms/frame" in res.stdout
+    want = np.fromfile(one_raw, np.float32)
+    got = np.fromfile(raw, np.float32)
+    assert want.shape == got.shape == (W * H * 3,) and want.std() > 1e-3
+    assert np.array_equal(got, want)
+    assert open(out, "rb").read() == open(one, "rb").read()

@@ -795,7 +795,7 @@ def _lean_case(torch, api, n, seed=3, passes=None):
     return net, encT, Sp, rng
 
 
-@pytest.mark.parametrize("n", [256, 700, 5000, 66_000])
+@pytest.mark.parametrize("n", [256, 700, 5000, 66_000, 300_000])   # 300,000: the three passes side by side in one launch
 def test_lean_path_equals_the_saved_activation_path(gpu, oracle, n):
     """the 8 x 128 training backward WITHOUT materialised activations (rtxn_mlp_train_forward_lean: outputs
     + sign masks; rtxn_mlp_train_backward_lean: dgrad chain + weight gradient with the activations recomputed from the encoding
