@@ -541,6 +541,20 @@ int rtxn_adam_step_sparse(long n, float* master, void* params_fp16, void* grads,
                           unsigned* param_steps, float lr, float beta1, float beta2, float eps, float loss_scale,
                           rtxn_stream_t stream);
 
+/* ---- deterministic training (debugging, tight comparisons) ------------------------------------------------------------
+ * By default every gradient sum that crosses workgroups is a float atomic (the weight-gradient kernels' final flush; the hash
+ * scatter, packed fp16 on the hashed levels as tiny-cuda-nn does): two runs of one step differ in the last bits, which Adam's
+ * 1/sqrt(v) turns into +-lr on entries whose gradient is noise around zero.  With shadows registered here those sums are
+ * accumulated in 64-bit fixed point (value x 2^40, integer atomics: order-independent) and folded into the gradient buffers
+ * once per call, so identical inputs give identical bits, run after run and across data-parallel ranks.
+ *   mlp_shadow:   rtxn_deterministic_workspace_bytes(rtxn_mlp_n_params) bytes, zeroed once by the caller, or NULL;
+ *   table_shadow: rtxn_deterministic_workspace_bytes(rtxn_hashgrid_n_params) bytes, zeroed once, or NULL (no hash grid).
+ * Process-wide and read when a backward / scatter entry point is CALLED (so: baked into a captured graph); (NULL, NULL)
+ * restores the default.  The folds leave the shadows zero.  Costs: 8-byte atomics in the scatter (about 2x its time) and one
+ * sweep over each shadow per call.  Not covered: the reported loss sum (a float atomic; it feeds nothing back). */
+size_t rtxn_deterministic_workspace_bytes(long n_params);
+int rtxn_set_deterministic_workspace(void* mlp_shadow, void* table_shadow);
+
 /* ---- one training batch without a host round trip ------------------------------------------------------------------
  * The body of the reference's training loop between the traversal and the optimizer (main.cu:703-781: launchSampler ->
  * network->forward -> launch_volrender_cuda -> loss->evaluate -> launch_volrender_backward_cuda -> network->backward) as

@@ -202,6 +202,8 @@ SYMBOLS = {
     "rtxn_adam_effective_lr": (_F, [_F, _F, _F, _I]),
     "rtxn_adam_step_captured": (_I, [_L, _P, _P, _P, _I, _P, _P, _P, _F, _F, _F, _F, _P]),
     "rtxn_adam_step_sparse": (_I, [_L, _P, _P, _P, _I, _P, _P, _P, _F, _F, _F, _F, _F, _P]),
+    "rtxn_deterministic_workspace_bytes": (C.c_size_t, [_L]),
+    "rtxn_set_deterministic_workspace": (_I, [_P, _P]),
     "rtxn_mlp_train_lean_supported": (_I, [_P]),
     "rtxn_mlp_train_lean_workspace_bytes": (C.c_size_t, [_P, _L]),
     "rtxn_mlp_train_forward_lean": (_I, [_P, _P, _L, _P, _P, _P, _P]),

@@ -629,6 +629,18 @@ def adam_step_sparse(master, params_fp16, grads, m, v, param_steps, lr=1e-3, bet
                                            _stream()), "rtxn_adam_step_sparse")
 
 
+def deterministic_shadow(n_params, device="cuda"):
+    """A zeroed 64-bit fixed-point shadow for a gradient buffer of n_params floats (rtxn_deterministic_workspace_bytes)."""
+    nbytes = _lib.lib().rtxn_deterministic_workspace_bytes(int(n_params))
+    return torch.zeros(nbytes // 8, dtype=torch.int64, device=device)
+
+
+def set_deterministic(mlp_shadow=None, table_shadow=None):
+    """rtxn_set_deterministic_workspace: process-wide; (None, None) restores the float atomics.  The caller keeps the tensors alive."""
+    check(_lib.lib().rtxn_set_deterministic_workspace(_ptr(mlp_shadow, torch.int64, "mlp_shadow"), _ptr(table_shadow, torch.int64, "table_shadow")),
+          "rtxn_set_deterministic_workspace")
+
+
 def train_gradients(net, *, grid=None, n_dir_freqs=0, table=None, start_points, end_points, seg_view, num_stored, indices,
                     total_segments, segment_capacity, n_rays, sample_type, t_scale=1.0, vr_mode, targets, loss_scale,
                     encT, dencT=None, workspace=None, output_half, radiance, t_vals, radiance_gradients, pixels, loss_gradients,

@@ -27,6 +27,7 @@
 #include "hashgrid_internal.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -70,6 +71,23 @@ __device__ __forceinline__ long live_samples(const DevCount& dc, long S_host) {
 __device__ __forceinline__ long padded_dev(long S) { return (S + kTile - 1) / kTile * kTile; }
 // the fused training kernels address X[feature][S_pad] with one 32-bit per-lane byte offset (row_elem): (s + 4*S_pad)*2 < 2^32
 constexpr long kMaxTrainSamples = (1L << 32) / 10 - kTile;
+
+// Deterministic mode (rtxn_set_deterministic_workspace).  Every gradient sum that crosses workgroups -- the weight-gradient
+// kernels' flush of their on-chip accumulators, the hash-grid scatter -- is a float atomic by default, and float addition does not
+// associate: two runs of the same step differ in the last bit (fp32) or the last few (packed fp16), which Adam's 1/sqrt(v) turns
+// into +-lr wherever a gradient is noise around zero.  With a workspace set, those sums go into a 64-bit FIXED-POINT shadow of the
+// gradient buffer instead (value x 2^40, integer atomics: associative, so any arrival order gives the same bits) and are folded
+// back -- one rounding per element -- by det_fold_kernel behind the kernels that fed them.  What a workgroup sums on its own
+// (registers, LDS, the wave-level run sums of the scatter) has a fixed order already.  q is parallel to the float buffer `base`.
+struct DetCtx {
+  const float* base;
+  long long* q;
+};
+constexpr float kDetScale = 1099511627776.0f;            // 2^40: 9e-13 resolution, 8e6 range
+__device__ __forceinline__ void grad_add(float* addr, float v, const DetCtx& det) {
+  if (det.q) atomicAdd(reinterpret_cast<unsigned long long*>(det.q + (addr - det.base)), (unsigned long long)__float2ll_rn(v * kDetScale));
+  else atomicAdd(addr, v);
+}
 
 // ------------------------------------------------------------------------- encoders
 // Where a kernel's samples come from: a materialised float[S][5] batch (the sampler's output, sampler/sampler.cu), or the
@@ -332,12 +350,14 @@ __device__ __forceinline__ float run_sum(float v, const RunSteps& k) {
   return v;
 }
 
-template <bool PK>
+// DET: every level through the fp32 form into the fixed-point shadow of dtable (det.q), see DetCtx
+template <bool PK, bool DET = false>
 __global__ __launch_bounds__(kThreads) void hashgrid_backward_kernel(HgLevels lv, int level0, SampleSrc src,
                                                                      const _Float16* __restrict__ dencT, long S, long Sp,
                                                                      float* __restrict__ dtable, _Float16* __restrict__ dtable_h,
                                                                      long hashed_lo, DevCount dc, const int* __restrict__ live_list,
-                                                                     const int* __restrict__ live_count) {
+                                                                     const int* __restrict__ live_count, DetCtx det = DetCtx{nullptr, nullptr}) {
+  static_assert(!(PK && DET), "the deterministic scatter is the fp32-shaped one");
   S = live_samples(dc, S);
   if (live_list) S = 32L * *live_count;                         // the launch walks the listed segments only
   if ((long)blockIdx.x * kThreads >= S) return;                 // whole block past the live samples (block-uniform)
@@ -417,7 +437,10 @@ __global__ __launch_bounds__(kThreads) void hashgrid_backward_kernel(HgLevels lv
       for (int f = 0; f < F && f < 8; ++f) {
         float v = w * d[f];
         if (aggregate) v = run_sum(v, steps);
-        if (ok && run_last && v != 0.0f) atomicAdd(&gdst[(size_t)idx * F + f], v);
+        if (ok && run_last && v != 0.0f) {
+          if (DET) grad_add(&gdst[(size_t)idx * F + f], v, det);
+          else atomicAdd(&gdst[(size_t)idx * F + f], v);
+        }
       }
     }
   }
@@ -887,6 +910,7 @@ struct FusedArgs {
   float* dparams;              // tcnn layout, accumulated into
   const int* live_list;        // segments (32 samples) that carry a loss gradient, ascending, or NULL: all samples in order
   const int* live_count;       // device count of live_list
+  DetCtx det;                  // deterministic mode: the final flush goes to the fixed-point shadow of dparams
 };
 
 typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
@@ -1218,7 +1242,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_fused64_kernel(FusedArgs 
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int o = 32 * rt_w + (e & 3) + 8 * (e >> 2) + 4 * h, c = 32 * ct_w + col;
-        if (c < N && acc[l][e] != 0.0f) atomicAdd(&dW[(long)o * N + c], acc[l][e]);
+        if (c < N && acc[l][e] != 0.0f) grad_add(&dW[(long)o * N + c], acc[l][e], a.det);
       }
       dW += (long)W * N;
     }
@@ -1226,7 +1250,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_bwd_fused64_kernel(FusedArgs 
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int o = (e & 3) + 8 * (e >> 2) + 4 * h, c = 32 * ct_w + col;
-      if (o < 16 && accL[e] != 0.0f) atomicAdd(&dW[(long)o * W + c], accL[e]);
+      if (o < 16 && accL[e] != 0.0f) grad_add(&dW[(long)o * W + c], accL[e], a.det);
     }
   }
 }
@@ -1251,6 +1275,7 @@ struct WgradArgs {
   const uint8_t* live_tiles;   // [Sp / 256] from mlp_bwd_kernel, or NULL: 256-sample tiles with dZ == 0 are not read
   const int* live_list;        // live segments: dZ is COMPACT (slot * 32 + sample), X sits where the forward wrote it; the
   const int* live_count;       // contraction runs over 32 * count samples
+  DetCtx det;
 };
 
 __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
@@ -1319,7 +1344,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs a) {
       for (int e = 0; e < 16; ++e) {
         const int o = 64 * tm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
         const int c = 64 * tn + 32 * j + r;
-        if (o < M && c < N) atomicAdd(&dW[(long)o * N + c], acc[i][j][e]);
+        if (o < M && c < N) grad_add(&dW[(long)o * N + c], acc[i][j][e], a.det);
       }
 }
 
@@ -1488,7 +1513,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_lds_kernel(WgradArgs a) {
       for (int e = 0; e < 16; ++e) {
         const int o = 64 * tm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
         const int c = 64 * tn + 32 * j + r;
-        if (o < M && c < N) atomicAdd(&dW[(long)o * N + c], acc[i][j][e]);
+        if (o < M && c < N) grad_add(&dW[(long)o * N + c], acc[i][j][e], a.det);
       }
 }
 
@@ -1546,6 +1571,7 @@ struct LeanArgs {
   const uint8_t* live_tiles;   // [tiles]: mlp_bwd_kernel's; a tile with 0 has no dZ
   const int* live_list;
   const int* live_count;
+  DetCtx det;
 };
 
 // (timing-only ablations, results wrong: -DRTXN_LN_NO_WAIT no wait for the dZ stages / weights, -DRTXN_LN_NO_CONTRACT no contraction,
@@ -1969,13 +1995,13 @@ __device__ __forceinline__ void wgrad_recompute_pass(LeanArgs a, const int sub_b
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int orow = 64 * tm + 32 * (t >> 1) + (e & 3) + 8 * (e >> 2) + 4 * h, c = 64 * tn + 32 * (t & 1) + col;
-        if (c < N && acc[i][t][e] != 0.0f) atomicAdd(&dW[(long)orow * N + c], acc[i][t][e]);
+        if (c < N && acc[i][t][e] != 0.0f) grad_add(&dW[(long)orow * N + c], acc[i][t][e], a.det);
       }
   }
   if (OUT) {
     float* dW = a.dparams + (long)W * E + (long)(LTOT - 1) * W * W;
     for (int i = tid; i < 16 * W; i += kThreads)
-      if (oacc[i] != 0.0f) atomicAdd(&dW[i], oacc[i]);
+      if (oacc[i] != 0.0f) grad_add(&dW[i], oacc[i], a.det);
   }
 }
 
@@ -2209,6 +2235,20 @@ __global__ __launch_bounds__(kThreads) void adam_sparse_kernel(long n, float* __
 
 // fp32 <-> fp16 copies of a gradient block (8 elements per thread): the data-parallel exchange of the hashed levels' gradient
 // travels in fp16 (tcnn keeps that gradient in fp16 to begin with), see rtx_nerf_amd/train.py
+// deterministic mode: fold the fixed-point sums into the gradient buffers they shadow (accumulate semantics, one rounding per
+// element) and clear them.  dst_h != NULL: elements from hashed_lo on live in the fp16 buffer (the hashed levels' table gradient).
+__global__ __launch_bounds__(kThreads) void det_fold_kernel(long long* __restrict__ q, long n, float* __restrict__ dst, _Float16* __restrict__ dst_h,
+                                                            long hashed_lo) {
+  for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
+    const long long v = q[i];
+    if (v == 0) continue;
+    q[i] = 0;
+    const float g = (float)((double)v * (1.0 / (double)kDetScale));
+    if (dst_h && i >= hashed_lo) dst_h[i - hashed_lo] = (_Float16)((float)dst_h[i - hashed_lo] + g);
+    else dst[i] += g;
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void f32_to_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, long n) {
   const long i = ((long)blockIdx.x * kThreads + threadIdx.x) * 8;
   if (i + 8 <= n && ((uintptr_t)(src + i) & 15) == 0 && ((uintptr_t)(dst + i) & 15) == 0) {
@@ -2242,9 +2282,34 @@ int check_train(const rtxn_mlp* m, const char* who) {
   return RTXN_OK;
 }
 
+// deterministic mode: the fixed-point shadows the caller registered (rtxn_set_deterministic_workspace), or NULL
+std::atomic<long long*> g_det_mlp{nullptr}, g_det_table{nullptr};
+
+DetCtx det_ctx(const float* base, std::atomic<long long*>& slot) {
+  long long* q = slot.load(std::memory_order_relaxed);
+  return DetCtx{q ? base : nullptr, q};
+}
+
+int det_fold(long long* q, long n, float* dst, void* dst_half, long hashed_lo, hipStream_t s) {
+  if (!q || n <= 0) return RTXN_OK;
+  const long blocks = (n + kThreads - 1) / kThreads;
+  det_fold_kernel<<<(unsigned)(blocks > 4096 ? 4096 : blocks), kThreads, 0, s>>>(q, n, dst, static_cast<_Float16*>(dst_half), hashed_lo);
+  RTXN_LAUNCH_CHECK("det_fold_kernel");
+  return RTXN_OK;
+}
+
 }  // namespace
 
 // ============================================================================ C ABI
+extern "C" size_t rtxn_deterministic_workspace_bytes(long n_params) { return n_params < 0 ? 0 : (size_t)n_params * sizeof(long long); }
+
+extern "C" int rtxn_set_deterministic_workspace(void* mlp_shadow, void* table_shadow) {
+  RTXN_REQUIRE((((uintptr_t)mlp_shadow | (uintptr_t)table_shadow) & 7) == 0, "rtxn_set_deterministic_workspace: shadows must be 8-byte aligned");
+  g_det_mlp.store(static_cast<long long*>(mlp_shadow), std::memory_order_relaxed);
+  g_det_table.store(static_cast<long long*>(table_shadow), std::memory_order_relaxed);
+  return RTXN_OK;
+}
+
 extern "C" long rtxn_padded_samples(long n_samples) { return n_samples < 0 ? -1 : padded(n_samples); }
 
 extern "C" size_t rtxn_mlp_train_workspace_bytes(const rtxn_mlp* m, long n_samples) {
@@ -2441,6 +2506,7 @@ static int train_backward_impl(const rtxn_mlp* m, const void* encT, const void* 
   // weight gradients of all layers in one launch: dW_l += dZ_l X_l^T, X_0 = enc, X_l = acts[l-1], X_L = acts[L-1]
   RTXN_REQUIRE(L + 1 <= 17, "rtxn_mlp_train_backward: %d layers exceed the weight-gradient launch table", L + 1);
   WgradArgs wa;
+  wa.det = det_ctx(dparams, g_det_mlp);
   wa.Sp = Sp;
   wa.dc = dc;
   wa.live_tiles = a.live_tiles;
@@ -2476,7 +2542,7 @@ static int train_backward_impl(const rtxn_mlp* m, const void* encT, const void* 
     wgrad_lds_kernel<<<dim3((unsigned)((Sp + wl.chunk - 1) / wl.chunk), (unsigned)(L + 1)), kThreads, kWgStages * kWgStage, s>>>(wl);
     RTXN_LAUNCH_CHECK("wgrad_lds_kernel");
   }
-  return RTXN_OK;
+  return det_fold(wa.det.q, m->n_params, dparams, nullptr, 0, s);
 }
 
 extern "C" int rtxn_mlp_train_backward(const rtxn_mlp* m, const void* encT, const void* output_half,
@@ -2549,6 +2615,7 @@ static int train_backward_lean_impl(const rtxn_mlp* m, const void* encT, const v
   la.live_tiles = a.live_tiles;
   la.live_list = live_list;
   la.live_count = live_count;
+  la.det = det_ctx(dparams, g_det_mlp);
   int dev = 0, n_cu = 0;
   RTXN_HIP(hipGetDevice(&dev));
   RTXN_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
@@ -2584,7 +2651,7 @@ static int train_backward_lean_impl(const rtxn_mlp* m, const void* encT, const v
     RTXN_HIP(set_lds_once(reinterpret_cast<const void*>(wgrad_recompute_all_kernel<7>), kLnLds));
     hipLaunchKernelGGL(wgrad_recompute_all_kernel<7>, dim3((unsigned)(slots * 8)), dim3(kThreads), kLnLds, s, la, split[0] * slots / 32, split[1] * slots / 32);
     RTXN_LAUNCH_CHECK("wgrad_recompute_all_kernel");
-    return RTXN_OK;
+    return det_fold(la.det.q, m->n_params, dparams, nullptr, 0, s);
   }
 #endif
   for (int i = 0; i < n_pass; ++i) {
@@ -2592,7 +2659,7 @@ static int train_backward_lean_impl(const rtxn_mlp* m, const void* encT, const v
     hipLaunchKernelGGL(pass[i], dim3((unsigned)grid), dim3(kThreads), kLnLds, s, la);
     RTXN_LAUNCH_CHECK("wgrad_recompute_kernel");
   }
-  return RTXN_OK;
+  return det_fold(la.det.q, m->n_params, dparams, nullptr, 0, s);
 }
 
 static int check_lean(const rtxn_mlp* m, const char* who, long n_samples, bool whole_segments) {
@@ -2671,6 +2738,7 @@ static int train_backward_recompute_impl(const rtxn_mlp* m, const void* encT, co
   a.dparams = dparams;
   a.live_list = live_list;
   a.live_count = live_count;
+  a.det = det_ctx(dparams, g_det_mlp);
   const int RT = 2, KS = 4;
   const size_t lds = (size_t)(a.KS0 * RT + (L - 1) * KS * RT) * 1024 + (size_t)(RT + (L - 1) * RT * KS + ((E + 31) / 32) * KS) * 1024 +
                      8 * (size_t)kImgBytes;
@@ -2689,7 +2757,7 @@ static int train_backward_recompute_impl(const rtxn_mlp* m, const void* encT, co
   RTXN_HIP(set_lds_once(reinterpret_cast<const void*>(fn), (int)lds));
   hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(kThreads), lds, rtxn::as_stream(stream), a);
   RTXN_LAUNCH_CHECK("mlp_bwd_fused64_kernel");
-  return RTXN_OK;
+  return det_fold(a.det.q, m->n_params, dparams, nullptr, 0, rtxn::as_stream(stream));
 }
 
 extern "C" int rtxn_mlp_train_backward_recompute(const rtxn_mlp* m, const void* encT, const void* output_half,
@@ -3040,6 +3108,14 @@ static int hashgrid_backward_impl(const rtxn_hashgrid* g, const SampleSrc& input
   const HgLevels lv = levels_of(g);
   const _Float16* de = static_cast<const _Float16*>(dencT);
   const unsigned sblocks = (unsigned)((n_samples + kThreads - 1) / kThreads);
+  const DetCtx det = det_ctx(dtable, g_det_table);
+  if (det.q) {
+    // deterministic: every level as fp32-shaped contributions into the fixed-point shadow, then one fold into dtable / dtable_h
+    hashgrid_backward_kernel<false, true><<<dim3(sblocks, (unsigned)NL), kThreads, 0, st>>>(
+        lv, 0, input, de, n_samples, Sp, dtable, nullptr, 0, dc, live_list, live_count, det);
+    RTXN_LAUNCH_CHECK("hashgrid_backward_kernel<deterministic>");
+    return det_fold(det.q, g->n_params, dtable, dtable_hashed_half, hashed_lo, st);
+  }
   if (first_hashed > 0) {
     hashgrid_backward_kernel<false><<<dim3(sblocks, (unsigned)first_hashed), kThreads, 0, st>>>(
         lv, 0, input, de, n_samples, Sp, dtable, nullptr, 0, dc, live_list, live_count);

@@ -56,7 +56,7 @@ class _Stage:
 class Trainer:
     def __init__(self, grid_res, occupancy=None, encoding="hash", n_neurons=64, n_hidden_layers=4,
                  hashgrid=None, n_dir_freqs=4, batch_rays=4096, max_segments=None, lr=1e-3, loss_scale=128.0,
-                 density_scale=1.0, mode="nerf", seed=1337, device="cuda"):
+                 density_scale=1.0, mode="nerf", seed=1337, device="cuda", deterministic=None):
         self.R = grid_res
         self.dev = torch.device(device)
         self.occ = occupancy
@@ -175,8 +175,18 @@ class Trainer:
         self._dp_pending = None
         self._dp_table = None
         self.dp_sparse = os.environ.get("RTXN_DP_SPARSE", "1") != "0"         # "force": lists for every level (tests)
+        # deterministic=True (or RTXN_DETERMINISTIC=1): every cross-workgroup gradient sum in 64-bit fixed point instead of float
+        # atomics (librtxn: rtxn_set_deterministic_workspace): two runs, or two ranks, of the same steps end with identical bits.
+        # The library's switch is process-wide, so every stepping method re-asserts this trainer's choice first (_det_select).
+        self.deterministic = (os.environ.get("RTXN_DETERMINISTIC", "0") == "1") if deterministic is None else bool(deterministic)
+        self._det_mlp = api.deterministic_shadow(self.master.numel(), device=d) if self.deterministic else None
+        self._det_table = (api.deterministic_shadow(self.table_master.numel(), device=d)
+                           if (self.deterministic and encoding == "hash") else None)
 
     # ------------------------------------------------------------------------------------------
+    def _det_select(self):
+        api.set_deterministic(self._det_mlp, self._det_table)
+
     def _segments(self, rays_o, rays_d, n):
         kw = dict(grid_res=self.R, rays_o=rays_o, rays_d=rays_d, width=n, height=1, ray_begin=0, ray_count=n,
                   occupancy=self.occ, occupancy_coarse=self.coarse, occupancy_bricks=self.bricks, occupancy_super=self.super_mip, mode=api.TRACE_DDA,
@@ -294,6 +304,7 @@ class Trainer:
         n = rays_o.shape[0]
         K = api.NUM_SAMPLES_PER_SEGMENT
         vr = api.VR_NERF if self.mode == "nerf" else api.VR_COMPAT
+        self._det_select()
         P = self._segments(rays_o, rays_d, n)
         S = P * K
         self._grads_clean = False          # the eager optimizer leaves the gradients in place (the captured one clears them)
@@ -557,6 +568,7 @@ class Trainer:
         cap = int(launch_segments) if launch_segments else self.max_segments
         cap = max(1, min(cap, self.max_segments))
         d = self.dev
+        self._det_select()                      # read by the entry points as they are captured: baked into the graphs
         self.graph_rays_o = torch.zeros((n, 3), device=d)
         self.graph_rays_d = torch.zeros((n, 3), device=d)
         self.graph_rays_d[:, 2] = 1.0
@@ -727,6 +739,7 @@ class Trainer:
     def step_entry(self):
         """One optimisation step on graph_rays_o / graph_rays_d / graph_targets through rtxn_train_step (entry_args() first).
         Returns the (device) loss scalar; like step_captured() it never reads the segment count on the host."""
+        self._det_select()
         if not getattr(self, "_grads_clean", False):
             self._clear_grads()
         if int(self.step_count) != getattr(self, "_entry_step_host", self.step_count):
