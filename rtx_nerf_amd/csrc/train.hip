@@ -507,6 +507,7 @@ __device__ __forceinline__ void store_fragment_rows_pair(_Float16* X, int kk, lo
 // sign masks per sample and layer and nothing else -- the forward of the LEAN 128-wide path (below: the dgrad chain needs
 // only the masks, the weight-gradient kernel recomputes the activations): 160 instead of 2,208 bytes written per sample.
 constexpr int kSaveNone = 0, kSaveAll = 1, kSaveMasks = 2;
+constexpr int kEncScratch = 6 * 1024;                    // per wave: 48 feature rows x 64 samples of the encoding (layer 0's operand)
 template <int W, int SAVE = kSaveAll>
 __global__ __launch_bounds__(kThreads, 2) void mlp_train_fwd_kernel(TrainArgs a) {
   constexpr int RT = W / 32, KS = W / 16;
@@ -541,10 +542,24 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_train_fwd_kernel(TrainArgs a)
     samp[ct] = s;
     lane_off[ct] = (unsigned)((s + 4L * h * a.Sp) * 2);
   }
-  // ---- layer 0: B fragments straight from encT (8 two-byte loads per k-step per column tile) ----
+  // ---- layer 0: B fragments from encT ----
+  // A lane owns ONE sample and needs half of its features: read directly that is 8 two-byte loads per k-step and column tile,
+  // 112 wave instructions of 128 useful bytes for the 112-feature encoding, and the texture path takes an instruction's 64
+  // addresses at the same pace whatever their width -- 14,000 cycles per tile and CU, 40 % of this kernel's time when it saves
+  // nothing (round 4).  Instead each wave fetches its 64 samples of 48 feature rows at a time as six 16-byte loads per lane (8
+  // rows x 128 B per instruction, whole lines), drops them row-major into a 6-KiB scratch of its own behind the weights, and
+  // picks its fragments out with two-byte LDS reads.  The two 64-byte halves of a row are swapped in rows 4-7 of every eight so
+  // that lane-half h = 1 (rows + 4) reads the other half of the banks than h = 0.
   half8 bf[KS][2], bg[KS][2];
   {
     stage_rt(a.packed, smem, KS0 * RT * 1024, tid);
+    uint8_t* scratch = smem + (size_t)(KS0 > KS ? KS0 : KS) * RT * 1024 + wave * kEncScratch;
+    const int r8 = lane >> 3, jg = lane & 7;              // row of a piece; 16-byte sample group of the wave's 64 samples
+    // (column of sample group jg: the wave's samples are two runs of 32 -- consecutive, or with the live list two listed segments)
+    const long gcol = samp[jg >> 2] - col + 8 * (jg & 3);
+    const _Float16* src = a.encT + gcol + (long)r8 * a.Sp;
+    const int wr_off = r8 * 128 + ((jg * 16) ^ (((r8 >> 2) & 1) * 64));
+    const int rd_off = (4 * h) * 128 + ((col * 2) ^ (h * 64));   // + feature row (of the chunk, rows & 7 < 4) * 128 + (ct * 64, same swap)
     rtxn::staged_barrier();
     floatx16 acc[RT][2];
 #pragma unroll
@@ -553,17 +568,29 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_train_fwd_kernel(TrainArgs a)
       for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[rt][ct][e] = 0.0f;
-    for (int kk = 0; kk < KS0; ++kk) {
-      half8 b[2];
+    for (int c0 = 0; c0 < a.E; c0 += 48) {               // E is a multiple of 16: a chunk is 1-3 whole k-steps
+      rtxn::int4v piece[6];
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
+      for (int p = 0; p < 6; ++p)
+        piece[p] = c0 + 8 * p < a.E ? *reinterpret_cast<const rtxn::int4v*>(src + (long)(c0 + 8 * p) * a.Sp) : rtxn::int4v{0, 0, 0, 0};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) b[ct][j] = *row_elem(a.encT, perm_feature(kk, 0, j), a.Sp, lane_off[ct]);
+      for (int p = 0; p < 6; ++p) *reinterpret_cast<rtxn::int4v*>(scratch + p * 1024 + wr_off) = piece[p];
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        const half8 af = *reinterpret_cast<const half8*>(smem + ((rt * KS0 + kk) * 64 + lane) * 16);
+      for (int k3 = 0; k3 < 3; ++k3) {
+        const int kk = c0 / 16 + k3;
+        if (kk >= KS0) break;
+        half8 b[2];
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, b[ct], acc[rt][ct], 0, 0, 0);
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            b[ct][j] = *reinterpret_cast<const _Float16*>(scratch + (perm_feature(k3, 0, j)) * 128 + (rd_off ^ (ct * 64)));
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const half8 af = *reinterpret_cast<const half8*>(smem + ((rt * KS0 + kk) * 64 + lane) * 16);
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, b[ct], acc[rt][ct], 0, 0, 0);
+        }
       }
     }
 #pragma unroll
@@ -2426,7 +2453,7 @@ static int train_forward_impl(const rtxn_mlp* m, const void* encT, long n_sample
   a.live_list = live_list;
   a.live_count = live_count;
   const int RT = W / 32, KS = W / 16, KS0 = a.E / 16;
-  const size_t lds = (size_t)(KS0 > KS ? KS0 : KS) * RT * 1024;
+  const size_t lds = (size_t)(KS0 > KS ? KS0 : KS) * RT * 1024 + 4 * kEncScratch;
   hipStream_t s = rtxn::as_stream(stream);
   const dim3 grid((unsigned)(Sp / kTile)), block(kThreads);
 #define RTXN_FWD_LAUNCH(WW, SAVE)                                                                        \
