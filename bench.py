@@ -165,14 +165,22 @@ def extra_train_config3(steps, warmup, kernel_steps=5, train_to=1500, frames=12)
     live = 32 * int(tr.live_ws[0].item()) if tr.live_ws is not None else int(S)     # of the last time_stages batch
     enc_b = L * 8 * F * 2
     bwd_b = n_hashed * 8 * 4 + (L - n_hashed) * 8 * F * 4
-    IC_GATHER_PEAK_GBS, ATOMIC_PEAK_GBS = 8600.0, 1300.0
+    ATOMIC_PEAK_GBS = 1300.0
     kern = {}
     if stages.get("encode"):
+        # the gather's ceiling is the vector L1's line rate (one 128-B line lookup per clock and CU), as for hashmlp_fwd_kernel: see extra_render_hash
         ms = stages["encode"]
         gbs = enc_b * S / (ms * 1e-3) / 1e9
-        kern["encode"] = {"kernel": "hashgrid_encode_f2_kernel", "ms": round(ms, 4), "bound": "cache gather (L2 / Infinity Cache)", "bytes_per_sample": enc_b,
-                          "gathers_per_s_T": round(L * 8 * S / (ms * 1e-3) / 1e12, 3), "achieved": round(gbs, 1), "peak": IC_GATHER_PEAK_GBS, "unit": "GB/s",
-                          "frac": round(gbs / IC_GATHER_PEAK_GBS, 4), "traffic": pmc_traffic("hashgrid_encode_f2")}
+        pm = pmc_kernel("hashgrid_encode_f2")
+        clock_ghz = (pm or {}).get("effective_clock_ghz") or 2.1
+        n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+        lps = pm["l1_line_accesses_per_launch"] / max(S, 1.0) if pm and pm.get("l1_line_accesses_per_launch") else 64.0
+        ach = lps * S / (ms * 1e-3) / 1e9
+        kern["encode"] = {"kernel": "hashgrid_encode_f2_kernel", "ms": round(ms, 4), "bound": "vector-L1 line rate (one 128-B line lookup per clock and CU)", "bytes_per_sample": enc_b,
+                          "gathers_per_s_T": round(L * 8 * S / (ms * 1e-3) / 1e12, 3), "useful_gather_gbs": round(gbs, 1),
+                          "lines_per_sample": round(lps, 2), "lines_per_sample_source": "TCP_TOTAL_CACHE_ACCESSES_sum (PMC)" if pm and pm.get("l1_line_accesses_per_launch") else "assumed",
+                          "achieved": round(ach, 1), "peak": round(n_cu * clock_ghz, 1), "unit": "G lines/s", "frac": round(ach / (n_cu * clock_ghz), 4),
+                          "traffic": pmc_traffic("hashgrid_encode_f2")}
     if stages.get("hash_bwd"):
         ms = stages["hash_bwd"]
         gbs = bwd_b * live / (ms * 1e-3) / 1e9
@@ -180,7 +188,9 @@ def extra_train_config3(steps, warmup, kernel_steps=5, train_to=1500, frames=12)
         kern["hash_bwd"] = {"kernel": "hashgrid_backward_kernel<pk_f16> + <f32>, live segments, run-aggregated", "ms": round(ms, 4), "bound": "memory-side atomics",
                             "live_samples": live, "live_fraction": round(live / max(S, 1), 4), "atomic_bytes_per_live_sample": bwd_b,
                             "achieved": round(gbs, 1), "peak": ATOMIC_PEAK_GBS, "unit": "GB/s of added bytes before run aggregation", "frac": round(gbs / ATOMIC_PEAK_GBS, 4),
-                            "traffic": (pk["hbm_bytes_per_launch_low"] + f32["hbm_bytes_per_launch_low"]) if (pk and f32 and "hbm_bytes_per_launch_low" in pk and "hbm_bytes_per_launch_low" in f32) else None}
+                            "traffic": (pk["hbm_bytes_per_launch_low"] + f32["hbm_bytes_per_launch_low"]) if (pk and f32 and "hbm_bytes_per_launch_low" in pk and "hbm_bytes_per_launch_low" in f32) else None,
+                            "atomic_requests_leaving_l2": (pk["l2_to_memory_atomic_requests_per_launch"] + f32["l2_to_memory_atomic_requests_per_launch"])
+                            if (pk and f32 and "l2_to_memory_atomic_requests_per_launch" in pk and "l2_to_memory_atomic_requests_per_launch" in f32) else None}
     dom = "hash_bwd" if "hash_bwd" in kern else "encode"
     rec = {
         "workload": "4096 rays/batch, hash grid L=16 F=2 T=2^19 base 16 x1.5 + Frequency(4) dirs + 4x64 ReLU MLP, 128^3 grid "
@@ -260,7 +270,20 @@ def extra_render_hash(tr, step_captured, trained_steps, kernel_steps, train_to=1
     flop = 2 * (tr.E * 64 + (tr.net.cfg.n_hidden_layers - 1) * 64 * 64 + 16 * 64)
     gbs = gather_b * smp / (ms * 1e-3) / 1e9
     tf = flop * smp / (ms * 1e-3) / 1e12
-    IC_GATHER_PEAK_GBS = 8600.0   # MI355X_MICROARCH.md, "Indexed rows": 38 MB table, uniformly random rows served by the Infinity Cache
+    # What bounds the kernel: the vector L1 looks up ONE 128-byte line per clock and CU, and an 8-byte gather occupies it for a
+    # whole line.  peak = 256 CUs x clock lines/s; achieved = the lines the kernel actually asked its L1 for
+    # (TCP_TOTAL_CACHE_ACCESSES_sum, rocprofv3 --pmc, profiles/rNN/pmc_kernels.json -- used only while the running library still
+    # carries the measured code) over the kernel time measured here.  Without a matching PMC entry: the 64 lines per sample of
+    # DESIGN 5.2's count (12 hashed levels x 4 (y, z) rows + the dense levels), marked as assumed.
+    pm = pmc_kernel("hashmlp_fwd_2")
+    clock_ghz = (pm or {}).get("effective_clock_ghz") or 2.1
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    peak_lines = n_cu * clock_ghz                          # G lines/s
+    if pm and pm.get("l1_line_accesses_per_launch"):
+        lines_per_sample, src = pm["l1_line_accesses_per_launch"] / max(smp, 1.0), "TCP_TOTAL_CACHE_ACCESSES_sum per launch / samples per launch"
+    else:
+        lines_per_sample, src = 64.0, "assumed (DESIGN 5.2): no PMC entry for the running kernel"
+    ach_lines = lines_per_sample * smp / (ms * 1e-3) / 1e9
     rec = {
         "workload": f"{W}x{H} inference render of the TRAINED configs[2] model (hash grid L={L} F=2 T=2^{tr.hg.cfg.log2_hashmap_size} + Frequency(4) dirs + "
                     f"4x64 MLP, {tr.step_count} optimisation steps on the analytic teacher), 128^3 Lego stand-in grid, 32 midpoint samples/segment, "
@@ -269,12 +292,13 @@ def extra_render_hash(tr, step_captured, trained_steps, kernel_steps, train_to=1
         "segments_per_frame_max": worst, "mean_samples_per_ray": round(smp / (W * H), 2), "dtype": "f16 table + MFMA / f32 accumulate",
         "psnr_vs_teacher_db": [round(p, 2) for p in psnrs], "held_out_views": 2, "train_steps": tr.step_count,
         "train_seconds_after_bench": round(train_s, 3), "train_steps_in_those_seconds": more,
-        "roofline": {"kernel": "hashmlp_fwd_kernel<2>", "bound": "cache gather (L2 / Infinity Cache; the 25-MB table does not come from HBM)",
-                     "achieved": round(gbs, 1), "peak": IC_GATHER_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / IC_GATHER_PEAK_GBS, 4),
-                     "peak_source": "MI355X_MICROARCH.md 'Indexed rows: gather into LDS': 38 MB table, uniformly random 1,152-B rows = 8.6 TB/s; "
-                                    "4-byte gathers fetch a 64-B sector each, so the same sector rate moves 1/16 of the bytes when no two lanes share one",
+        "roofline": {"kernel": "hashmlp_fwd_kernel<2>", "bound": "vector-L1 line rate (one 128-B line lookup per clock and CU; the 25-MB table is served by L2 / Infinity Cache, not HBM)",
+                     "achieved": round(ach_lines, 1), "peak": round(peak_lines, 1), "unit": "G lines/s", "frac": round(ach_lines / peak_lines, 4),
+                     "lines_per_sample": round(lines_per_sample, 2), "lines_per_sample_source": src, "lines_per_sample_assumed_r03": 64,
+                     "clock_ghz": clock_ghz, "texture_path_busy_frac": (round(pm["TA_TA_BUSY_sum_avg"] / (n_cu * pm["kernel_ms_under_counters"] * 1e-3 * clock_ghz * 1e9), 4)
+                                                                          if pm and pm.get("TA_TA_BUSY_sum_avg") else None),
                      "traffic": pmc_traffic("hashmlp_fwd_2"), "kernel_ms": round(ms, 4), "bytes_per_sample": gather_b, "gathers_per_sample": L * 8,
-                     "gathers_per_s": round(L * 8 * smp / (ms * 1e-3) / 1e12, 3), "gathers_unit": "T/s", "samples_per_launch": smp,
+                     "gathers_per_s": round(L * 8 * smp / (ms * 1e-3) / 1e12, 3), "gathers_unit": "T/s", "useful_gather_gbs": round(gbs, 1), "samples_per_launch": smp,
                      "mfma": {"flop_per_sample": flop, "achieved": round(tf, 1), "unit": "TFLOP/s", "frac": round(tf / MFMA_F16_DENSE_PEAK_TFLOPS, 4)}},
     }
     del pipe

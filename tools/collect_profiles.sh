@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence quoted in DESIGN.md / profiles/README.md (run on the GPU box from the repo root):
-#   tools/collect_profiles.sh [outdir] [phases]        default gpurun_out/profiles, phases "bench traces pmc1 pmc2 train finish"
+#   tools/collect_profiles.sh [outdir] [phases]        default gpurun_out/profiles, phases "bench traces pmc1 pmc2 pmc3 pmc4 train finish"
 #   (phase `ref`: the 8x128 reference iteration's counters and trace alone; then `PMC_MERGE=profiles/rNN/pmc_kernels.json ... finish`)
 # (the whole set takes longer than one gpurun call allows: run `... bench traces pmc1` and `... pmc2 train finish` as two calls;
 # `finish` flattens whatever the earlier phases left under <outdir>)
@@ -8,7 +8,7 @@
 # and WRITE_SIZE each in a pass of their own).  The program itself follows `--` (never a launcher): python3 <script>.
 set -e
 out=${1:-gpurun_out/profiles}
-phases=${2:-bench traces pmc1 pmc2 train finish}
+phases=${2:-bench traces pmc1 pmc2 pmc3 pmc4 train finish}
 has() { case " $phases " in *" $1 "*) return 0;; *) return 1;; esac; }
 repo=$(pwd)
 mkdir -p "$out"
@@ -25,6 +25,16 @@ echo "kernel traces done"
 fi
 SQ="GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_INST_ANY"
 TCC="TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_ATOMIC_sum"
+# round 4: what the vector L1 / texture path is asked for (the hash-grid gather's ceiling) and what atomics leave the L2
+# (two counters per pass, each pass under its own timeout with a heartbeat: six TCP counters in one pass never came back)
+TCP1="TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum"
+TCP2="TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum"
+ATOM="TCC_EA0_ATOMIC_sum TCC_ATOMIC_sum"
+extra() {  # extra <tag> <counters...>: one pass of tools/pmc_extras.py config3
+  tag=$1; shift
+  timeout -k 10 240 rocprofv3 --pmc "$@" --output-format csv -d "$repo/$out/pmc_config3_$tag" -- python3 "$repo/tools/pmc_extras.py" config3 > /dev/null 2>&1 || echo "pass $tag failed or timed out"
+  echo "pmc config3 $tag done"
+}
 pmc() {   # pmc <tag> <script> <args...>: four passes of one command
   tag=$1; shift
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$repo/$out/pmc_${tag}_fetch" -- python3 "$@" > /dev/null 2>&1
@@ -39,6 +49,13 @@ pmc config5 "$repo/tools/pmc_extras.py" config5
 fi
 if has pmc2; then
 pmc config3 "$repo/tools/pmc_extras.py" config3
+fi
+if has pmc3; then
+extra tcp $TCP1
+extra tcp2 $TCP2
+extra atom $ATOM
+fi
+if has pmc4; then
 pmc ref8x128 "$repo/tools/pmc_extras.py" ref8x128
 fi
 if has ref; then   # only the 8x128 reference iteration again (after a change to its kernels): counters + kernel trace
@@ -70,5 +87,8 @@ flat "$out/pmc_headline_sq/*/*counter_collection.csv" $out/pmc_sq.csv
 # PMC_MERGE=<earlier pmc_kernels.json>: a partial re-collection (phase `ref`) keeps the earlier entries whose kernels are unchanged
 python3 tools/pmc_kernels_json.py ${PMC_MERGE:+--merge $PMC_MERGE} $out/pmc_kernels.json "${PMC_NOTE:-rocprofv3 --pmc, separate passes per counter set (FETCH_SIZE | WRITE_SIZE | SQ group | TCC group) over: bench.py --steps 3 --warmup 1 --no-cpu --no-extras --kernel-steps 2 --serial; tools/pmc_extras.py config5 | config3 | ref8x128}" \
   $(ls $out/pmc_*/*/*counter_collection.csv) > $out/pmc_kernels_summary.txt
-rm -rf $out/kt_* $out/pmc_*_fetch $out/pmc_*_write $out/pmc_*_sq $out/pmc_*_tcc
+flat "$out/pmc_config3_tcp/*/*counter_collection.csv" $out/pmc_config3_tcp.csv
+flat "$out/pmc_config3_tcp2/*/*counter_collection.csv" $out/pmc_config3_tcp2.csv
+flat "$out/pmc_config3_atom/*/*counter_collection.csv" $out/pmc_config3_atomics.csv
+rm -rf $out/kt_* $out/pmc_*_fetch $out/pmc_*_write $out/pmc_*_sq $out/pmc_*_tcc $out/pmc_*_tcp $out/pmc_*_tcp2 $out/pmc_*_atom
 ls -la $out

@@ -26,13 +26,19 @@ KERNELS = {
     "hashmlp_fwd_2": ("hashmlp_fwd_kernel<2>", ["hashmlp_fwd_kernelILi2E"]),
     "mlp_enc_fwd16_2": ("mlp_enc_fwd16_kernel<2>", ["mlp_enc_fwd16_kernelILi2E"]),
     "hashgrid_encode_f2": ("hashgrid_encode_f2_kernel", ["hashgrid_encode_f2_kernel"]),
-    "hashgrid_backward_pk": ("hashgrid_backward_kernel<true>", ["hashgrid_backward_kernelILb1E"]),
-    "hashgrid_backward_f32": ("hashgrid_backward_kernel<false>", ["hashgrid_backward_kernelILb0E"]),
+    # (rocprofv3 leaves these two names mangled -- _Float16 in the signature -- so the pattern is the mangled prefix)
+    "hashgrid_backward_pk": ("hashgrid_backward_kernelILb1ELb0E", ["hashgrid_backward_kernelILb1ELb0E"]),
+    "hashgrid_backward_f32": ("hashgrid_backward_kernelILb0ELb0E", ["hashgrid_backward_kernelILb0ELb0E"]),
     "mlp_bwd_fused64_4_3": ("mlp_bwd_fused64_kernel<4, 3>", ["mlp_bwd_fused64_kernelILi4ELi3E"]),
     "volrender_l2_fused_multi": ("volrender_l2_fused_multi_kernel<4>", ["volrender_l2_fused_multi_kernelILi4E"]),
     "volrender_fwd_pair_nerf_compact": ("volrender_fwd_pair_kernel<1, true>", ["volrender_fwd_pair_kernelILi1ELb1E"]),
-    "mlp_train_fwd_128_save": ("mlp_train_fwd_kernel<128, true>", ["mlp_train_fwd_kernelILi128ELb1E"]),
-    "mlp_train_fwd_128_out": ("mlp_train_fwd_kernel<128, false>", ["mlp_train_fwd_kernelILi128ELb0E"]),
+    "mlp_train_fwd_128_save": ("mlp_train_fwd_kernel<128, 1>", ["mlp_train_fwd_kernelILi128ELi1E"]),
+    "mlp_train_fwd_128_out": ("mlp_train_fwd_kernel<128, 0>", ["mlp_train_fwd_kernelILi128ELi0E"]),
+    "mlp_train_fwd_128_masks": ("mlp_train_fwd_kernel<128, 2>", ["mlp_train_fwd_kernelILi128ELi2E"]),
+    "wgrad_recompute_all": ("wgrad_recompute_all_kernel<7>", ["wgrad_recompute_all_kernelILi7E"]),
+    "wgrad_recompute_0_3": ("wgrad_recompute_kernel<7, 0, 3, false, 8>", ["wgrad_recompute_kernelILi7ELi0ELi3ELb0ELi8E"]),
+    "wgrad_recompute_3_6": ("wgrad_recompute_kernel<7, 3, 6, false, 8>", ["wgrad_recompute_kernelILi7ELi3ELi6ELb0ELi8E"]),
+    "wgrad_recompute_6_8": ("wgrad_recompute_kernel<7, 6, 8, true, 8>", ["wgrad_recompute_kernelILi7ELi6ELi8ELb1ELi8E"]),
     "mlp_bwd_128": ("mlp_bwd_kernel<128>", ["mlp_bwd_kernelILi128E"]),
     "wgrad_lds": ("wgrad_lds_kernel", ["wgrad_lds_kernel"]),
     "adam": ("adam_kernel", ["adam_kernel"]),
@@ -75,6 +81,12 @@ def main():
                 d["mfma_busy_frac"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cycles), 4)
             if "SQ_LDS_IDX_ACTIVE" in c:
                 d["lds_busy_frac"] = round(c["SQ_LDS_IDX_ACTIVE"] / (256 * cycles), 4)
+        if "TCP_TOTAL_CACHE_ACCESSES_sum" in c:            # vector-L1 tag lookups = 128-byte lines asked of the L1 per launch
+            d["l1_line_accesses_per_launch"] = int(c["TCP_TOTAL_CACHE_ACCESSES_sum"])
+        if "TCP_TCC_READ_REQ_sum" in c:
+            d["l1_to_l2_read_requests_per_launch"] = int(c["TCP_TCC_READ_REQ_sum"])
+        if "TCC_EA0_ATOMIC_sum" in c:                      # atomic requests the L2 sends on to the memory side
+            d["l2_to_memory_atomic_requests_per_launch"] = int(c["TCC_EA0_ATOMIC_sum"])
         if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c and c["TCC_HIT_sum"] + c["TCC_MISS_sum"] > 0:
             d["l2_hit_rate"] = round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4)
         res["kernels"][key] = d
