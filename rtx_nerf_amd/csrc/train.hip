@@ -2010,6 +2010,11 @@ __device__ __forceinline__ void wgrad_recompute_pass(LeanArgs a, const int sub_b
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the last look-ahead stages land in LDS this block still owns
   __syncthreads();
+  // The accumulators were last written by asm MFMAs, which hipcc's hazard recogniser does not see: the MFMA-result -> read wait
+  // states are spent here, with the accumulators going THROUGH the statement (rtxn::mfma_results_settle, for AGPRs;
+  // tools/check_asm_mfma_reads.py counted 18 of the 19 between the last contraction and the first v_accvgpr_read without it).
+#pragma unroll
+  for (int i = 0; i < NL; ++i) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]));
   // ---- one pass of atomics per wave: its quadrant of every layer of the pass ----
   const int E = KS0 * 16;
 #pragma unroll

@@ -512,10 +512,17 @@ class Trainer:
                   "arrays": [{"name": k, "dtype": str(a.dtype), "shape": list(a.shape)} for k, a in arrs.items()]}
         blob = json.dumps(header).encode()
         with open(path, "wb") as f:
-            f.write(b"RTXNCKPT" + struct.pack("<II", 1, len(blob)) + blob)
+            f.write(b"RTXNCKPT" + struct.pack("<II", self._CKPT_VERSION, len(blob)) + blob)
             for a in arrs.values():
                 f.write(b"\0" * ((-f.tell()) % 64))
                 f.write(np.ascontiguousarray(a).tobytes())
+
+    # version 2 (round 3's format + a guarantee): every array of state_arrays() is in the file.  Version 1 files written before
+    # the table's per-entry Adam step counts existed (or with RTXN_TABLE_ADAM=dense) lack `table_adam_steps`; loading one used
+    # to leave the counts at zero beside warmed moments -- every entry's bias correction restarted at t = 1, an effective table
+    # learning rate of ~0.3x for thousands of steps, silently.  Now: a missing array is an error, except that a
+    # version-1 file's missing step counts are filled with the file's global step (what the dense rule would have used), loudly.
+    _CKPT_VERSION = 2
 
     def load_checkpoint(self, path):
         with open(path, "rb") as f:
@@ -523,9 +530,17 @@ class Trainer:
                 raise ValueError(f"{path}: not an RTXN checkpoint")
             version, n = struct.unpack("<II", f.read(8))
             header = json.loads(f.read(n))
-            if version != 1 or header["encoding"] != self.encoding:
+            if version not in (1, self._CKPT_VERSION) or header["encoding"] != self.encoding:
                 raise ValueError(f"{path}: version {version} / encoding {header['encoding']} does not match this trainer")
             dst = self.state_arrays()
+            missing = set(dst) - {ent["name"] for ent in header["arrays"]}
+            if missing == {"table_adam_steps"} and version == 1:
+                import warnings
+                warnings.warn(f"{path}: version-1 checkpoint without per-entry table step counts: every entry's count is set to the "
+                              f"checkpoint's step ({header['step']})")
+                dst["table_adam_steps"].fill_(int(header["step"]))
+            elif missing:
+                raise ValueError(f"{path}: checkpoint lacks {sorted(missing)}, which this trainer's state needs")
             for ent in header["arrays"]:
                 f.seek((-f.tell()) % 64, 1)
                 a = np.frombuffer(f.read(int(np.prod(ent["shape"])) * np.dtype(ent["dtype"]).itemsize), dtype=ent["dtype"])
@@ -733,6 +748,8 @@ class Trainer:
         o.lr, o.beta1, o.beta2, o.eps = self.lr, 0.9, 0.999, 1e-8
         o.table_lr, o.table_eps, o.loss_scale_divisor = self.lr * 10.0, 1e-15, 1.0
         self._entry_args, self._entry_cap = a, cap
+        self._entry_step_host = self.step_count      # what the device counter holds now (an eager step() in between is noticed by step_entry)
+        self._entry_inputs = (self.graph_rays_o.data_ptr(), self.graph_rays_d.data_ptr(), self.graph_targets.data_ptr())
         self._clear_grads()            # the call's optimizer clears what it consumes; it must start from zeros
         return a
 
@@ -740,6 +757,11 @@ class Trainer:
         """One optimisation step on graph_rays_o / graph_rays_d / graph_targets through rtxn_train_step (entry_args() first).
         Returns the (device) loss scalar; like step_captured() it never reads the segment count on the host."""
         self._det_select()
+        if getattr(self, "_entry_args", None) is None:
+            raise RuntimeError("step_entry: call entry_args() first")
+        if self._entry_inputs != (self.graph_rays_o.data_ptr(), self.graph_rays_d.data_ptr(), self.graph_targets.data_ptr()):
+            # capture_step() re-created the input buffers after entry_args(): the argument block still points at the old ones
+            raise RuntimeError("step_entry: graph_rays_o / graph_rays_d / graph_targets were re-allocated since entry_args(); call entry_args() again")
         if not getattr(self, "_grads_clean", False):
             self._clear_grads()
         if int(self.step_count) != getattr(self, "_entry_step_host", self.step_count):

@@ -46,6 +46,33 @@ def test_checker_ignores_reads_inside_asm_and_compiler_mfmas(tmp_path):
     assert chk.check(str(g)) == []          # hipcc pads the MFMAs it emits itself
 
 
+AGPR_BAD = """
+_Z7kernel2v:
+	;;#ASMSTART
+	v_mfma_f32_32x32x16_f16 a[0:15], v[18:21], v[22:25], a[0:15]
+	;;#ASMEND
+	v_accvgpr_read_b32 v40, a3
+	s_nop 15
+	s_nop 7
+	v_accvgpr_read_b32 v41, a4
+	v_add_f32_e32 v0, v0, v1
+	s_endpgm
+"""
+
+
+def test_checker_tracks_accumulators_in_agprs(tmp_path):
+    """the weight-gradient accumulators of the fused backward kernels live in AGPRs (asm "+a"); a compiler-generated
+    v_accvgpr_read inside the MFMA's wait states is the same hazard as a VGPR read.  a3 is read at once (flagged), a4 behind the
+    wait states (fine); v0 / v1 are a different register file than a0 / a1 (not flagged)."""
+    f = tmp_path / "agpr.s"
+    f.write_text(AGPR_BAD)
+    found = chk.check(str(f))
+    assert len(found) == 1 and "reads a3 0 wait states" in found[0], found
+    g = tmp_path / "agpr_ok.s"
+    g.write_text(AGPR_BAD.replace("	v_accvgpr_read_b32 v40, a3\n", ""))
+    assert chk.check(str(g)) == []
+
+
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not present")
 def test_built_isa_keeps_compiler_reads_behind_asm_mfma_wait_states():
     out = subprocess.run(["make", "-C", ROOT, "-s", "-j4", "check-isa"], capture_output=True, text=True)

@@ -15,23 +15,26 @@ import sys
 
 NEED = 19
 RE_KERNEL = re.compile(r"^(_Z\w+):")
-RE_REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+# VGPRs and AGPRs are tracked in separate namespaces ("v", n) / ("a", n): the weight-gradient accumulators of
+# mlp_bwd_fused64_kernel and wgrad_recompute_* live in AGPRs through asm "+a" operands, and a compiler-generated
+# v_accvgpr_read (or any other instruction naming an a-register) inside the wait states is the same hazard.
+RE_REG = re.compile(r"\b([va])(\d+)\b|\b([va])\[(\d+):(\d+)\]")
 
 
 def regs(tok):
     out = []
     for m in RE_REG.finditer(tok):
         if m.group(1) is not None:
-            out.append(int(m.group(1)))
+            out.append((m.group(1), int(m.group(2))))
         else:
-            out.extend(range(int(m.group(2)), int(m.group(3)) + 1))
+            out.extend((m.group(3), i) for i in range(int(m.group(4)), int(m.group(5)) + 1))
     return out
 
 
 def check(path):
     findings = []
     kernel, in_asm = None, False
-    pending = {}            # vgpr -> wait states since an asm MFMA wrote it
+    pending = {}            # (file, number) of a VGPR / AGPR -> wait states since an asm MFMA wrote it
     for n, raw in enumerate(open(path), 1):
         line = raw.strip()
         m = RE_KERNEL.match(line)
@@ -59,7 +62,7 @@ def check(path):
         if not in_asm and not op.startswith("s_"):
             for r in {r for o in src_ops for r in regs(o)}:
                 if r in pending and pending[r] < NEED:
-                    findings.append(f"{path}:{n}: {kernel[:70]}: `{line}` reads v{r} {pending[r]} wait states after an asm MFMA wrote it")
+                    findings.append(f"{path}:{n}: {kernel[:70]}: `{line}` reads {r[0]}{r[1]} {pending[r]} wait states after an asm MFMA wrote it")
                     break
         for r in list(pending):
             pending[r] += states
