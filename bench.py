@@ -348,9 +348,17 @@ def train_ref_record(batch_rays, grid_res, steps, warmup, dense_grid=True, mode=
     tr = Trainer(R, occ, encoding="freq", n_neurons=128, n_hidden_layers=8, n_dir_freqs=12, batch_rays=B, max_segments=cap, lr=1e-3,
                  loss_scale=1.0 if mode == "compat" else 128.0, density_scale=1.0 if mode == "compat" else 300.0, mode=mode)
 
+    # (batches are gathered into buffers allocated once: a fresh tensor per step went through torch's caching allocator, and after
+    # an earlier record's torch.cuda.empty_cache() that made the EAGER loop below 2-4x slower on the host while every kernel and
+    # the captured step took what they always take -- tools/probe/order_probe.py, profiles/r04/order_probe.txt)
+    bo, bd, bt = (torch.empty((B, 3), device="cuda") for _ in range(3))
+
     def batch():
         idx = torch.randint(0, ro.shape[0], (B,), device="cuda", generator=g)
-        return ro[idx].contiguous(), rd[idx].contiguous(), tg[idx].contiguous()
+        torch.index_select(ro, 0, idx, out=bo)
+        torch.index_select(rd, 0, idx, out=bd)
+        torch.index_select(tg, 0, idx, out=bt)
+        return bo, bd, bt
 
     for _ in range(warmup):
         loss = tr.step(*batch())
@@ -446,8 +454,10 @@ def train_ref_record(batch_rays, grid_res, steps, warmup, dense_grid=True, mode=
 
 
 def extra_train_ref8x128(steps, warmup):
-    # (the 4096-ray variant first: measured in the same process AFTER the two large ones -- 70-GB workspaces allocated and
-    # released -- its steps took twice as long)
+    # (round 3 measured the 4096-ray variant first because after the two large ones "its steps took twice as long".  Round 4 looked:
+    # tools/probe/order_probe.py -- kernel times by HIP events and the captured step are the same before and after a 43-GiB
+    # workspace has come and gone (ratio 0.99-1.01); what doubled was the host side of the EAGER loop after torch.cuda.empty_cache(),
+    # through per-step tensor allocations that train_ref_record no longer makes.  The order is kept for continuity of the records.)
     small = train_ref_record(4096, 128, 3 * steps, warmup, dense_grid=False, mode="nerf")
     return {"b22528_dense8": train_ref_record(128 * 176, 8, steps, warmup, captured=False),
             "b45056_dense8": train_ref_record(256 * 176, 8, max(4, steps // 2), warmup, captured=False),
