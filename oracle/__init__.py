@@ -207,6 +207,21 @@ def render(look_at, focal, aspect, W, H, R, occ, trace_mode, cfg, params_f16, ra
     return pix, int(tot.value)
 
 
+def render_tiled(look_at, focal, aspect, W, H, R, occ, trace_mode, cfg, params_f16, ray_ids):
+    """orc_render_tiled: the same ray march with the network evaluated 64 samples at a time by an AVX2 + FMA micro-kernel (the
+    cpu_baseline leg of bench.py); agrees with render() up to the single-precision sine of the encoding."""
+    la = _f32(look_at).reshape(16)
+    p = np.ascontiguousarray(params_f16, dtype=np.float16)
+    ids = np.ascontiguousarray(ray_ids, dtype=np.uint32)
+    occ_a = None if occ is None else np.ascontiguousarray(occ, dtype=np.uint32)
+    pix = np.zeros((ids.size, 3), np.float32)
+    tot = C.c_long(0)
+    lib().orc_render_tiled(_p(la), C.c_float(focal), C.c_float(aspect), C.c_uint(W), C.c_uint(H), C.c_int(R),
+                           _p(occ_a), C.c_int(trace_mode), C.byref(cfg), _p(p), _p(ids), C.c_long(ids.size),
+                           _p(pix), C.byref(tot))
+    return pix, int(tot.value)
+
+
 def volrender_fwd_nerf(radiance, num_hits, indices, step, K=32):
     rad, st = _f32(radiance), _f32(step)
     nh, idx = _i32(num_hits), _i32(indices)

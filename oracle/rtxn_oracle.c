@@ -696,6 +696,144 @@ void orc_render(const float* look_at, float focal_length, float aspect_ratio, un
 }
 
 /* ------------------------------------------------------------------------- */
+/* cpu_baseline leg of bench.py: the same host ray-march with the network     */
+/* evaluated for 64 samples at a time (two segments) as small GEMMs --        */
+/* AVX2 + FMA micro-kernel of 4 samples x 16 outputs, weights reused across   */
+/* the tile, activations rounded to fp16 by the F16C conversion instructions, */
+/* the encoding's sines in single precision on an exactly reduced argument.   */
+/* Same algorithm and roundings as orc_render (fp16 weights, fp32 accumulate, */
+/* fp16 activations); the summation ORDER over k is the same too, so the only */
+/* differences are the float sine (<= 1 fp16 ulp of a feature, now and then)  */
+/* -- validated against orc_render in tests/test_oracle_kat.py.  It exists so */
+/* that the CPU figure beside the GPU one is a tuned one*/
+/* ------------------------------------------------------------------------- */
+#include <immintrin.h>
+
+static inline float rh_hw(float f) { return _cvtsh_ss(_cvtss_sh(f, _MM_FROUND_TO_NEAREST_INT)); }
+
+/* out[s][r] = act( sum_k wT[k][r] * in[s][k] ), s < 64 (padded tile), r < rows (multiple of 16); relu_round: ReLU + fp16 */
+static void tiled_layer(const float* wT, int in_w, int rows, const float* in, int in_stride, float* out, int out_stride, int relu_round) {
+  for (int s0 = 0; s0 < 64; s0 += 4) {
+    const float* a0 = in + (long)s0 * in_stride;
+    for (int r0 = 0; r0 < rows; r0 += 16) {
+      __m256 c00 = _mm256_setzero_ps(), c01 = c00, c10 = c00, c11 = c00, c20 = c00, c21 = c00, c30 = c00, c31 = c00;
+      const float* w = wT + r0;
+      for (int k = 0; k < in_w; ++k, w += rows) {
+        const __m256 w0 = _mm256_loadu_ps(w), w1 = _mm256_loadu_ps(w + 8);
+        const __m256 x0 = _mm256_broadcast_ss(a0 + k), x1 = _mm256_broadcast_ss(a0 + in_stride + k);
+        const __m256 x2 = _mm256_broadcast_ss(a0 + 2 * in_stride + k), x3 = _mm256_broadcast_ss(a0 + 3 * in_stride + k);
+        c00 = _mm256_fmadd_ps(w0, x0, c00); c01 = _mm256_fmadd_ps(w1, x0, c01);
+        c10 = _mm256_fmadd_ps(w0, x1, c10); c11 = _mm256_fmadd_ps(w1, x1, c11);
+        c20 = _mm256_fmadd_ps(w0, x2, c20); c21 = _mm256_fmadd_ps(w1, x2, c21);
+        c30 = _mm256_fmadd_ps(w0, x3, c30); c31 = _mm256_fmadd_ps(w1, x3, c31);
+      }
+      __m256 c[4][2] = {{c00, c01}, {c10, c11}, {c20, c21}, {c30, c31}};
+      for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 2; ++j) {
+          __m256 v = c[i][j];
+          if (relu_round) {
+            v = _mm256_max_ps(v, _mm256_setzero_ps());
+            v = _mm256_cvtph_ps(_mm256_cvtps_ph(v, _MM_FROUND_TO_NEAREST_INT));
+          }
+          _mm256_storeu_ps(out + (long)(s0 + i) * out_stride + r0 + 8 * j, v);
+        }
+    }
+  }
+}
+
+void orc_render_tiled(const float* look_at, float focal_length, float aspect_ratio, unsigned width, unsigned height, int R,
+                      const uint32_t* occ, int trace_mode, const orc_mlp_cfg* cfg, const uint16_t* params, const unsigned* ray_ids,
+                      long n_rays, float* pixels, long* total_samples) {
+  const int W = cfg->n_neurons, P = orc_mlp_enc_padded(cfg), nh = cfg->n_hidden_layers;
+  const int ST = P > W ? P : W;                      /* row stride of the activation tiles */
+  float* wT = net_prepare(cfg, params);
+  long tot = 0;
+  const int S = 3 * R + 8;
+#pragma omp parallel reduction(+ : tot)
+  {
+    float* sp = (float*)malloc(sizeof(float) * 3 * S);
+    float* ep = (float*)malloc(sizeof(float) * 3 * S);
+    float* ta = (float*)aligned_alloc(64, sizeof(float) * 64 * ST);
+    float* tb = (float*)aligned_alloc(64, sizeof(float) * 64 * ST);
+    float* rad = (float*)malloc(sizeof(float) * 4 * ORC_K * S);
+#pragma omp for schedule(dynamic, 4)
+    for (long r = 0; r < n_rays; ++r) {
+      unsigned gid = ray_ids[r];
+      float o[3], d[3], v[2];
+      orc_make_ray(look_at, focal_length, aspect_ratio, width, height, gid % width, gid / width, o, d, v);
+      orc_sink s;
+      s.start = sp; s.end = ep; s.t0 = 0; s.t1 = 0; s.seg_ray = 0; s.base = 0; s.cap = S; s.ray = 0; s.n = 0;
+      if (trace_mode == 0) march_compat(o, d, R, occ, &s);
+      else march_dda(o, d, R, occ, &s);
+      const int nseg = s.n < S ? s.n : S;
+      const float inc = 1.0f / ORC_K;
+      for (int j0 = 0; j0 < nseg; j0 += 2) {          /* a tile: two segments = 64 samples (the second may be padding) */
+        for (int q = 0; q < 64; ++q) {
+          const int j = j0 + q / ORC_K < nseg ? j0 + q / ORC_K : j0, i = q % ORC_K;
+          float t = 0.0f;
+          for (int u = 0; u < i; ++u) t += inc;         /* the reference accumulates t by repeated += 1/32 (sampler.cu:65) */
+          float in5[5];
+          for (int a = 0; a < 3; ++a) in5[a] = fmaf(t, ep[3 * j + a] - sp[3 * j + a], sp[3 * j + a]);
+          in5[3] = v[0]; in5[4] = v[1];
+          float* e = ta + (long)q * ST;
+          int f_idx = 0;
+          for (int part = 0; part < 2; ++part) {
+            const int nd = part == 0 ? cfg->n_pos_dims : cfg->n_dir_dims, F = part == 0 ? cfg->n_pos_freqs : cfg->n_dir_freqs;
+            const int off = part == 0 ? 0 : cfg->n_pos_dims;
+            for (int dim = 0; dim < nd; ++dim)
+              for (int f = 0; f < F; ++f) {
+                float tt = ldexpf(in5[off + dim], f);             /* exact */
+                tt -= 2.0f * floorf(tt * 0.5f);                   /* exact: sin(pi t) has period 2 */
+                e[f_idx++] = rh_hw(sinf((float)M_PI * tt));
+                e[f_idx++] = rh_hw(sinf((float)M_PI * tt + (float)(M_PI / 2)));
+              }
+          }
+          for (; f_idx < P; ++f_idx) e[f_idx] = 1.0f;
+        }
+        const float* w = wT;
+        int in_w = P;
+        float *a = ta, *b = tb;
+        for (int l = 0; l < nh; ++l) {
+          tiled_layer(w, in_w, W, a, ST, b, ST, 1);
+          w += (long)W * in_w;
+          in_w = W;
+          float* t2 = a; a = b; b = t2;
+        }
+        tiled_layer(w, W, 16, a, ST, b, ST, 0);
+        const int live = (nseg - j0 >= 2 ? 2 : 1) * ORC_K;
+        for (int q = 0; q < live; ++q)
+          for (int c = 0; c < 4; ++c) {
+            const float z = b[(long)q * ST + c];
+            rad[4 * ((long)j0 * ORC_K + q) + c] = rh_hw(cfg->output_activation == 1 ? 1.0f / (1.0f + expf(-z)) : z);
+          }
+      }
+      float T = 0.0f, t_prev = 0.0f, acc3[3] = {0, 0, 0};
+      for (int j = 0; j < nseg; ++j) {
+        float t_initial = 0.0f;
+        for (int i = 0; i < ORC_K; ++i) {
+          t_initial += inc;
+          const float* rd = rad + 4 * ((long)j * ORC_K + i);
+          const float delta = fabsf(t_initial - t_prev);
+          t_prev = t_initial;
+          T = fmaf(delta, rd[3], T);
+          const float wgt = expf(-T) * (1 - expf(-delta * rd[3]));
+          acc3[0] += wgt * rd[0];
+          acc3[1] += wgt * rd[1];
+          acc3[2] += wgt * rd[2];
+        }
+      }
+      tot += (long)nseg * ORC_K;
+      pixels[3 * r] = acc3[0];
+      pixels[3 * r + 1] = acc3[1];
+      pixels[3 * r + 2] = acc3[2];
+    }
+    free(sp); free(ep); free(ta); free(tb); free(rad);
+  }
+  free(wT);
+  if (total_samples) *total_samples = tot;
+}
+
+/* ------------------------------------------------------------------------- */
 /* RTXN_VR_NERF (this build's corrected mode, not in the reference):          */
 /* canonical quadrature, step = world-space length of each sample's interval, */
 /*   C = sum_i T_i (1-exp(-x_i)) c_i, x_i = step_i sigma_i,                   */

@@ -365,6 +365,26 @@ def test_render_equals_staged_pipeline(oracle):
         np.testing.assert_array_equal(pix, pix2)
 
 
+@pytest.mark.parametrize("W,nh,occupied,mode", [(128, 8, True, 1), (64, 2, False, 0), (128, 3, True, 0)])
+def test_tiled_cpu_render_agrees_with_the_scalar_restatement(oracle, W, nh, occupied, mode):
+    """orc_render_tiled (bench.py's cpu_baseline leg: 64-sample tiles through an AVX2 + FMA micro-kernel, F16C roundings) against
+    orc_render on the same rays: the same segments and sample count; pixels within 2e-4 -- the k order of every dot product is the
+    same, what differs is the single-precision sine of the encoding (a feature one fp16 ulp off now and then).  Odd segment
+    counts exercise the half-filled last tile."""
+    R, Wd, Hd = 16, 20, 14
+    cfg = oracle.mlp_cfg(n_neurons=W, n_hidden_layers=nh)
+    params = scenes.xavier_params_fp16(W, nh, oracle.mlp_enc_padded(cfg), seed=9)
+    occ = scenes.pack_occupancy(scenes.sphere_density(R, 0.7)) if occupied else None
+    la = scenes.pose_spherical(35.0, -20.0, origin_scale=10.0)
+    f = scenes.lego_focal_length(True)
+    ids = np.arange(Wd * Hd, dtype=np.uint32)
+    a, na = oracle.render(la, f, Wd / Hd, Wd, Hd, R, occ, mode, cfg, params, ids)
+    b, nb = oracle.render_tiled(la, f, Wd / Hd, Wd, Hd, R, occ, mode, cfg, params, ids)
+    assert na == nb > 0 and a.std() > 1e-3
+    np.testing.assert_allclose(b, a, rtol=0, atol=2e-4)
+    assert np.abs(a - b).mean() < 5e-6
+
+
 @pytest.mark.parametrize("variant", ["dense", "sphere"])
 def test_config1_host_ray_march(oracle, variant):
     """BASELINE.json configs[0]: 32^3 grid + 2x64 MLP, 1024 rays (32x32 launch), host-CPU ray march,
