@@ -508,9 +508,15 @@ __device__ __forceinline__ void store_fragment_rows_pair(_Float16* X, int kk, lo
 // only the masks, the weight-gradient kernel recomputes the activations): 160 instead of 2,208 bytes written per sample.
 constexpr int kSaveNone = 0, kSaveAll = 1, kSaveMasks = 2;
 constexpr int kEncScratch = 6 * 1024;                    // per wave: 48 feature rows x 64 samples of the encoding (layer 0's operand)
-template <int W, int SAVE = kSaveAll>
-__global__ __launch_bounds__(kThreads, 2) void mlp_train_fwd_kernel(TrainArgs a) {
-  constexpr int RT = W / 32, KS = W / 16;
+// NW: waves per block = 64-sample column pairs per block tile.  4 (256 samples, two blocks per CU, one weight buffer): the form of
+// rounds 1-3.  8 (512 samples, ONE block per CU, the weights double-buffered, the next layer's fetched under this layer's MFMAs;
+// 128 wide only): a layer's 32 KiB of A fragments then feed twice the samples -- an experiment (RTXN_TRAIN_FWD_WAVES=8): half the
+// LDS-DMA weight stream per sample bought nothing (train_forward_impl has the A/B), so this kernel is not paced by it.
+template <int W, int SAVE = kSaveAll, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 2) void mlp_train_fwd_kernel(TrainArgs a) {
+  constexpr int RT = W / 32, KS = W / 16, TILE = 64 * NW;
+  constexpr bool DB = NW == 8;                             // double-buffered weights
+  static_assert(NW == 4 || (NW == 8 && W == 128), "8-wave blocks are built for the 128-wide model");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
   a.S = live_samples(a.dc, a.S);
@@ -519,11 +525,33 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_train_fwd_kernel(TrainArgs a)
   // and leaves their activations where the full pass would have (the backward kernels and the weight-gradient GEMM read them
   // there); slots past the list neither store nor count.
   const int live_n = a.live_list ? *a.live_count : 0;
-  if (a.live_list ? (int)blockIdx.x * 8 >= live_n : (long)blockIdx.x * kTile >= a.S) return;
-  const long tile0 = (long)blockIdx.x * kTile + wave * 64;
+  if (a.live_list ? (int)blockIdx.x * (2 * NW) >= live_n : (long)blockIdx.x * TILE >= a.S) return;
+  const long tile0 = (long)blockIdx.x * TILE + wave * 64;
   const int KS0 = a.E / 16;
   const int L = a.n_hidden;
   long off = 0;
+  const int WB = (KS0 > KS ? KS0 : KS) * RT * 1024;        // one weight buffer
+  // every wave of the block fetches its share of a layer's fragments (1 KiB per wave instruction)
+  auto stage_w = [&](const uint8_t* g, uint8_t* lds_buf, int bytes) {
+    for (int o = wave * 1024; o < bytes; o += NW * 1024)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + o + lane * 16),
+                                       (__attribute__((address_space(3))) void*)(lds_buf + o), 16, 0, 0);
+  };
+  auto wbuf = [&](int l) -> uint8_t* { return smem + (DB ? (l & 1) * WB : 0); };
+  auto layer_bytes = [&](int l) -> int { return (l == 0 ? KS0 * RT : (l < L ? KS * RT : KS)) * 1024; };
+  // Layer l's fragments in LDS, ready.  Single buffer: fetched here (everyone is done with layer l-1 first).  Double buffer: they
+  // were fetched a layer ago; wait for them, and the buffer layer l-1 used is free for layer l+1 (prefetch(l) issues that).
+  auto weights_ready = [&](int l) -> const uint8_t* {
+    if (!DB) {
+      if (l > 0) __syncthreads();
+      stage_w(a.packed + off, wbuf(l), layer_bytes(l));
+    }
+    rtxn::staged_barrier();
+    return wbuf(l);
+  };
+  auto prefetch = [&](int l) {                             // layer l + 1 into the other buffer (no output layer in the live pass)
+    if (DB && l + 1 <= L && !(a.live_list && l + 1 == L)) stage_w(a.packed + off + layer_bytes(l), wbuf(l + 1), layer_bytes(l + 1));
+  };
 
   // per-lane byte offset of this lane's sample within a feature row, lane-half row shift (4h rows) folded in
   unsigned lane_off[2];
@@ -535,9 +563,12 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_train_fwd_kernel(TrainArgs a)
     ok_s[ct] = s < a.S;
     store_s[ct] = true;                                   // padding columns of the last tile are written as zeros
     if (a.live_list) {
-      const int slot = (int)blockIdx.x * 8 + wave * 2 + ct;
+      const int slot = (int)blockIdx.x * (2 * NW) + wave * 2 + ct;
       ok_s[ct] = store_s[ct] = slot < live_n;
       s = (long)(ok_s[ct] ? a.live_list[slot] : 0) * 32 + col;     // slots past the list read segment 0 and store nothing
+    } else if (tile0 >= a.Sp) {                             // 512-sample tiles over a row stride that is a multiple of 256: waves past it
+      ok_s[ct] = store_s[ct] = false;                       // read the first columns and store nothing
+      s = ct * 32 + col;
     }
     samp[ct] = s;
     lane_off[ct] = (unsigned)((s + 4L * h * a.Sp) * 2);
@@ -552,15 +583,15 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_train_fwd_kernel(TrainArgs a)
   // that lane-half h = 1 (rows + 4) reads the other half of the banks than h = 0.
   half8 bf[KS][2], bg[KS][2];
   {
-    stage_rt(a.packed, smem, KS0 * RT * 1024, tid);
-    uint8_t* scratch = smem + (size_t)(KS0 > KS ? KS0 : KS) * RT * 1024 + wave * kEncScratch;
+    if (DB) stage_w(a.packed, wbuf(0), layer_bytes(0));
+    uint8_t* scratch = smem + (DB ? 2 : 1) * WB + wave * kEncScratch;
     const int r8 = lane >> 3, jg = lane & 7;              // row of a piece; 16-byte sample group of the wave's 64 samples
     // (column of sample group jg: the wave's samples are two runs of 32 -- consecutive, or with the live list two listed segments)
     const long gcol = samp[jg >> 2] - col + 8 * (jg & 3);
     const _Float16* src = a.encT + gcol + (long)r8 * a.Sp;
     const int wr_off = r8 * 128 + ((jg * 16) ^ (((r8 >> 2) & 1) * 64));
     const int rd_off = (4 * h) * 128 + ((col * 2) ^ (h * 64));   // + feature row (of the chunk, rows & 7 < 4) * 128 + (ct * 64, same swap)
-    rtxn::staged_barrier();
+    const uint8_t* w0 = weights_ready(0);
     floatx16 acc[RT][2];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -587,12 +618,15 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_train_fwd_kernel(TrainArgs a)
             b[ct][j] = *reinterpret_cast<const _Float16*>(scratch + (perm_feature(k3, 0, j)) * 128 + (rd_off ^ (ct * 64)));
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-          const half8 af = *reinterpret_cast<const half8*>(smem + ((rt * KS0 + kk) * 64 + lane) * 16);
+          const half8 af = *reinterpret_cast<const half8*>(w0 + ((rt * KS0 + kk) * 64 + lane) * 16);
 #pragma unroll
           for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, b[ct], acc[rt][ct], 0, 0, 0);
         }
       }
     }
+    // (layer 0 reads LDS with compiler-generated loads, in front of which hipcc waits for every LDS-DMA in flight: layer 1's
+    // fragments are fetched behind them, not underneath)
+    prefetch(0);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -641,9 +675,11 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_train_fwd_kernel(TrainArgs a)
   // hidden layer on the hand-scheduled pipeline of the inference kernel (accumulators double-buffered by row tile: the
   // compiler-scheduled loop kept all RT tiles live and spilled at W = 128); nothing is staged underneath it here, and
   // the row tile it leaves pending is converted at once because the activations are stored after every layer
-  auto hidden_layer = [&](half8 (&in)[KS][2], half8 (&out)[KS][2]) {
+  auto hidden_layer = [&](int l, half8 (&in)[KS][2], half8 (&out)[KS][2]) {
+    const uint8_t* w = weights_ready(l);
+    prefetch(l);                                          // under this layer's MFMAs (pipe_layer reads LDS in asm: no compiler wait)
     floatx16 acc2[2][2];
-    rtxn::pipe_layer<RT, KS, KS>(smem, in, out, acc2, lane);
+    rtxn::pipe_layer<RT, KS, KS>(w, in, out, acc2, lane);
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -652,24 +688,15 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_train_fwd_kernel(TrainArgs a)
   // ---- hidden layers 1..L-1 (ping-pong bf <-> bg) ----
   int l = 1;
   for (; l + 1 < L; l += 2) {
-    __syncthreads();
-    stage_rt(a.packed + off, smem, KS * RT * 1024, tid);
-    rtxn::staged_barrier();
-    hidden_layer(bf, bg);
+    hidden_layer(l, bf, bg);
     save_acts(l, bg);
     off += (long)KS * RT * 1024;
-    __syncthreads();
-    stage_rt(a.packed + off, smem, KS * RT * 1024, tid);
-    rtxn::staged_barrier();
-    hidden_layer(bg, bf);
+    hidden_layer(l + 1, bg, bf);
     save_acts(l + 1, bf);
     off += (long)KS * RT * 1024;
   }
   if (l < L) {
-    __syncthreads();
-    stage_rt(a.packed + off, smem, KS * RT * 1024, tid);
-    rtxn::staged_barrier();
-    hidden_layer(bf, bg);
+    hidden_layer(l, bf, bg);
     save_acts(l, bg);
     off += (long)KS * RT * 1024;
 #pragma unroll
@@ -679,11 +706,9 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_train_fwd_kernel(TrainArgs a)
   }
   if (a.live_list) return;                                // the live pass saves activations only: the outputs exist already
   // ---- output layer ----
-  __syncthreads();
-  stage_rt(a.packed + off, smem, KS * 1024, tid);
-  rtxn::staged_barrier();
+  const uint8_t* wL = weights_ready(L);
   floatx16 acc[2];
-  out_mma<KS, KS>(smem, bf, acc, lane);
+  out_mma<KS, KS>(wL, bf, acc, lane);
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct) {
     const long s = tile0 + ct * 32 + col;
@@ -2458,17 +2483,26 @@ static int train_forward_impl(const rtxn_mlp* m, const void* encT, long n_sample
   a.live_list = live_list;
   a.live_count = live_count;
   const int RT = W / 32, KS = W / 16, KS0 = a.E / 16;
-  const size_t lds = (size_t)(KS0 > KS ? KS0 : KS) * RT * 1024 + 4 * kEncScratch;
+  // 128 wide, RTXN_TRAIN_FWD_WAVES=8: 8-wave blocks of 512 samples with double-buffered weights.  Built on the guess that the kernel
+  // is paced by its weight stream; the same-box A/B says it is not (outputs only 1.050 against 1.068 ms per 4.7 M samples, with the
+  // sign masks 1.43 against 1.35: the double buffer's vmcnt(0) also waits for the mask stores), so the 4-wave form stays the default.
+  static const bool waves8 = getenv("RTXN_TRAIN_FWD_WAVES") && atoi(getenv("RTXN_TRAIN_FWD_WAVES")) == 8;
+  const int NW = W == 128 && waves8 ? 8 : 4;
+  const size_t lds = (size_t)(KS0 > KS ? KS0 : KS) * RT * 1024 * (NW == 8 ? 2 : 1) + NW * kEncScratch;
   hipStream_t s = rtxn::as_stream(stream);
-  const dim3 grid((unsigned)(Sp / kTile)), block(kThreads);
-#define RTXN_FWD_LAUNCH(WW, SAVE)                                                                        \
-  do {                                                                                                   \
-    RTXN_HIP(set_lds_once(reinterpret_cast<const void*>(mlp_train_fwd_kernel<WW, SAVE>), (int)lds));      \
-    hipLaunchKernelGGL((mlp_train_fwd_kernel<WW, SAVE>), grid, block, lds, s, a);                         \
+  const dim3 grid((unsigned)((Sp + 64 * NW - 1) / (64 * NW))), block(64 * NW);
+#define RTXN_FWD_LAUNCH(WW, SAVE, NWV)                                                                        \
+  do {                                                                                                        \
+    RTXN_HIP(set_lds_once(reinterpret_cast<const void*>(mlp_train_fwd_kernel<WW, SAVE, NWV>), (int)lds));      \
+    hipLaunchKernelGGL((mlp_train_fwd_kernel<WW, SAVE, NWV>), grid, block, lds, s, a);                         \
   } while (0)
-  if (W == 64) { if (workspace) RTXN_FWD_LAUNCH(64, kSaveAll); else RTXN_FWD_LAUNCH(64, kSaveNone); }
-  else if (lean) RTXN_FWD_LAUNCH(128, kSaveMasks);
-  else         { if (workspace) RTXN_FWD_LAUNCH(128, kSaveAll); else RTXN_FWD_LAUNCH(128, kSaveNone); }
+  if (W == 64) { if (workspace) RTXN_FWD_LAUNCH(64, kSaveAll, 4); else RTXN_FWD_LAUNCH(64, kSaveNone, 4); }
+  else if (NW == 8) {
+    if (lean) RTXN_FWD_LAUNCH(128, kSaveMasks, 8);
+    else if (workspace) RTXN_FWD_LAUNCH(128, kSaveAll, 8);
+    else RTXN_FWD_LAUNCH(128, kSaveNone, 8);
+  } else if (lean) RTXN_FWD_LAUNCH(128, kSaveMasks, 4);
+  else         { if (workspace) RTXN_FWD_LAUNCH(128, kSaveAll, 4); else RTXN_FWD_LAUNCH(128, kSaveNone, 4); }
 #undef RTXN_FWD_LAUNCH
   RTXN_LAUNCH_CHECK(workspace ? "mlp_train_fwd_kernel" : "mlp_train_fwd_kernel<outputs only>");
   return RTXN_OK;
