@@ -24,6 +24,7 @@ build/%.s: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/mlp_internal.h $(CSRC)/hashgri
 	$(HIPCC) $(HIPFLAGS) $(EXTRA) -S --cuda-device-only $< -o $@
 check-isa: build/train.s build/mlp.s build/hashmlp.s
 	python3 tools/check_asm_mfma_reads.py $^
+	python3 tools/check_asm_sgpr_hazard.py $^
 
 build/loader.o: $(CSRC)/loader.cpp $(CSRC)/common.h include/rtxn.h
 	@mkdir -p build

@@ -77,3 +77,30 @@ def test_checker_tracks_accumulators_in_agprs(tmp_path):
 def test_built_isa_keeps_compiler_reads_behind_asm_mfma_wait_states():
     out = subprocess.run(["make", "-C", ROOT, "-s", "-j4", "check-isa"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+SGPR_BAD = """
+_Z6kernelv:
+	v_readlane_b32 s4, v248, 15
+	v_readlane_b32 s5, v248, 16
+	;;#ASMSTART
+	global_load_dwordx4 a[0:3], v204, s[4:5]
+	;;#ASMEND
+	s_endpgm
+"""
+
+
+def test_sgpr_checker_flags_an_asm_load_right_behind_a_restored_spill(tmp_path):
+    """Round 4: an asm vector-memory instruction reading an SGPR pair that v_readlane restored less than 5 wait states earlier
+    (hipcc pads only its own instructions) -- the fault of the first register-staged weight loads; `s_nop 4` in the statement."""
+    import check_asm_sgpr_hazard as sg
+    f = tmp_path / "bad.s"
+    f.write_text(SGPR_BAD)
+    found = sg.check(str(f))
+    assert len(found) == 1 and "reads s4 1 wait states" in found[0], found
+    g = tmp_path / "good.s"
+    g.write_text(SGPR_BAD.replace("	global_load", "	s_nop 4\n	global_load"))
+    assert sg.check(str(g)) == []
+    h = tmp_path / "salu.s"          # an SALU-written pair needs no padding
+    h.write_text(SGPR_BAD.replace("v_readlane_b32 s4, v248, 15", "s_mov_b32 s4, s8").replace("v_readlane_b32 s5, v248, 16", "s_mov_b32 s5, s9"))
+    assert sg.check(str(h)) == []
