@@ -204,6 +204,8 @@ __device__ __forceinline__ void mfma_results_settle(Acc (&acc)[CT]) {
 // is what the source says.  ZERO: first k-step of a row tile, C = 0.  Hazards, by construction: a unit reads a tile whose last
 // MFMA is at least two 16-pass MFMAs behind it; nothing here reads `dst`.
 #define RTXN_M32(ACC, B, C) "v_mfma_f32_32x32x16_f16 %[" ACC "], %[a], %[" B "], " C "\n\t"
+// operands exchanged: the product comes out TRANSPOSED (lane = the weight tile's row, registers = samples) -- same k order, same values
+#define RTXN_M32T(ACC, B, C) "v_mfma_f32_32x32x16_f16 %[" ACC "], %[" B "], %[a], " C "\n\t"
 #define RTXN_PAIR32_CASES(M0, M1, ACC0, ACC1)                                                                                          \
   if constexpr (NUP == 0) asm volatile(M0 M1 : ACC0, ACC1 : RTXN_IN32);                                                                  \
   else if constexpr (NUP == 2)                                                                                                    \
@@ -216,11 +218,17 @@ __device__ __forceinline__ void mfma_results_settle(Acc (&acc)[CT]) {
 #define RTXN_IN32 [a] "v"(a), [b0] "v"(b0), [b1] "v"(b1)
 #define RTXN_UOUT(U, I) [r##U] "=&v"(r[I])
 #define RTXN_UIN(U, I) [x##U] "v"(x[I]), [y##U] "v"(y[I])
-template <bool ZERO, int NUP>
+template <bool ZERO, int NUP, bool SWAP = false>
 __device__ __forceinline__ void pair32(floatx16& acc0, floatx16& acc1, const half8& a, const half8& b0, const half8& b1,
                                        int (&r)[NUP > 0 ? NUP : 1], const float (&x)[NUP > 0 ? NUP : 1], const float (&y)[NUP > 0 ? NUP : 1]) {
   static_assert(NUP == 0 || NUP == 2 || NUP == 4, "unit pattern not written");
-  if constexpr (ZERO) {
+  if constexpr (SWAP) {
+    if constexpr (ZERO) {
+      RTXN_PAIR32_CASES(RTXN_M32T("c0", "b0", "0"), RTXN_M32T("c1", "b1", "0"), [c0] "=&v"(acc0), [c1] "=&v"(acc1))
+    } else {
+      RTXN_PAIR32_CASES(RTXN_M32T("c0", "b0", "%[c0]"), RTXN_M32T("c1", "b1", "%[c1]"), [c0] "+v"(acc0), [c1] "+v"(acc1))
+    }
+  } else if constexpr (ZERO) {
     RTXN_PAIR32_CASES(RTXN_M32("c0", "b0", "0"), RTXN_M32("c1", "b1", "0"), [c0] "=&v"(acc0), [c1] "=&v"(acc1))
   } else {
     RTXN_PAIR32_CASES(RTXN_M32("c0", "b0", "%[c0]"), RTXN_M32("c1", "b1", "%[c1]"), [c0] "+v"(acc0), [c1] "+v"(acc1))
@@ -232,7 +240,7 @@ __device__ __forceinline__ void pair32(floatx16& acc0, floatx16& acc1, const hal
 // that many k-steps ahead, with a counted s_waitcnt lgkmcnt(N) in front of each consumer (nothing else in this function may
 // touch LDS or SMEM); accumulators are double-buffered by row-tile parity: acc[rt & 1] collects row tile rt while the
 // finished tile rt-1 in acc[~rt & 1] is converted, U pack units per k-step, inside that k-step's asm statement.
-template <int RT, int KS, int NB, int I>
+template <int RT, int KS, int NB, int I, bool SWAP = false>
 struct PipeStep {
   static constexpr int CT = 2, D = RTXN_PIPE, N = RT * KS;
   static constexpr int U = (8 * CT + KS - 1) / KS;                 // units per k-step, row tiles 1..: 2 (KS = 8) or 4 (KS = 4)
@@ -251,7 +259,7 @@ struct PipeStep {
       x[i] = acc[cur ^ 1][ct][8 * (q / 4) + 2 * (q % 4)];
       y[i] = acc[cur ^ 1][ct][8 * (q / 4) + 2 * (q % 4) + 1];
     }
-    pair32<kk == 0, NUP>(acc[cur][0], acc[cur][1], ring[I % D], bf[kk][0], bf[kk][1], r, x, y);
+    pair32<kk == 0, NUP, SWAP>(acc[cur][0], acc[cur][1], ring[I % D], bf[kk][0], bf[kk][1], r, x, y);
 #pragma unroll
     for (int i = 0; i < NUP; ++i) {      // -> dword e of B fragment nbf[2 (rt - 1) + s][ct]
       const int P = p0 + i, ct = P / 8, q = P % 8;
@@ -261,11 +269,15 @@ struct PipeStep {
     }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (I + D < N) lds_read_frag<(I + D) * 1024>(ring[I % D], addr);
-    if constexpr (I + 1 < N) PipeStep<RT, KS, NB, I + 1>::run(addr, bf, nbf, ring, acc);
+    if constexpr (I + 1 < N) PipeStep<RT, KS, NB, I + 1, SWAP>::run(addr, bf, nbf, ring, acc);
   }
 };
 
-template <int RT, int KS, int NB>
+// SWAP: every MFMA with its operands exchanged -- tile (rt, ct) comes out transposed: lane (col, h) holds FEATURE 32 rt + col of
+// the 16 samples 32 ct + (e & 3) + 8 (e >> 2) + 4 h, and the unchanged pack units leave in nbf[2 rt + s][ct] that feature's
+// values (ReLU, fp16) at the eight samples 32 ct + 16 s + {4 h .. 4 h + 3, 8 + 4 h .. 8 + 4 h + 3}: an A operand whose k runs
+// over SAMPLES (the lean weight-gradient kernel's output layer).
+template <int RT, int KS, int NB, bool SWAP = false>
 __device__ __forceinline__ void pipe_layer(const uint8_t* lds_buf, half8 (&bf)[NB][2], half8 (&nbf)[NB][2], floatx16 (&acc)[2][2], int lane) {
   constexpr int D = RTXN_PIPE, N = RT * KS;
   static_assert(D >= 1 && D <= 4, "ring depth");
@@ -278,7 +290,7 @@ __device__ __forceinline__ void pipe_layer(const uint8_t* lds_buf, half8 (&bf)[N
   if constexpr (D > 1 && N > 1) lds_read_frag<1024>(ring[1 % D], addr);
   if constexpr (D > 2 && N > 2) lds_read_frag<2048>(ring[2 % D], addr);
   if constexpr (D > 3 && N > 3) lds_read_frag<3072>(ring[3 % D], addr);
-  PipeStep<RT, KS, NB, 0>::run(addr, bf, nbf, ring, acc);
+  PipeStep<RT, KS, NB, 0, SWAP>::run(addr, bf, nbf, ring, acc);
   // the caller converts the pending tile in acc[1] with ordinary code: see mfma_results_settle
   mfma_results_settle(acc[1]);
 }

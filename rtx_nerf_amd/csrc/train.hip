@@ -1585,8 +1585,9 @@ __global__ __launch_bounds__(kThreads) void wgrad_lds_kernel(WgradArgs a) {
 //     registers per layer).  The model's gradient therefore takes several passes of this kernel, each recomputing the forward as
 //     far as its layers need: as shipped THREE -- layers 0-2 (forward through layer 1), 3-5 (through 4), 6-7 + the output
 //     layer (through 7): 15 layer-forwards = 1.9 forward passes of recompute, 192 AGPRs.  Four layers per pass (two passes, 1.4
-//     forward passes) fill all 256 AGPRs and hipcc then spills accumulator tiles around the tile loop (-DRTXN_LEAN_TWO_PASS).
-//     The output layer's 16 x 128 gradient is accumulated in 8 KiB of LDS (ds_add_f32, 8 per thread and tile).
+//     forward passes) fill all 256 AGPRs and hipcc then spills accumulator tiles around the tile loop (tried, gone).
+//     The output layer's 16 x 128 gradient costs no image at all: the last hidden layer is computed with the MFMA operands
+//     exchanged, which leaves its activations as an A operand over samples (see the last layer's forward), 64 AGPRs.
 //   * The contraction runs over samples -- the LANE index of the chain's fragments -- so each wave drops A_{l-1} into a
 //     [sample][feature] LDS image (rows of 328 bytes: conflict-free ds_write_b64, the transposing ds_read_b64_tr_b16 two-way on 3
 //     of 32 lanes) and the B operands come back through the transposing read (as mlp_bwd_fused64_kernel); only two images fit, so
@@ -1605,9 +1606,13 @@ constexpr int kLnOffW = 0;                    // one layer's forward weights (32
 constexpr int kLnOffRing = 32 * 1024;
 constexpr int kLnOffX = kLnOffRing + 4 * kLnStage;
 constexpr int kLnOffOL = kLnOffX + 2 * kLnImg;   // dZ of the output layer, 16 rows x 256 samples
-constexpr int kLnOffAcc = kLnOffOL + 8192;       // fp32 [16][128]: the output layer's gradient of this block
-constexpr int kLnLds = kLnOffAcc + 8192;
-static_assert(kLnLds <= 160 * 1024, "LDS");
+constexpr int kLnLds = kLnOffOL + 8192;
+#ifdef RTXN_LN_STAMPS
+constexpr int kLnLdsLaunch = kLnLds + 4096;   // the stamps
+#else
+constexpr int kLnLdsLaunch = kLnLds;
+#endif
+static_assert(kLnLdsLaunch <= 160 * 1024, "LDS");
 static_assert(kLnStr % 8 == 0 && kLnOffX % 16 == 0 && kLnOffOL % 16 == 0, "alignment of the transposing and 16-byte reads");
 
 struct LeanArgs {
@@ -1658,6 +1663,25 @@ __device__ __forceinline__ void ln_operands_ready(half8& a0, half8& a1, half8& b
   asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1) : "n"(N));
 }
 
+// Diagnostic build only (-DRTXN_LN_STAMPS, tools/probe/lean_stamps.py; never in the shipped library): the first block of each
+// pass records s_memtime at the phase boundaries of its tiles 20 and 21, every wave its own, into the LDS left over behind
+// kLnLds, and copies them out when it is done.  Slot 0 top of the tile, 1 encoding in registers; layer l at 2 + 11 l:
+// +0 step begins, +1 past [W+T], +2 forward done, +3 past [v0], +4 contraction 0, +5 past [v1], +6 contraction 1,
+// +7 past [v2] (second image written), +8 contraction 2, +9 past [v3], +10 contraction 3; 90 output layer begins, 91 tile done.
+#ifdef RTXN_LN_STAMPS
+constexpr int kLnStampTiles = 2, kLnStampSlots = 92, kLnStampFirst = 20;   // tiles 20, 21 of the block: steady state
+__device__ unsigned g_ln_stamps[3 * 4 * kLnStampTiles * kLnStampSlots];
+#define RTXN_LN_STAMP(k)                                                                                          \
+  do {                                                                                                            \
+    if (sub_block == 0 && tile_it >= kLnStampFirst && tile_it < kLnStampFirst + kLnStampTiles) {                      \
+      const unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime();                                                 \
+      if (lane == 0) stamp_lds[(wave * kLnStampTiles + (tile_it - kLnStampFirst)) * kLnStampSlots + (k)] = t_;    \
+    }                                                                                                             \
+  } while (0)
+#else
+#define RTXN_LN_STAMP(k)
+#endif
+
 // L0 <= l < L1: the layers whose gradient this pass accumulates (at most 4); OUT: also the output layer (then L1 == LTOT)
 // sub_block of sub_grid: this block's place among the blocks that run THIS pass (see wgrad_recompute_kernel)
 template <int KS0, int L0, int L1, bool OUT, int LTOT>
@@ -1665,6 +1689,7 @@ __device__ __forceinline__ void wgrad_recompute_pass(LeanArgs a, const int sub_b
   constexpr int W = 128, RT = 4, KS = 8, NL = L1 - L0;
   constexpr int FWD_END = OUT ? LTOT : L1 - 1;            // forward layers 0 .. FWD_END-1 are recomputed
   static_assert(NL >= 1 && NL <= 4 && L0 >= 0 && L1 <= LTOT && (!OUT || L1 == LTOT), "pass layout");
+  static_assert(!OUT || (NL >= 2 && NL <= 3), "the output layer's dZ is fetched in the step before the last (a gradient layer); its accumulators take 64 AGPRs");
   static_assert(KS0 >= 1 && KS0 <= KS, "encoded width");
   constexpr int W0_OPS = (KS0 * RT + 3) / 4;              // stage_rt's LDS-DMA instructions per wave for layer 0; 8 for a hidden layer
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1693,10 +1718,11 @@ __device__ __forceinline__ void wgrad_recompute_pass(LeanArgs a, const int sub_b
 
   uint8_t* const ring = smem + kLnOffRing;
   uint8_t* const ximg = smem + kLnOffX;
-  float* const oacc = reinterpret_cast<float*>(smem + kLnOffAcc);
-  if (OUT) {
-    for (int i = tid; i < 16 * W; i += kThreads) oacc[i] = 0.0f;
-  }
+#ifdef RTXN_LN_STAMPS
+  unsigned* const stamp_lds = reinterpret_cast<unsigned*>(smem + kLnLds);
+  for (int i = tid; i < 4 * kLnStampTiles * kLnStampSlots; i += kThreads) stamp_lds[i] = 0;
+  int tile_it = 0;
+#endif
   // ---- fixed per-lane address parts ----
   // dZ stage fill: this wave's pieces are image rows 32 wave + 8 i + (lane >> 3), i = 0..3; lane slot (lane & 7) of a row holds
   // the 16-byte sample group (lane & 7) ^ ((row >> 1) & 7)
@@ -1758,6 +1784,15 @@ __device__ __forceinline__ void wgrad_recompute_pass(LeanArgs a, const int sub_b
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][t][e] = 0.0f;
+  // the output layer's gradient, TRANSPOSED and for this wave's samples only: oq[rt] lane (o = col < 16, h), register e = feature
+  // 32 rt + (e & 3) + 8 (e >> 2) + 4 h (64 more AGPRs of the pass with two hidden layers; see the last layer's forward below)
+  floatx16 oq[4];
+  if constexpr (OUT) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oq[t][e] = 0.0f;
+  }
 
   // 64 samples of the contraction: dZ stage in ring slot `slot`, X image at LDS address `image`.  Operands double-buffered by
   // k-step: the six reads of k-step ks + 1 are in flight while the four MFMAs of ks run (one wave per SIMD: nothing else hides them)
@@ -1805,6 +1840,7 @@ __device__ __forceinline__ void wgrad_recompute_pass(LeanArgs a, const int sub_b
   while (tile < a.n_tiles) {
     const int nxt_tile = next_live(tile + sub_grid);
     const int look = nxt_tile < a.n_tiles ? nxt_tile : tile;       // no further tile: the look-ahead stages re-read this one (unused)
+    RTXN_LN_STAMP(0);
     const long tile0 = (long)tile * kTile + wave * 64;
     // where the wave's two 32-sample column tiles sit in encT: consecutive, or with the live list two listed segments
     long col0[2];
@@ -1871,6 +1907,7 @@ __device__ __forceinline__ void wgrad_recompute_pass(LeanArgs a, const int sub_b
         for (int ct = 0; ct < 2; ++ct) act[0][kk][ct] = __builtin_bit_cast(half8, w[kk][ct]);
       // (the first barrier of step 0 stands between these reads and the first image written over the scratch)
     }
+    RTXN_LN_STAMP(1);
     // One layer, l a compile-time constant: [forward: nxt = relu(W_l cur)] THEN [weight gradient of layer l from A_{l-1} = cur],
     // then cur = nxt.  Forward first, so that the four dZ stages of the layer -- issued one by one as the previous layer's
     // contraction freed their slots -- have the forward's ~3,000 cycles to arrive: with the contraction first, the fourth stage
@@ -1899,6 +1936,7 @@ __device__ __forceinline__ void wgrad_recompute_pass(LeanArgs a, const int sub_b
         constexpr int w_next = has_f ? (next_f == 0 ? W0_OPS : 8) : 0;           // issued by this step only if it runs a forward (see [v0])
         constexpr int next_w = l + 1 < L1 && l + 1 >= L0 ? l + 1 : L0;            // the next layer with a gradient (cyclically)
         constexpr bool next_w_same_tile = has_w && l + 1 < L1;
+        RTXN_LN_STAMP(2 + 11 * l);
         // ---- [W+T] ----
         if constexpr (has_f) ln_wait_vm<(prev_w ? 12 : 0)>();
         ln_barrier();
@@ -1907,8 +1945,8 @@ __device__ __forceinline__ void wgrad_recompute_pass(LeanArgs a, const int sub_b
           // layer `l` if it has a gradient (then prev was l - 1 or the previous tile's last layer), else this tile's first such layer
           constexpr int lw = has_w ? l : L0;
           issue_stage(3, lw, (long)tile * kTile + 64 * 3);
-          if constexpr (OUT && has_w && l == LTOT - 1) issue_ol((long)tile * kTile);
         }
+        RTXN_LN_STAMP(2 + 11 * l + 1);
         // ---- forward ----
 #ifdef RTXN_LN_NO_FWD
         if constexpr (false) {
@@ -1935,6 +1973,43 @@ __device__ __forceinline__ void wgrad_recompute_pass(LeanArgs a, const int sub_b
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) nxt[2 * rt + s2][ct] = pack8<true>(f[ct], s2);
             }
+          } else if constexpr (OUT && l == LTOT - 1) {
+            // The last hidden layer's activations feed nothing but the output layer's gradient dW_L[o][f] = sum_s dZ_L[o][s] A[f][s]:
+            // a contraction over SAMPLES, the lane index of the chain's fragments.  Instead of a round through LDS images (first
+            // build: two image halves, four barriers, 6,400 of the tile's 66,000 cycles) the layer is computed with the MFMA
+            // operands exchanged: the pipeline then leaves in nxt[2 rt + s][ct] feature 32 rt + col at eight samples per lane
+            // (rtxn::pipe_layer, SWAP) -- already an A operand with k = samples.  The B operand is dZ_L at the same eight samples
+            // (two 8-byte reads from the wave's own 2-KiB sub-image: no barrier), the product dW_L^T stays in AGPRs for the kernel.
+            floatx16 acc2[2][2];
+            rtxn::pipe_layer<RT, KS, KS, true>(wl, cur, nxt, acc2, lane);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+              for (int ct = 0; ct < 2; ++ct) nxt[2 * (RT - 1) + s2][ct] = rtxn::relu_pack(acc2[1][ct], s2);
+            // row o = col & 15 of the sub-image (lanes col >= 16 repeat rows: columns 16-31 of the product, never stored); sample
+            // group g sits in 16-byte slot g ^ ((row >> 1) & 7)
+            const unsigned ol_row = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) uint8_t*)(smem + kLnOffOL) + wave * 2048 + (col & 15) * 128 + 8 * h;
+            const unsigned swz = ((col & 15) >> 1) & 7;
+            s16x4 dl[2][2][2];
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+              for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                  const unsigned ad = ol_row + (((unsigned)(4 * ct + 2 * s + q) ^ swz) << 4);
+                  asm volatile("ds_read_b64 %0, %1" : "=v"(dl[ct][s][q]) : "v"(ad));
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dl[0][0][0]), "+v"(dl[0][0][1]), "+v"(dl[0][1][0]), "+v"(dl[0][1][1]), "+v"(dl[1][0][0]), "+v"(dl[1][0][1]), "+v"(dl[1][1][0]), "+v"(dl[1][1][1]));
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+              for (int s = 0; s < 2; ++s) {
+                const half8 bz = __builtin_shufflevector(__builtin_bit_cast(half4v, dl[ct][s][0]), __builtin_bit_cast(half4v, dl[ct][s][1]), 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)         // four different accumulators in a row: a dependent MFMA is four behind
+                  asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(oq[rt]) : "v"(nxt[2 * rt + s][ct]), "v"(bz));
+              }
           } else {
             floatx16 acc2[2][2];
             rtxn::pipe_layer<RT, KS, KS>(wl, cur, nxt, acc2, lane);
@@ -1944,6 +2019,7 @@ __device__ __forceinline__ void wgrad_recompute_pass(LeanArgs a, const int sub_b
               for (int ct = 0; ct < 2; ++ct) nxt[2 * (RT - 1) + s2][ct] = rtxn::relu_pack(acc2[1][ct], s2);
           }
         }
+        RTXN_LN_STAMP(2 + 11 * l + 2);
         auto issue_next_weights = [&]() {
           if constexpr (has_f) {
             constexpr int wbytes = (next_f == 0 ? KS0 : KS) * RT * 1024;
@@ -1955,6 +2031,10 @@ __device__ __forceinline__ void wgrad_recompute_pass(LeanArgs a, const int sub_b
         };
         if constexpr (has_w) {
           constexpr int li = l - L0;
+          // the output layer's dZ of this tile is fetched one step ahead of its use (the last layer's forward): two more
+          // instructions behind this step's stages 1-3
+          constexpr bool ol_here = OUT && l == LTOT - 2;
+          constexpr int w_behind = w_next + (ol_here ? 2 : 0);
           // stage issued as slot v - 1 comes free: the next gradient layer's v - 1 (this tile's, or the next tile's first)
           auto look_ahead = [&](int v) {
             if (next_w_same_tile) issue_stage(v - 1, next_w, (long)tile * kTile + 64 * (v - 1));
@@ -1964,24 +2044,34 @@ __device__ __forceinline__ void wgrad_recompute_pass(LeanArgs a, const int sub_b
           ln_wait_vm<12>();
           ln_barrier();                                   // stage (l, 0), the images of waves 0, 1; everyone has left the forward
           issue_next_weights();
+          if constexpr (ol_here) issue_ol((long)tile * kTile);
+          RTXN_LN_STAMP(2 + 11 * l + 3);
           contract(acc[li], 0, 0);
-          ln_wait_vm<8 + w_next>();
+          RTXN_LN_STAMP(2 + 11 * l + 4);
+          ln_wait_vm<8 + w_behind>();
           ln_barrier();
           look_ahead(1);
+          RTXN_LN_STAMP(2 + 11 * l + 5);
           contract(acc[li], 1, 1);
+          RTXN_LN_STAMP(2 + 11 * l + 6);
           ln_barrier();                                   // both images have been read by everyone
           if (wave >= 2) write_image(ximg + (wave - 2) * kLnImg, cur);
-          ln_wait_vm<8 + w_next>();
+          ln_wait_vm<8 + w_behind>();
           ln_barrier();
           look_ahead(2);
+          RTXN_LN_STAMP(2 + 11 * l + 7);
           contract(acc[li], 2, 0);
-          ln_wait_vm<8 + w_next>();
+          RTXN_LN_STAMP(2 + 11 * l + 8);
+          ln_wait_vm<8 + w_behind>();
           ln_barrier();
           look_ahead(3);
+          RTXN_LN_STAMP(2 + 11 * l + 9);
           contract(acc[li], 3, 1);
+          RTXN_LN_STAMP(2 + 11 * l + 10);
         } else {
           ln_barrier();                                   // everyone has left the forward: its weights may be overwritten
           issue_next_weights();
+          RTXN_LN_STAMP(2 + 11 * l + 3);
         }
       }
     };
@@ -1994,43 +2084,10 @@ __device__ __forceinline__ void wgrad_recompute_pass(LeanArgs a, const int sub_b
     layer_step(std::integral_constant<int, 6>{});
     layer_step(std::integral_constant<int, 7>{});
     static_assert(LTOT <= 8, "layer_step is spelled out for eight layers");
-    if (OUT) {
-      // ---- output layer: dW_L[16 x 128] += dZ_L A_{L-1}^T; wave w: columns 32 w .. 32 w + 31, rows 0-15 of a 32-row tile ----
-      half8 (&cur)[KS][2] = act[LTOT & 1];
-      floatx16 o;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) o[e] = 0.0f;
-      const unsigned ol_addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) uint8_t*)(smem + kLnOffOL);
-      auto contract_ol = [&](int v, int img) {
-        // lanes with col >= 16 read past the 16 rows: rows 16-31 of the product, never stored
-        unsigned st = ol_addr + v * 2048, xi = ximg_addr + img * kLnImg + lane_tr + 64 * wave;
-        asm volatile("" : "+s"(st), "+v"(xi));
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          half8 a0, b0;
-          ln_read_b128<0>(a0, st + frag_off[ks]);
-          ln_read_tr(b0, xi, (16 * ks) * kLnStr, (16 * ks + 4) * kLnStr);
-          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(b0));
-          o = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, o, 0, 0, 0);
-        }
-      };
-      ln_barrier();
-      if (wave < 2) write_image(ximg + wave * kLnImg, cur);
-      ln_wait_vm<12>();                                   // behind the output layer's dZ: the three look-ahead stages of the last layer
-      ln_barrier();
-      contract_ol(0, 0);
-      contract_ol(1, 1);
-      ln_barrier();
-      if (wave >= 2) write_image(ximg + (wave - 2) * kLnImg, cur);
-      ln_barrier();
-      contract_ol(2, 0);
-      contract_ol(3, 1);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int orow = (e & 3) + 8 * (e >> 2) + 4 * h;  // < 16
-        atomicAdd(&oacc[orow * W + 32 * wave + col], o[e]);
-      }
-    }
+    RTXN_LN_STAMP(91);
+#ifdef RTXN_LN_STAMPS
+    ++tile_it;
+#endif
     tile = nxt_tile;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the last look-ahead stages land in LDS this block still owns
@@ -2040,6 +2097,7 @@ __device__ __forceinline__ void wgrad_recompute_pass(LeanArgs a, const int sub_b
   // tools/check_asm_mfma_reads.py counted 18 of the 19 between the last contraction and the first v_accvgpr_read without it).
 #pragma unroll
   for (int i = 0; i < NL; ++i) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]));
+  if constexpr (OUT) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(oq[0]), "+a"(oq[1]), "+a"(oq[2]), "+a"(oq[3]));
   // ---- one pass of atomics per wave: its quadrant of every layer of the pass ----
   const int E = KS0 * 16;
 #pragma unroll
@@ -2055,11 +2113,22 @@ __device__ __forceinline__ void wgrad_recompute_pass(LeanArgs a, const int sub_b
         if (c < N && acc[i][t][e] != 0.0f) grad_add(&dW[(long)orow * N + c], acc[i][t][e], a.det);
       }
   }
-  if (OUT) {
-    float* dW = a.dparams + (long)W * E + (long)(LTOT - 1) * W * W;
-    for (int i = tid; i < 16 * W; i += kThreads)
-      if (oacc[i] != 0.0f) grad_add(&dW[i], oacc[i], a.det);
+  if constexpr (OUT) {
+    float* dW = a.dparams + (long)W * E + (long)(LTOT - 1) * W * W;     // [16][W]; every wave adds its samples' share
+    if (col < 16) {
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int f = 32 * rt + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (oq[rt][e] != 0.0f) grad_add(&dW[col * W + f], oq[rt][e], a.det);
+        }
+    }
   }
+#ifdef RTXN_LN_STAMPS
+  if (sub_block == 0)
+    for (int i = tid; i < 4 * kLnStampTiles * kLnStampSlots; i += kThreads) g_ln_stamps[(L0 / 3) * 4 * kLnStampTiles * kLnStampSlots + i] = stamp_lds[i];
+#endif
 }
 
 // One pass as a launch of its own (small batches: fewer tiles than CUs).
@@ -2688,41 +2757,29 @@ static int train_backward_lean_impl(const rtxn_mlp* m, const void* encT, const v
   if (n_cu <= 0) n_cu = 256;
   const int grid = la.n_tiles < n_cu ? la.n_tiles : n_cu;   // persistent: one block per CU (registers and LDS)
   typedef void (*lean_fn)(LeanArgs);
-  // Three passes: layers 0-2 | 3-5 | 6-7 + output -- 192 accumulator registers per wave, 1.9 forward passes of recompute.  Two
-  // passes (0-3 | 4-7 + output: 1.4 passes of recompute) need all 256 AGPRs for the accumulators, and with none to spare hipcc
-  // spills three accumulator tiles to scratch around the tile loop's back edge (build with -DRTXN_LEAN_TWO_PASS for the A/B;
-  // tests/test_build_quality.py keeps the shipped kernels free of scratch).
-#ifdef RTXN_LEAN_TWO_PASS
-  constexpr int n_pass = 2;
-  static const lean_fn pass[2] = {wgrad_recompute_kernel<7, 0, 4, false, 8>, wgrad_recompute_kernel<7, 4, 8, true, 8>};
-#else
+  // Three passes: layers 0-2 | 3-5 | 6-7 + output -- 192 accumulator registers per wave, 1.9 forward passes of recompute.  (Two
+  // passes, 0-3 | 4-7 + output: 1.4 passes of recompute, need all 256 AGPRs for the hidden layers' accumulators alone; tried in
+  // round 4 -- hipcc spilled accumulator tiles to scratch around the tile loop's back edge -- and gone since the output layer's
+  // gradient lives in AGPRs too.)
   constexpr int n_pass = 3;
   static const lean_fn pass[3] = {wgrad_recompute_kernel<7, 0, 3, false, 8>, wgrad_recompute_kernel<7, 3, 6, false, 8>,
                                   wgrad_recompute_kernel<7, 6, 8, true, 8>};
-#endif
-#ifndef RTXN_LEAN_TWO_PASS
   // large batches: the three passes side by side in one launch (wgrad_recompute_all_kernel); the CU split follows the passes'
   // measured cost (RTXN_LEAN_SPLIT="s1,s2" of 32 slots per XCD for experiments; RTXN_LEAN_SPLIT=0: one launch per pass)
-  static int split[2] = {-1, -1};
-  if (split[0] < 0) {
-    int s1 = 8, s2 = 18;
-    if (const char* e = getenv("RTXN_LEAN_SPLIT")) {
-      if (sscanf(e, "%d,%d", &s1, &s2) != 2) s1 = s2 = 0;
-    }
-    split[1] = s2;
-    split[0] = s1;
+  int split[2] = {8, 20};
+  if (const char* e = getenv("RTXN_LEAN_SPLIT")) {
+    if (sscanf(e, "%d,%d", &split[0], &split[1]) != 2) split[0] = split[1] = 0;
   }
   const int slots = n_cu / 8;
   if (split[0] > 0 && split[0] < split[1] && split[1] < slots && la.n_tiles >= 4 * n_cu) {
-    RTXN_HIP(set_lds_once(reinterpret_cast<const void*>(wgrad_recompute_all_kernel<7>), kLnLds));
-    hipLaunchKernelGGL(wgrad_recompute_all_kernel<7>, dim3((unsigned)(slots * 8)), dim3(kThreads), kLnLds, s, la, split[0] * slots / 32, split[1] * slots / 32);
+    RTXN_HIP(set_lds_once(reinterpret_cast<const void*>(wgrad_recompute_all_kernel<7>), kLnLdsLaunch));
+    hipLaunchKernelGGL(wgrad_recompute_all_kernel<7>, dim3((unsigned)(slots * 8)), dim3(kThreads), kLnLdsLaunch, s, la, split[0] * slots / 32, split[1] * slots / 32);
     RTXN_LAUNCH_CHECK("wgrad_recompute_all_kernel");
     return det_fold(la.det.q, m->n_params, dparams, nullptr, 0, s);
   }
-#endif
   for (int i = 0; i < n_pass; ++i) {
-    RTXN_HIP(set_lds_once(reinterpret_cast<const void*>(pass[i]), kLnLds));
-    hipLaunchKernelGGL(pass[i], dim3((unsigned)grid), dim3(kThreads), kLnLds, s, la);
+    RTXN_HIP(set_lds_once(reinterpret_cast<const void*>(pass[i]), kLnLdsLaunch));
+    hipLaunchKernelGGL(pass[i], dim3((unsigned)grid), dim3(kThreads), kLnLdsLaunch, s, la);
     RTXN_LAUNCH_CHECK("wgrad_recompute_kernel");
   }
   return det_fold(la.det.q, m->n_params, dparams, nullptr, 0, s);
@@ -2751,6 +2808,13 @@ extern "C" int rtxn_mlp_train_forward_lean(const rtxn_mlp* m, const void* encT, 
   RTXN_REQUIRE(encT && workspace_lean && output_half, "rtxn_mlp_train_forward_lean: NULL buffer");
   return train_forward_impl(m, encT, n_samples, workspace_lean, output_half, radiance, DevCount{nullptr, 0}, stream, nullptr, nullptr, true);
 }
+
+#ifdef RTXN_LN_STAMPS
+// diagnostic builds only: the stamps of the last lean weight-gradient launch (3 passes x 4 waves x 2 tiles x 92 slots)
+extern "C" int rtxn_debug_read_lean_stamps(unsigned* dst) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_ln_stamps), sizeof(unsigned) * 3 * 4 * kLnStampTiles * kLnStampSlots) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int rtxn_mlp_train_backward_lean(const rtxn_mlp* m, const void* encT, const void* output_half, const void* dout_half4,
                                             long n_samples, void* workspace_lean, const void* live_ws, float* dparams,
