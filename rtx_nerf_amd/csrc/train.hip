@@ -1591,13 +1591,14 @@ __global__ __launch_bounds__(kThreads) void wgrad_lds_kernel(WgradArgs a) {
 //   * The contraction runs over samples -- the LANE index of the chain's fragments -- so each wave drops A_{l-1} into a
 //     [sample][feature] LDS image (rows of 328 bytes: conflict-free ds_write_b64, the transposing ds_read_b64_tr_b16 two-way on 3
 //     of 32 lanes) and the B operands come back through the transposing read (as mlp_bwd_fused64_kernel); only two images fit, so
-//     a layer's contraction runs in two halves (waves 0, 1 write, all contract; waves 2, 3 write, all contract).
+//     a layer's contraction runs in two halves of 128 samples (waves 0, 1 write, all contract; waves 2, 3 write, all contract).
 //   * dZ_l arrives by LDS-DMA in stages of 64 samples x 128 rows (whole 128-byte lines, source-side bank swizzle: the layout of
-//     wgrad_lds_kernel) through a ring of four 16-KiB slots, three stages in flight; a stage is retired by a counted
-//     `s_waitcnt vmcnt(K)` + barrier.  The order of every wave's vector-memory operations is static, so each K is a constant:
-//     the operations issued after the awaited stage -- the two younger stages (8) and, where it was issued in between, the next
-//     layer's weight fetch (8; 7 for layer 0).  At a tile boundary more has been issued than K assumes, which only waits longer.
-//     A block with no further tile issues its look-ahead stages anyway (re-reading its last tile) so that the count holds.
+//     wgrad_lds_kernel) through a ring of four 16-KiB slots = one layer of one tile; a layer is contracted as two pairs of stages,
+//     and a pair is retired by a counted `s_waitcnt vmcnt(K)` + barrier.  The order of every wave's vector-memory operations is
+//     static, so each K is a constant: the operations issued after the awaited pair -- the other pair (8), the next layer's
+//     weight fetch (8; 7 for layer 0), the look-ahead to the next layer's first pair (8).  Where more has been issued than K
+//     assumes, the wait is only longer.  The first gradient layer's four stages are issued at the top of the tile, behind the
+//     wait for the encoding; the last gradient layer looks ahead to nothing and touches the next tile's encoding instead.
 //   * Tiles whose loss gradients are all zero (mlp_bwd_kernel's live_tiles: it writes no dZ for them) are stepped over.
 constexpr int kLnStr = 328;                   // bytes per sample row of an X image: 256 + 72 (72 = 8 x 9: rows land 9 bank pairs apart)
 constexpr int kLnImg = 64 * kLnStr;           // one wave's 64 samples
@@ -1606,7 +1607,10 @@ constexpr int kLnOffW = 0;                    // one layer's forward weights (32
 constexpr int kLnOffRing = 32 * 1024;
 constexpr int kLnOffX = kLnOffRing + 4 * kLnStage;
 constexpr int kLnOffOL = kLnOffX + 2 * kLnImg;   // dZ of the output layer, 16 rows x 256 samples
-constexpr int kLnLds = kLnOffOL + 8192;
+constexpr int kLnEncScratch = 112 * 128;           // one wave's encoded tile, [feature][64 samples]: 14 KiB, from kLnOffX on (the images, the
+constexpr int kLnOffJunk = kLnOffX + 4 * kLnEncScratch;   // output layer's dZ and 7 KiB more are all free at the top of a tile); 256 B nobody reads
+static_assert(kLnOffJunk >= kLnOffOL + 8192, "the scratch ends behind the output layer's dZ");
+constexpr int kLnLds = kLnOffJunk + 256;
 #ifdef RTXN_LN_STAMPS
 constexpr int kLnLdsLaunch = kLnLds + 4096;   // the stamps
 #else
@@ -1666,11 +1670,12 @@ __device__ __forceinline__ void ln_operands_ready(half8& a0, half8& a1, half8& b
 // Diagnostic build only (-DRTXN_LN_STAMPS, tools/probe/lean_stamps.py; never in the shipped library): the first block of each
 // pass records s_memtime at the phase boundaries of its tiles 20 and 21, every wave its own, into the LDS left over behind
 // kLnLds, and copies them out when it is done.  Slot 0 top of the tile, 1 encoding in registers; layer l at 2 + 11 l:
-// +0 step begins, +1 past [W+T], +2 forward done, +3 past [v0], +4 contraction 0, +5 past [v1], +6 contraction 1,
-// +7 past [v2] (second image written), +8 contraction 2, +9 past [v3], +10 contraction 3; 90 output layer begins, 91 tile done.
+// +0 step begins, +1 past [W+T], +2 forward done, +3 past [v0], +4 first pair contracted, +7 past [v2] (second images written),
+// +8 second pair contracted; 91 tile done.
 #ifdef RTXN_LN_STAMPS
 constexpr int kLnStampTiles = 2, kLnStampSlots = 92, kLnStampFirst = 20;   // tiles 20, 21 of the block: steady state
 __device__ unsigned g_ln_stamps[3 * 4 * kLnStampTiles * kLnStampSlots];
+__device__ unsigned long long g_ln_clock[3 * 8];   // per pass, first block: s_memtime / s_memrealtime (100 MHz) at its begin and end, its tiles
 #define RTXN_LN_STAMP(k)                                                                                          \
   do {                                                                                                            \
     if (sub_block == 0 && tile_it >= kLnStampFirst && tile_it < kLnStampFirst + kLnStampTiles) {                      \
@@ -1715,6 +1720,7 @@ __device__ __forceinline__ void wgrad_recompute_pass(LeanArgs a, const int sub_b
   };
   int tile = next_live(sub_block);
   if (tile >= a.n_tiles) return;
+  static_assert(KS0 == 7, "the encoding's scratch and its 14 fetches per wave are spelled for 112 features");
 
   uint8_t* const ring = smem + kLnOffRing;
   uint8_t* const ximg = smem + kLnOffX;
@@ -1722,6 +1728,7 @@ __device__ __forceinline__ void wgrad_recompute_pass(LeanArgs a, const int sub_b
   unsigned* const stamp_lds = reinterpret_cast<unsigned*>(smem + kLnLds);
   for (int i = tid; i < 4 * kLnStampTiles * kLnStampSlots; i += kThreads) stamp_lds[i] = 0;
   int tile_it = 0;
+  const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
   // ---- fixed per-lane address parts ----
   // dZ stage fill: this wave's pieces are image rows 32 wave + 8 i + (lane >> 3), i = 0..3; lane slot (lane & 7) of a row holds
@@ -1759,6 +1766,29 @@ __device__ __forceinline__ void wgrad_recompute_pass(LeanArgs a, const int sub_b
       base += 16 * Sp_l;
     }
   };
+  // Every 128-byte line of tile t's encoding for this wave, touched once (4 bytes per lane into 256 B of LDS nobody reads): by the
+  // time the tile's real fetch asks for them they sit in the L2.  Four instructions: rows lane and 64 + lane of both 32-sample segments.
+  auto prefetch_enc = [&](int t) {
+    long Sp_l = a.Sp;
+    asm volatile("" : "+s"(Sp_l));
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      long c0 = (long)t * kTile + wave * 64 + ct * 32;
+      if (a.live_list) {
+        const int slot = t * 8 + wave * 2 + ct;
+        int seg = 0;
+        const int* p = a.live_list + slot;
+        if (slot < live_n) asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(seg) : "s"(p) : "memory");
+        c0 = (long)seg * 32;
+      }
+#pragma unroll
+      for (int rh = 0; rh < 2; ++rh) {
+        const int row = lane + 64 * rh < 112 ? lane + 64 * rh : 111;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.encT + c0 + (long)row * Sp_l),
+                                         (__attribute__((address_space(3))) void*)(smem + kLnOffJunk), 4, 0, 0);
+      }
+    }
+  };
   // fragment (k-step ks) of lane (h, r = col): row 32 q + r, 16-byte slot (2 ks + h) ^ ((r >> 1) & 7); row group q at + q * 4096
   int frag_off[4];
 #pragma unroll
@@ -1794,32 +1824,36 @@ __device__ __forceinline__ void wgrad_recompute_pass(LeanArgs a, const int sub_b
       for (int e = 0; e < 16; ++e) oq[t][e] = 0.0f;
   }
 
-  // 64 samples of the contraction: dZ stage in ring slot `slot`, X image at LDS address `image`.  Operands double-buffered by
-  // k-step: the six reads of k-step ks + 1 are in flight while the four MFMAs of ks run (one wave per SIMD: nothing else hides them)
+  // 128 samples of the contraction: dZ stages in ring slots s0, s0 + 1 against X images 0, 1 -- eight k-steps in one software
+  // pipeline.  Operands double-buffered by k-step: the six reads of k-step ks + 1 are in flight while the four MFMAs of ks run (one
+  // wave per SIMD: nothing else hides them); run as two separate 64-sample contractions (first build) every stage paid the
+  // pipeline's ramp and a barrier of its own.
   const unsigned ring_addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) uint8_t*)ring;
   const unsigned ximg_addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) uint8_t*)ximg;
-  auto contract = [&](floatx16 (&q)[4], int slot, int img) {
+  auto contract_pair = [&](floatx16 (&q)[4], int s0) {
 #ifdef RTXN_LN_NO_CONTRACT
     return;
 #endif
     // (laundered: as loop invariants of the tile loop hipcc computed every stage's sixteen operand addresses ahead of it and
     // parked them in AGPRs -- 52 of them, and then spilled an accumulator tile to scratch)
-    unsigned st = ring_addr + slot * kLnStage + (2 * tm) * 4096;
-    unsigned xi = ximg_addr + img * kLnImg + lane_tr + 64 * (2 * tn);
+    unsigned st = ring_addr + s0 * kLnStage + (2 * tm) * 4096;
+    unsigned xi = ximg_addr + lane_tr + 64 * (2 * tn);
     asm volatile("" : "+s"(st), "+v"(xi));
     half8 a0[2], a1[2], b0[2], b1[2];
-    auto fetch = [&](int ks, int s) {
-      ln_read_b128<0>(a0[s], st + frag_off[ks]);
-      ln_read_b128<4096>(a1[s], st + frag_off[ks]);
-      ln_read_tr(b0[s], xi, (16 * ks) * kLnStr, (16 * ks + 4) * kLnStr);
-      ln_read_tr(b1[s], xi, (16 * ks) * kLnStr + 64, (16 * ks + 4) * kLnStr + 64);
+    auto fetch = [&](int k8, int s) {                    // k-step k8 of the pair: stage s0 + (k8 >> 2), image k8 >> 2, k-step k8 & 3 of it
+      const unsigned sa = st + (k8 >> 2) * kLnStage + frag_off[k8 & 3], xa = xi + (k8 >> 2) * kLnImg;
+      const int ks = k8 & 3;
+      ln_read_b128<0>(a0[s], sa);
+      ln_read_b128<4096>(a1[s], sa);
+      ln_read_tr(b0[s], xa, (16 * ks) * kLnStr, (16 * ks + 4) * kLnStr);
+      ln_read_tr(b1[s], xa, (16 * ks) * kLnStr + 64, (16 * ks + 4) * kLnStr + 64);
     };
     fetch(0, 0);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int s = ks & 1;
-      if (ks + 1 < 4) {
-        fetch(ks + 1, s ^ 1);
+    for (int k8 = 0; k8 < 8; ++k8) {
+      const int s = k8 & 1;
+      if (k8 + 1 < 8) {
+        fetch(k8 + 1, s ^ 1);
         ln_operands_ready<6>(a0[s], a1[s], b0[s], b1[s]);
       } else {
         ln_operands_ready<0>(a0[s], a1[s], b0[s], b1[s]);
@@ -1834,8 +1868,6 @@ __device__ __forceinline__ void wgrad_recompute_pass(LeanArgs a, const int sub_b
 
   // ---- prologue: layer 0's weights (from then on every forward fetches the next one's) and the first three stages of the first tile ----
   if (FWD_END > 0) stage_rt(a.packed_fwd, smem + kLnOffW, KS0 * RT * 1024, tid);
-#pragma unroll
-  for (int v = 0; v < 3; ++v) issue_stage(v, L0, (long)tile * kTile + 64 * v);
 
   while (tile < a.n_tiles) {
     const int nxt_tile = next_live(tile + sub_grid);
@@ -1859,53 +1891,51 @@ __device__ __forceinline__ void wgrad_recompute_pass(LeanArgs a, const int sub_b
     }
     // ---- encoded input as B fragments (k-steps >= KS0: zeros, the padding columns of dW_0's operand) ----
     // A lane of the chain owns ONE sample and needs 56 of its 112 features: as two-byte loads that is 112 wave instructions of 128
-    // useful bytes each, and the texture path takes an instruction's 64 addresses at the same pace whatever their width -- 14,000
-    // cycles per tile and CU, 2.4 of the first build's 4.4 ms (ablation: profiles/r04/lean_ablation.txt).  Instead each wave
-    // fetches its 64 samples x 112 rows as 14 sixteen-byte loads per lane (8 rows x 128 B per instruction, whole lines), drops them
-    // row-major into a 7-KiB scratch of its own in the X-image region (free between tiles) in two halves of 56 rows, and picks its
-    // fragments out with two-byte LDS reads.  (pointers are not laundered: a laundered pointer loses its address space -- flat loads)
+    // useful bytes each, and the texture path takes an instruction's 64 addresses at the same pace whatever their width (first
+    // build: 14,000 cycles per tile).  Each wave fetches its 64 samples x 112 rows as 14 LDS-DMA instructions (8 rows x 128 B each,
+    // whole lines) into a 14-KiB scratch of its own -- everything from the X images on is free between tiles -- and picks its
+    // fragments out with two-byte LDS reads.  The wait for those 14 is the one place where this kernel stands still for a memory
+    // round trip (phase stamps, profiles/r04/lean_stamps.txt: 5,000-10,000 cycles per tile with the lines coming from HBM), so the
+    // previous tile's last step has touched every line once (prefetch_enc below: they come from the L2 now), and the tile's four
+    // dZ stages are issued behind the wait, not in front of it, so that it does not wait for them as well.
     long Sp_t = a.Sp;
     asm volatile("" : "+s"(Sp_t));
     half8 act[2][KS][2];                                // ping-pong: layer l reads act[l & 1], its forward writes act[(l + 1) & 1]
     {
-      static_assert(KS0 == 7, "the encoding's two halves of 56 rows are spelled for 112 features");
       ln_barrier();                                     // everyone has left the previous tile's last contraction: the X images are free
-      uint8_t* scratch = ximg + wave * 7168;
+      uint8_t* scratch = smem + kLnOffX + wave * kLnEncScratch;
       const int r8 = lane >> 3, jg = lane & 7;          // row of a piece, 16-byte sample group of the wave's 64 samples
       const _Float16* src = a.encT + (jg < 4 ? col0[0] : col0[1]) + 8 * (jg & 3) + (long)r8 * Sp_t;
-      rtxn::int4v piece[2][7];
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-        for (int p = 0; p < 7; ++p) piece[hf][p] = *reinterpret_cast<const rtxn::int4v*>(src + (long)(56 * hf + 8 * p) * Sp_t);
+      for (int p = 0; p < 14; ++p)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (long)(8 * p) * Sp_t),
+                                         (__attribute__((address_space(3))) void*)(scratch + p * 1024), 16, 0, 0);
+      ln_wait_vm<0>();                                  // own pieces, own reads: no barrier
       rtxn::int4v w[KS][2];
 #pragma unroll
       for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) w[kk][ct] = rtxn::int4v{0, 0, 0, 0};
-      const uint8_t* mine = scratch + (4 * h) * 128 + col * 2;     // + feature row (mod 56) * 128 + ct * 64
+      const uint8_t* mine = scratch + (4 * h) * 128 + col * 2;     // + feature row * 128 + ct * 64
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
+      for (int kk = 0; kk < KS0; ++kk)
 #pragma unroll
-        for (int p = 0; p < 7; ++p) *reinterpret_cast<rtxn::int4v*>(scratch + (8 * p + r8) * 128 + jg * 16) = piece[hf][p];
+        for (int j = 0; j < 8; ++j) {
+          const int f0 = perm_feature(kk, 0, j);
 #pragma unroll
-        for (int kk = 0; kk < KS0; ++kk)
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int f0 = perm_feature(kk, 0, j);      // + 4 h: the same group of eight rows, so the same half
-            if (f0 / 56 != hf) continue;
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-              const unsigned v = *reinterpret_cast<const unsigned short*>(mine + (f0 - 56 * hf) * 128 + ct * 64);
-              w[kk][ct][j >> 1] |= (int)(v << (16 * (j & 1)));
-            }
+          for (int ct = 0; ct < 2; ++ct) {
+            const unsigned v = *reinterpret_cast<const unsigned short*>(mine + f0 * 128 + ct * 64);
+            w[kk][ct][j >> 1] |= (int)(v << (16 * (j & 1)));
           }
-      }
+        }
 #pragma unroll
       for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) act[0][kk][ct] = __builtin_bit_cast(half8, w[kk][ct]);
       // (the first barrier of step 0 stands between these reads and the first image written over the scratch)
+      // the four dZ stages of the tile's first gradient layer: the whole ring is free
+#pragma unroll
+      for (int v = 0; v < 4; ++v) issue_stage(v, L0, (long)tile * kTile + 64 * v);
     }
     RTXN_LN_STAMP(1);
     // One layer, l a compile-time constant: [forward: nxt = relu(W_l cur)] THEN [weight gradient of layer l from A_{l-1} = cur],
@@ -1913,14 +1943,14 @@ __device__ __forceinline__ void wgrad_recompute_pass(LeanArgs a, const int sub_b
     // contraction freed their slots -- have the forward's ~3,000 cycles to arrive: with the contraction first, the fourth stage
     // was issued when the layer began and every layer paid one memory latency (first build: 14.5 us per tile of layers 0-2).
     // Vector-memory order of a wave, which the counted waits below rely on (all static):
-    //   [W+T] wait W_l, barrier (also: everyone is done with the previous layer's X images and ring slot 3) -> issue stage (l', 3) of
-    //         the NEXT layer with a gradient, if the step before this one had one (its slot 3 has just come free)
+    //   [W+T] wait W_l, barrier (also: everyone is done with the previous layer's X images and ring slots 2, 3) -> issue stages
+    //         (l, 2), (l, 3) if the previous step was a gradient layer of this tile (it looked ahead to (l, 0), (l, 1))
     //   forward_l; waves 0, 1 write X
-    //   [v0]  wait stage (l, 0): behind it (l, 1), (l, 2), (l, 3) = 12; barrier (also: everyone is done with W_l) -> issue W of the
-    //         next forward layer (the next tile's layer 0 after the last one); contract
-    //   [v1..v3] wait stage (l, v): behind it two stages and the weights = 8 + w; barrier -> issue stage (l', v - 1); contract
-    // W_l therefore has behind it the three look-ahead stages of the previous step's contraction (12) if that step had one.
-    // Where more has been issued than a count assumes (tile boundaries, the output layer's dZ) the wait is only longer.
+    //   [v0]  wait stages (l, 0), (l, 1): behind them (l, 2), (l, 3) = 8; barrier (also: everyone is done with W_l) -> issue W of the
+    //         next forward layer (the next tile's layer 0 after the last one) [+ the output layer's dZ]; contract the first pair
+    //   [v2]  barrier -> look ahead: stages (l + 1, 0), (l + 1, 1), or the prefetch of the next tile's encoding (4); waves 2, 3 write
+    //         X; wait stages (l, 2), (l, 3): behind them the weights and the look-ahead; barrier; contract the second pair
+    // W_l therefore has behind it the look-ahead of the previous step (8) if that step was a gradient layer.
     auto layer_step = [&](auto LC) {
       constexpr int l = decltype(LC)::value;
       constexpr bool has_w = l >= L0 && l < L1, has_f = l < FWD_END;
@@ -1938,13 +1968,13 @@ __device__ __forceinline__ void wgrad_recompute_pass(LeanArgs a, const int sub_b
         constexpr bool next_w_same_tile = has_w && l + 1 < L1;
         RTXN_LN_STAMP(2 + 11 * l);
         // ---- [W+T] ----
-        if constexpr (has_f) ln_wait_vm<(prev_w ? 12 : 0)>();
+        if constexpr (has_f) ln_wait_vm<(prev_w ? 8 : 0)>();
         ln_barrier();
-        if constexpr (prev_w) {
-          // slot 3: stage 3 of the layer whose stages 0-2 the previous step's contraction looked ahead to -- this tile's
-          // layer `l` if it has a gradient (then prev was l - 1 or the previous tile's last layer), else this tile's first such layer
-          constexpr int lw = has_w ? l : L0;
-          issue_stage(3, lw, (long)tile * kTile + 64 * 3);
+        if constexpr (has_w && l > L0) {
+          // slots 2, 3 (the previous step's second pair has just left them): stages 2, 3 of this layer, whose stages 0, 1 the
+          // previous step looked ahead to
+          issue_stage(2, l, (long)tile * kTile + 64 * 2);
+          issue_stage(3, l, (long)tile * kTile + 64 * 3);
         }
         RTXN_LN_STAMP(2 + 11 * l + 1);
         // ---- forward ----
@@ -2035,39 +2065,34 @@ __device__ __forceinline__ void wgrad_recompute_pass(LeanArgs a, const int sub_b
           // instructions behind this step's stages 1-3
           constexpr bool ol_here = OUT && l == LTOT - 2;
           constexpr int w_behind = w_next + (ol_here ? 2 : 0);
-          // stage issued as slot v - 1 comes free: the next gradient layer's v - 1 (this tile's, or the next tile's first)
-          auto look_ahead = [&](int v) {
-            if (next_w_same_tile) issue_stage(v - 1, next_w, (long)tile * kTile + 64 * (v - 1));
-            else issue_stage(v - 1, L0, (long)look * kTile + 64 * (v - 1));
+          // Issued when the first pair has left slots 0, 1: the next gradient layer's stages 0, 1.  The tile's last gradient layer
+          // looks ahead to nothing (the next tile issues its four stages itself, behind its wait for the encoding): it warms the L2
+          // with the next tile's encoding instead.
+          auto look_ahead = [&]() {
+            if constexpr (next_w_same_tile) {
+              issue_stage(0, next_w, (long)tile * kTile);
+              issue_stage(1, next_w, (long)tile * kTile + 64);
+            } else {
+              prefetch_enc(look);
+            }
           };
+          constexpr int ahead_ops = next_w_same_tile ? 8 : 4;
           if (wave < 2) write_image(ximg + wave * kLnImg, cur);
-          ln_wait_vm<12>();
-          ln_barrier();                                   // stage (l, 0), the images of waves 0, 1; everyone has left the forward
+          ln_wait_vm<8>();                                // stages 0, 1: behind them stages 2, 3
+          ln_barrier();                                   // + the images of waves 0, 1; everyone has left the forward
           issue_next_weights();
           if constexpr (ol_here) issue_ol((long)tile * kTile);
           RTXN_LN_STAMP(2 + 11 * l + 3);
-          contract(acc[li], 0, 0);
+          contract_pair(acc[li], 0);
           RTXN_LN_STAMP(2 + 11 * l + 4);
-          ln_wait_vm<8 + w_behind>();
-          ln_barrier();
-          look_ahead(1);
-          RTXN_LN_STAMP(2 + 11 * l + 5);
-          contract(acc[li], 1, 1);
-          RTXN_LN_STAMP(2 + 11 * l + 6);
-          ln_barrier();                                   // both images have been read by everyone
+          ln_barrier();                                   // both images and slots 0, 1 have been read by everyone
+          look_ahead();
           if (wave >= 2) write_image(ximg + (wave - 2) * kLnImg, cur);
-          ln_wait_vm<8 + w_behind>();
+          ln_wait_vm<w_behind + ahead_ops>();             // stages 2, 3: behind them the weights (+ the output layer's dZ) and the look-ahead
           ln_barrier();
-          look_ahead(2);
           RTXN_LN_STAMP(2 + 11 * l + 7);
-          contract(acc[li], 2, 0);
+          contract_pair(acc[li], 2);
           RTXN_LN_STAMP(2 + 11 * l + 8);
-          ln_wait_vm<8 + w_behind>();
-          ln_barrier();
-          look_ahead(3);
-          RTXN_LN_STAMP(2 + 11 * l + 9);
-          contract(acc[li], 3, 1);
-          RTXN_LN_STAMP(2 + 11 * l + 10);
         } else {
           ln_barrier();                                   // everyone has left the forward: its weights may be overwritten
           issue_next_weights();
@@ -2126,8 +2151,13 @@ __device__ __forceinline__ void wgrad_recompute_pass(LeanArgs a, const int sub_b
     }
   }
 #ifdef RTXN_LN_STAMPS
-  if (sub_block == 0)
+  if (sub_block == 0) {
     for (int i = tid; i < 4 * kLnStampTiles * kLnStampSlots; i += kThreads) g_ln_stamps[(L0 / 3) * 4 * kLnStampTiles * kLnStampSlots + i] = stamp_lds[i];
+    if (tid == 0) {
+      unsigned long long* c = g_ln_clock + (L0 / 3) * 8;
+      c[0] = clk0, c[1] = __builtin_amdgcn_s_memtime(), c[2] = rt0, c[3] = __builtin_amdgcn_s_memrealtime(), c[4] = (unsigned long long)tile_it;
+    }
+  }
 #endif
 }
 
@@ -2766,7 +2796,7 @@ static int train_backward_lean_impl(const rtxn_mlp* m, const void* encT, const v
                                   wgrad_recompute_kernel<7, 6, 8, true, 8>};
   // large batches: the three passes side by side in one launch (wgrad_recompute_all_kernel); the CU split follows the passes'
   // measured cost (RTXN_LEAN_SPLIT="s1,s2" of 32 slots per XCD for experiments; RTXN_LEAN_SPLIT=0: one launch per pass)
-  int split[2] = {8, 20};
+  int split[2] = {9, 20};
   if (const char* e = getenv("RTXN_LEAN_SPLIT")) {
     if (sscanf(e, "%d,%d", &split[0], &split[1]) != 2) split[0] = split[1] = 0;
   }
@@ -2813,6 +2843,9 @@ extern "C" int rtxn_mlp_train_forward_lean(const rtxn_mlp* m, const void* encT, 
 // diagnostic builds only: the stamps of the last lean weight-gradient launch (3 passes x 4 waves x 2 tiles x 92 slots)
 extern "C" int rtxn_debug_read_lean_stamps(unsigned* dst) {
   return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_ln_stamps), sizeof(unsigned) * 3 * 4 * kLnStampTiles * kLnStampSlots) == hipSuccess ? 0 : 1;
+}
+extern "C" int rtxn_debug_read_lean_clock(unsigned long long* dst) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_ln_clock), sizeof(unsigned long long) * 3 * 8) == hipSuccess ? 0 : 1;
 }
 #endif
 

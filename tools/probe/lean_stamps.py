@@ -5,8 +5,8 @@ block of each pass, tiles 20 and 21 (diagnostic build, -DRTXN_LN_STAMPS).
   RTXN_LIB_PATH=rtx_nerf_amd/librtxn_lnstamps.so python tools/probe/lean_stamps.py [samples]
 Per pass and layer, mean over the four waves and two tiles, in cycles:
   wt   [W+T]: wait for the layer's weights + barrier + issue of stage 3        fwd  the recomputed forward layer
-  v0   first image written, wait for stage 0, barrier, next weights issued     c0..c3  the four 64-sample contractions
-  v1/v3  wait for the stage + barrier + look-ahead issue                        v2  + the second pair of images written"""
+  v0   first images written, wait for stages 0, 1, barrier, next weights issued   c01, c23  the two 128-sample contractions
+  v2   barrier, look-ahead issue, second images written, wait for stages 2, 3, barrier"""
 import ctypes
 import os
 import sys
@@ -44,10 +44,19 @@ def d(p, a, b):
     return float(((st[p, :, :, b] - st[p, :, :, a]) & 0xFFFFFFFF).mean())
 
 
+fc = _lib.lib().rtxn_debug_read_lean_clock
+fc.restype = ctypes.c_int
+cb = (ctypes.c_uint64 * 24)()
+assert fc(cb) == 0
+clk = np.frombuffer(cb, dtype=np.uint64).reshape(3, 8).astype(np.int64)
 passes = [("layers 0-2", 0, 3, 2, False), ("layers 3-5", 3, 6, 5, False), ("layers 6-7 + output", 6, 8, 8, True)]
 for p, (name, l0, l1, fwd_end, has_out) in enumerate(passes):
     last = 7 if has_out else l1 - 1
     period = float(((st[p, :, 1, 0] - st[p, :, 0, 0]) & 0xFFFFFFFF).mean())
+    c = clk[p]
+    us = (c[3] - c[2]) / 100.0
+    print(f"pass {name}: first block ran {us:.0f} us = {c[1] - c[0]} s_memtime ticks ({(c[1] - c[0]) / us / 1000:.3f} G ticks/s) over {c[4]} tiles: "
+          f"{(c[1] - c[0]) / max(c[4], 1):.0f} ticks per tile on average")
     print(f"pass {name}: tile period {period:.0f} cycles; top -> encoding in registers {d(p, 0, 1):.0f}")
     tot = dict(wt=0.0, fwd=0.0, sync=0.0, contract=0.0)
     for l in range(last + 1):
@@ -61,11 +70,11 @@ for p, (name, l0, l1, fwd_end, has_out) in enumerate(passes):
         tot["fwd"] += fw
         tot["sync"] += d(p, b + 2, b + 3)
         if has_w:
-            c = [d(p, b + 3 + 2 * i, b + 4 + 2 * i) for i in range(4)]
-            v = [d(p, b + 4 + 2 * i, b + 5 + 2 * i) for i in range(3)]
-            line += f"  c0 {c[0]:5.0f}  v1 {v[0]:5.0f}  c1 {c[1]:5.0f}  v2 {v[1]:5.0f}  c2 {c[2]:5.0f}  v3 {v[2]:5.0f}  c3 {c[3]:5.0f}"
+            c = [d(p, b + 3, b + 4), d(p, b + 7, b + 8)]
+            v2 = d(p, b + 4, b + 7)
+            line += f"  c01 {c[0]:5.0f}  v2 {v2:5.0f}  c23 {c[1]:5.0f}"
             tot["contract"] += sum(c)
-            tot["sync"] += sum(v)
+            tot["sync"] += v2
         print(line)
     if has_out:
         print(f"  tile end {d(p, 90, 91):.0f}")
