@@ -191,6 +191,15 @@ def extra_train_config3(steps, warmup, kernel_steps=5, train_to=1500, frames=12)
                             "traffic": (pk["hbm_bytes_per_launch_low"] + f32["hbm_bytes_per_launch_low"]) if (pk and f32 and "hbm_bytes_per_launch_low" in pk and "hbm_bytes_per_launch_low" in f32) else None,
                             "atomic_requests_leaving_l2": (pk["l2_to_memory_atomic_requests_per_launch"] + f32["l2_to_memory_atomic_requests_per_launch"])
                             if (pk and f32 and "l2_to_memory_atomic_requests_per_launch" in pk and "l2_to_memory_atomic_requests_per_launch" in f32) else None}
+    if "hash_bwd" in kern and kern["hash_bwd"].get("atomic_requests_leaving_l2"):
+        # What the kernel is really paced by: every atomic is executed at the memory side (PMC: TCC_EA0_ATOMIC == TCC_ATOMIC), and a wave
+        # instruction whose 64 lanes hit 64 different lines leaves the L2 as 64 requests; the guide measured that shape at 0.08 TB/s of
+        # added bytes = 20 G requests/s chip-wide (MI355X_MICROARCH.md, Global float atomics, row 'access shape').  Requests counted
+        # AFTER the run aggregation, from the committed counter pass; the kernel time of this run.
+        hb = kern["hash_bwd"]
+        req_s = hb["atomic_requests_leaving_l2"] / (hb["ms"] * 1e-3) / 1e9
+        hb["scattered"] = {"achieved": round(req_s, 2), "peak": 20.0, "unit": "G atomic requests/s leaving the L2 (one lane, one line)", "frac": round(req_s / 20.0, 4),
+                           "requests_per_live_sample": round(hb["atomic_requests_leaving_l2"] / max(live, 1), 1)}
     dom = "hash_bwd" if "hash_bwd" in kern else "encode"
     rec = {
         "workload": "4096 rays/batch, hash grid L=16 F=2 T=2^19 base 16 x1.5 + Frequency(4) dirs + 4x64 ReLU MLP, 128^3 grid "

@@ -506,7 +506,24 @@ __device__ __forceinline__ void store_fragment_rows_pair(_Float16* X, int kk, lo
 // (mlp_bwd_fused64_kernel) rebuilds the activations in registers from the encoded input.  kSaveMasks: outputs + the 16-byte
 // sign masks per sample and layer and nothing else -- the forward of the LEAN 128-wide path (below: the dgrad chain needs
 // only the masks, the weight-gradient kernel recomputes the activations): 160 instead of 2,208 bytes written per sample.
+typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
 constexpr int kSaveNone = 0, kSaveAll = 1, kSaveMasks = 2;
+// Diagnostic build only (-DRTXN_FWD_STAMPS, tools/probe/fwd_stamps.py; never in the shipped library): blocks kFwdStampBlock.. + 3 record
+// s_memtime per wave: 0 entry, 1 layer 0 done (encoding fetched, transposed, multiplied), then per hidden layer l = 1..L-1 at 2 + 3 (l - 1):
+// weights ready, MFMAs done, activations / masks saved; 2 + 3 (L - 1): output layer's weights ready, + 1: outputs stored.
+#ifdef RTXN_FWD_STAMPS
+constexpr int kFwdStampBlock = 6000, kFwdStampSlots = 32;
+__device__ unsigned g_fwd_stamps[4 * 4 * kFwdStampSlots];
+#define RTXN_FWD_STAMP(k)                                                                                               \
+  do {                                                                                                                  \
+    if (blockIdx.x >= kFwdStampBlock && blockIdx.x < kFwdStampBlock + 4 && NW == 4) {                                   \
+      const unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime();                                                       \
+      if (lane == 0) g_fwd_stamps[((blockIdx.x - kFwdStampBlock) * 4 + wave) * kFwdStampSlots + (k)] = t_;              \
+    }                                                                                                                   \
+  } while (0)
+#else
+#define RTXN_FWD_STAMP(k)
+#endif
 constexpr int kEncScratch = 6 * 1024;                    // per wave: 48 feature rows x 64 samples of the encoding (layer 0's operand)
 // NW: waves per block = 64-sample column pairs per block tile.  4 (256 samples, two blocks per CU, one weight buffer): the form of
 // rounds 1-3.  8 (512 samples, ONE block per CU, the weights double-buffered, the next layer's fetched under this layer's MFMAs;
@@ -530,6 +547,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_train_fwd_kernel(TrainArgs a) 
   const int KS0 = a.E / 16;
   const int L = a.n_hidden;
   long off = 0;
+  RTXN_FWD_STAMP(0);
   const int WB = (KS0 > KS ? KS0 : KS) * RT * 1024;        // one weight buffer
   // every wave of the block fetches its share of a layer's fragments (1 KiB per wave instruction)
   auto stage_w = [&](const uint8_t* g, uint8_t* lds_buf, int bytes) {
@@ -591,6 +609,15 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_train_fwd_kernel(TrainArgs a) 
     const _Float16* src = a.encT + gcol + (long)r8 * a.Sp;
     const int wr_off = r8 * 128 + ((jg * 16) ^ (((r8 >> 2) & 1) * 64));
     const int rd_off = (4 * h) * 128 + ((col * 2) ^ (h * 64));   // + feature row (of the chunk, rows & 7 < 4) * 128 + (ct * 64, same swap)
+    // a chunk's six loads are issued a chunk ahead -- the first in front of the wait for layer 0's weights -- so that the kernel
+    // stands still for ONE memory round trip per tile, not one per chunk plus the weights' (19,000 of the tile's 73,000 cycles)
+    auto load_chunk = [&](int c0, rtxn::int4v (&pc)[6]) {
+#pragma unroll
+      for (int p = 0; p < 6; ++p)
+        pc[p] = c0 + 8 * p < a.E ? *reinterpret_cast<const rtxn::int4v*>(src + (long)(c0 + 8 * p) * a.Sp) : rtxn::int4v{0, 0, 0, 0};
+    };
+    rtxn::int4v piece[6], ahead[6];                      // two chunks in flight, taking turns (no copies: a copy would wait for the load)
+    load_chunk(0, piece);
     const uint8_t* w0 = weights_ready(0);
     floatx16 acc[RT][2];
 #pragma unroll
@@ -599,13 +626,9 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_train_fwd_kernel(TrainArgs a) 
       for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[rt][ct][e] = 0.0f;
-    for (int c0 = 0; c0 < a.E; c0 += 48) {               // E is a multiple of 16: a chunk is 1-3 whole k-steps
-      rtxn::int4v piece[6];
+    auto chunk = [&](int c0, const rtxn::int4v (&pc)[6]) {
 #pragma unroll
-      for (int p = 0; p < 6; ++p)
-        piece[p] = c0 + 8 * p < a.E ? *reinterpret_cast<const rtxn::int4v*>(src + (long)(c0 + 8 * p) * a.Sp) : rtxn::int4v{0, 0, 0, 0};
-#pragma unroll
-      for (int p = 0; p < 6; ++p) *reinterpret_cast<rtxn::int4v*>(scratch + p * 1024 + wr_off) = piece[p];
+      for (int p = 0; p < 6; ++p) *reinterpret_cast<rtxn::int4v*>(scratch + p * 1024 + wr_off) = pc[p];
 #pragma unroll
       for (int k3 = 0; k3 < 3; ++k3) {
         const int kk = c0 / 16 + k3;
@@ -622,6 +645,14 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_train_fwd_kernel(TrainArgs a) 
 #pragma unroll
           for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, b[ct], acc[rt][ct], 0, 0, 0);
         }
+      }
+    };
+    for (int c0 = 0; c0 < a.E; c0 += 96) {               // E is a multiple of 16: a chunk is 1-3 whole k-steps
+      if (c0 + 48 < a.E) load_chunk(c0 + 48, ahead);
+      chunk(c0, piece);
+      if (c0 + 48 < a.E) {
+        if (c0 + 96 < a.E) load_chunk(c0 + 96, piece);
+        chunk(c0 + 48, ahead);
       }
     }
     // (layer 0 reads LDS with compiler-generated loads, in front of which hipcc waits for every LDS-DMA in flight: layer 1's
@@ -652,25 +683,36 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_train_fwd_kernel(TrainArgs a) 
             if (store_s[ct]) *row_elem(dst, perm_feature(kk, 0, j), a.Sp, lane_off[ct]) = ok_s[ct] ? v[kk][ct][j] : (_Float16)0.0f;
     }
     // sign masks for the backward chain (mlp_bwd_kernel, see there): values are post-ReLU (>= 0), so "> 0" is "the half is
-    // not +0"
+    // not +0".  Two instructions per dword of activations: v_pk_min_u16 with (1, 1) turns both halves into their bit, and
+    // v_dot2_u32_u16 with the weights (1 << s, 2 << s) drops the pair at bit s of a running 16-bit field (two k-steps per field:
+    // the weights are 16-bit).  Spelled as compares, shifts and ors this was ~550 VALU instructions per layer and wave -- 2,200 of
+    // a layer's 5,800 cycles in the forward that stores nothing else (phase stamps, profiles/r04/fwd_stamps.txt).
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
+      unsigned field[KS / 2];
+#pragma unroll
+      for (int kp = 0; kp < KS / 2; ++kp) {
+        unsigned f = 0;
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+          const rtxn::int4v w = __builtin_bit_cast(rtxn::int4v, v[2 * kp + k2][ct]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int s = 8 * k2 + 2 * e;
+            unsigned nz;
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(nz) : "v"(w[e]), "s"(0x00010001u));
+            f = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, nz), ushort2v{(unsigned short)(1u << s), (unsigned short)(2u << s)}, f, false);
+          }
+        }
+        field[kp] = f;
+      }
       unsigned long long mk = 0;
 #pragma unroll
-      for (int kk = 0; kk < KS; ++kk) {
-        const rtxn::int4v w = __builtin_bit_cast(rtxn::int4v, v[kk][ct]);
-        unsigned bits = 0;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const unsigned d = (unsigned)w[e];
-          bits |= ((d & 0xffffu) != 0 ? 1u : 0u) << (2 * e);
-          bits |= ((d >> 16) != 0 ? 1u : 0u) << (2 * e + 1);
-        }
-        mk |= (unsigned long long)bits << (8 * kk);
-      }
+      for (int kp = 0; kp < KS / 2; ++kp) mk |= (unsigned long long)field[kp] << (16 * kp);
       if (store_s[ct]) a.masks[((long)l * a.Sp + samp[ct]) * 2 + h] = mk;
     }
   };
+  RTXN_FWD_STAMP(1);
   save_acts(0, bf);
   // hidden layer on the hand-scheduled pipeline of the inference kernel (accumulators double-buffered by row tile: the
   // compiler-scheduled loop kept all RT tiles live and spilled at W = 128); nothing is staged underneath it here, and
@@ -678,26 +720,31 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_train_fwd_kernel(TrainArgs a) 
   auto hidden_layer = [&](int l, half8 (&in)[KS][2], half8 (&out)[KS][2]) {
     const uint8_t* w = weights_ready(l);
     prefetch(l);                                          // under this layer's MFMAs (pipe_layer reads LDS in asm: no compiler wait)
+    RTXN_FWD_STAMP(2 + 3 * (l - 1));
     floatx16 acc2[2][2];
     rtxn::pipe_layer<RT, KS, KS>(w, in, out, acc2, lane);
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) out[2 * (RT - 1) + s2][ct] = rtxn::relu_pack(acc2[1][ct], s2);
+    RTXN_FWD_STAMP(2 + 3 * (l - 1) + 1);
   };
   // ---- hidden layers 1..L-1 (ping-pong bf <-> bg) ----
   int l = 1;
   for (; l + 1 < L; l += 2) {
     hidden_layer(l, bf, bg);
     save_acts(l, bg);
+    RTXN_FWD_STAMP(2 + 3 * (l - 1) + 2);
     off += (long)KS * RT * 1024;
     hidden_layer(l + 1, bg, bf);
     save_acts(l + 1, bf);
+    RTXN_FWD_STAMP(2 + 3 * l + 2);
     off += (long)KS * RT * 1024;
   }
   if (l < L) {
     hidden_layer(l, bf, bg);
     save_acts(l, bg);
+    RTXN_FWD_STAMP(2 + 3 * (l - 1) + 2);
     off += (long)KS * RT * 1024;
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk)
@@ -707,6 +754,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_train_fwd_kernel(TrainArgs a) 
   if (a.live_list) return;                                // the live pass saves activations only: the outputs exist already
   // ---- output layer ----
   const uint8_t* wL = weights_ready(L);
+  RTXN_FWD_STAMP(2 + 3 * (L - 1));
   floatx16 acc[2];
   out_mma<KS, KS>(wL, bf, acc, lane);
 #pragma unroll
@@ -727,7 +775,13 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_train_fwd_kernel(TrainArgs a) 
     *reinterpret_cast<half4v*>(o + 8 + 4 * h) = hi;
     if (a.radiance && h == 0) a.radiance[s] = make_float4((float)lo[0], (float)lo[1], (float)lo[2], (float)lo[3]);
   }
+  RTXN_FWD_STAMP(2 + 3 * (L - 1) + 1);
 }
+#ifdef RTXN_FWD_STAMPS
+extern "C" int rtxn_debug_read_fwd_stamps(unsigned* dst) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_fwd_stamps), sizeof(unsigned) * 4 * 4 * kFwdStampSlots) == hipSuccess ? 0 : 1;
+}
+#endif
 
 // ------------------------------------------------------------------------- MLP backward (dgrad)
 template <int W>

@@ -9,7 +9,10 @@ S = int(sys.argv[1]) if len(sys.argv) > 1 else 4_695_827
 splits = sys.argv[2:] or ["8,18", "8,20", "9,20", "9,21", "8,19", "0"]
 W, L, E = 128, 8, 112
 net = api.Network(n_neurons=W, n_hidden_layers=L)
-net.set_params(torch.from_numpy(scenes.xavier_params_fp16(W, L, E, seed=3)).cuda())
+wts = scenes.xavier_params_fp16(W, L, E, seed=3)
+if os.environ.get("LEAN_ZERO_WEIGHTS"):      # same instruction stream on zeros (activations, masks and hidden dZ all zero): is the kernel power-limited?
+    wts = np.zeros_like(wts)
+net.set_params(torch.from_numpy(wts).cuda())
 Sp = api.padded_samples(S)
 g = torch.Generator(device="cuda").manual_seed(5)
 encT = (torch.rand((E, Sp), device="cuda", generator=g) * 2 - 1).half()
