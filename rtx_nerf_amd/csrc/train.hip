@@ -115,6 +115,20 @@ __device__ __forceinline__ void sample_pos(const SampleSrc& src, long s, bool ok
     }
   }
 }
+// The same for an index the caller has made valid, WITHOUT a branch between the two sources: the addresses are selected, not the
+// loaded values (a merge of loaded values is a register copy, and hipcc waits for the loads in front of it); for the explicit
+// samples both reads hit the same address and the interpolation weight is 0.  Every lane loads; nothing waits between the loads.
+__device__ __forceinline__ void sample_pos_unmasked(const SampleSrc& src, long s, float (&x)[3]) {
+  const long g = (s >> 5) * 3;
+  const float* p0 = src.in ? src.in + 5 * s : src.start + g;
+  const float* p1 = src.in ? p0 : src.end + g;
+  const float t = src.in ? 0.0f : ((float)(int)(s & 31) + (src.midpoint ? 0.5f : 0.0f)) * (1.0f / 32);
+  float og[3], en[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) og[a] = p0[a], en[a] = p1[a];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) x[a] = fmaf(t, en[a] - og[a], og[a]);
+}
 __device__ __forceinline__ void sample_dir(const SampleSrc& src, long s, bool ok, float (&v)[2]) {
   if (src.in) {
     v[0] = ok ? src.in[5 * s + 3] : 0.0f;
@@ -370,20 +384,36 @@ __global__ __launch_bounds__(kThreads) void hashgrid_backward_kernel(HgLevels lv
   long s = (long)blockIdx.x * kThreads + threadIdx.x;           // every lane stays: the aggregation reads across the wave
   const bool ok = s < S;
   if (live_list) s = ok ? (long)live_list[s >> 5] * 32 + (s & 31) : 0;
+  // Loads are unconditional on a clamped index and masked afterwards: a load under `ok ? ... : 0` comes out of hipcc as a branch
+  // with `s_waitcnt vmcnt(0)` behind it -- this kernel's start was five memory round trips in a row (list entry, one per
+  // feature, two for the position); now the list entry, then everything else at once.
+  const long sc = ok ? s : 0;
+  // the position is fetched beside the gradient, its loads first (most waves leave right below: 12-24 bytes per lane read in vain,
+  // but no round trip of their own)
+  float x3[3];
+  sample_pos_unmasked(src, sc, x3);
   float d[8];
   bool any_grad = false;
-  for (int f = 0; f < F && f < 8; ++f) {
-    d[f] = ok ? (float)dencT[(long)(l * F + f) * Sp + s] : 0.0f;
-    any_grad |= d[f] != 0.0f;
+  if (F == 2) {
+    const float d0 = (float)dencT[(long)(l * 2) * Sp + sc], d1 = (float)dencT[(long)(l * 2 + 1) * Sp + sc];
+    d[0] = ok ? d0 : 0.0f;
+    d[1] = ok ? d1 : 0.0f;
+    any_grad = d[0] != 0.0f || d[1] != 0.0f;
+  } else {
+    for (int f = 0; f < F && f < 8; ++f) {
+      d[f] = ok ? (float)dencT[(long)(l * F + f) * Sp + s] : 0.0f;
+      any_grad |= d[f] != 0.0f;
+    }
   }
+
   // A wave whose 64 samples all have a zero gradient at this level adds nothing: most of a NeRF batch (samples behind the
   // surface: transmittance 0) -- on the configs[2] batch 71 % of the waves leave here.
   if (__ballot(any_grad) == 0) return;
-  float fr[3], x3[3];
+  float fr[3];
   unsigned g[3];
-  sample_pos(src, s, ok, x3);
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
+    if (!ok) x3[a] = 0.0f;
     const float x01 = fmaf(x3[a], 0.5f, 0.5f);
     const float p = fmaf(x01, lv.scale[l], 0.5f), fl = floorf(p);
     g[a] = (unsigned)(int)fl;
@@ -614,11 +644,16 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_train_fwd_kernel(TrainArgs a) 
     auto load_chunk = [&](int c0, rtxn::int4v (&pc)[6]) {
 #pragma unroll
       for (int p = 0; p < 6; ++p)
-        pc[p] = c0 + 8 * p < a.E ? *reinterpret_cast<const rtxn::int4v*>(src + (long)(c0 + 8 * p) * a.Sp) : rtxn::int4v{0, 0, 0, 0};
+        // rows past the encoding are clamped, not skipped: their k-steps are never multiplied, and a conditional load here came out
+        // of hipcc as six branches with `s_waitcnt vmcnt(0)` behind every single load -- six memory round trips in a row per chunk
+        // (6,900 cycles from the block's entry to its first chunk's last load: phase stamps)
+        pc[p] = *reinterpret_cast<const rtxn::int4v*>(src + (long)min(c0 + 8 * p, a.E - 8) * a.Sp);
     };
     rtxn::int4v piece[6], ahead[6];                      // two chunks in flight, taking turns (no copies: a copy would wait for the load)
     load_chunk(0, piece);
+    RTXN_FWD_STAMP(26);
     const uint8_t* w0 = weights_ready(0);
+    RTXN_FWD_STAMP(27);
     floatx16 acc[RT][2];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -629,30 +664,36 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_train_fwd_kernel(TrainArgs a) 
     auto chunk = [&](int c0, const rtxn::int4v (&pc)[6]) {
 #pragma unroll
       for (int p = 0; p < 6; ++p) *reinterpret_cast<rtxn::int4v*>(scratch + p * 1024 + wr_off) = pc[p];
+      // all of the chunk's fragment reads first, then its MFMAs: k-step by k-step (reads, wait, permute, multiply) every k-step
+      // was two or three LDS round trips in a row with the partner block's layer on the same pipe (1,700-2,000 cycles each: stamps)
+      half8 b[3][2];
 #pragma unroll
-      for (int k3 = 0; k3 < 3; ++k3) {
-        const int kk = c0 / 16 + k3;
-        if (kk >= KS0) break;
-        half8 b[2];
+      for (int k3 = 0; k3 < 3; ++k3)
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
           for (int j = 0; j < 8; ++j)
-            b[ct][j] = *reinterpret_cast<const _Float16*>(scratch + (perm_feature(k3, 0, j)) * 128 + (rd_off ^ (ct * 64)));
+            b[k3][ct][j] = *reinterpret_cast<const _Float16*>(scratch + (perm_feature(k3, 0, j)) * 128 + (rd_off ^ (ct * 64)));
+#pragma unroll
+      for (int k3 = 0; k3 < 3; ++k3) {
+        const int kk = c0 / 16 + k3;
+        if (kk >= KS0) break;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
           const half8 af = *reinterpret_cast<const half8*>(w0 + ((rt * KS0 + kk) * 64 + lane) * 16);
 #pragma unroll
-          for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, b[ct], acc[rt][ct], 0, 0, 0);
+          for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, b[k3][ct], acc[rt][ct], 0, 0, 0);
         }
       }
     };
     for (int c0 = 0; c0 < a.E; c0 += 96) {               // E is a multiple of 16: a chunk is 1-3 whole k-steps
       if (c0 + 48 < a.E) load_chunk(c0 + 48, ahead);
       chunk(c0, piece);
+      RTXN_FWD_STAMP(28 + (c0 ? 2 : 0));
       if (c0 + 48 < a.E) {
         if (c0 + 96 < a.E) load_chunk(c0 + 96, piece);
         chunk(c0 + 48, ahead);
+        RTXN_FWD_STAMP(29);
       }
     }
     // (layer 0 reads LDS with compiler-generated loads, in front of which hipcc waits for every LDS-DMA in flight: layer 1's

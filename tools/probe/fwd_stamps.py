@@ -40,6 +40,8 @@ st = np.frombuffer(buf, dtype=np.uint32).reshape(4, 4, 32).astype(np.int64)
 d = lambda a, b: ((st[:, :, b] - st[:, :, a]) & 0xFFFFFFFF)
 print(f"mode {mode}: block lifetime {d(0, 2 + 3 * (L - 1) + 1).mean():.0f} cycles (per block: {d(0, 2 + 3 * (L - 1) + 1).mean(axis=1).round()})")
 print(f"  layer 0 (fetch + transpose + 7 k-steps) {d(0, 1).mean():.0f}")
+print(f"    entry -> first chunk's loads issued {d(0, 26).mean():.0f}; -> layer 0's weights landed (and that chunk) {d(26, 27).mean():.0f}; chunk 0 {d(27, 28).mean():.0f}; "
+      f"chunk 1 {d(28, 29).mean():.0f}; chunk 2 {d(29, 30).mean():.0f}; pack {d(30, 1).mean():.0f}")
 prev = 1
 for l in range(1, L):
     b = 2 + 3 * (l - 1)
