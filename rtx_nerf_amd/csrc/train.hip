@@ -664,6 +664,9 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_train_fwd_kernel(TrainArgs a) 
     auto chunk = [&](int c0, const rtxn::int4v (&pc)[6]) {
 #pragma unroll
       for (int p = 0; p < 6; ++p) *reinterpret_cast<rtxn::int4v*>(scratch + p * 1024 + wr_off) = pc[p];
+#ifdef RTXN_FWD_STAMPS
+      if (c0 == 0) RTXN_FWD_STAMP(25);
+#endif
       // all of the chunk's fragment reads first, then its MFMAs: k-step by k-step (reads, wait, permute, multiply) every k-step
       // was two or three LDS round trips in a row with the partner block's layer on the same pipe (1,700-2,000 cycles each: stamps)
       half8 b[3][2];
@@ -674,6 +677,12 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_train_fwd_kernel(TrainArgs a) 
 #pragma unroll
           for (int j = 0; j < 8; ++j)
             b[k3][ct][j] = *reinterpret_cast<const _Float16*>(scratch + (perm_feature(k3, 0, j)) * 128 + (rd_off ^ (ct * 64)));
+#ifdef RTXN_FWD_STAMPS
+      if (c0 == 0) {
+        asm volatile("" : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[2][0]), "+v"(b[2][1]));
+        RTXN_FWD_STAMP(31);
+      }
+#endif
 #pragma unroll
       for (int k3 = 0; k3 < 3; ++k3) {
         const int kk = c0 / 16 + k3;
@@ -2682,7 +2691,10 @@ static int train_forward_impl(const rtxn_mlp* m, const void* encT, long n_sample
   // sign masks 1.43 against 1.35: the double buffer's vmcnt(0) also waits for the mask stores), so the 4-wave form stays the default.
   static const bool waves8 = getenv("RTXN_TRAIN_FWD_WAVES") && atoi(getenv("RTXN_TRAIN_FWD_WAVES")) == 8;
   const int NW = W == 128 && waves8 ? 8 : 4;
-  const size_t lds = (size_t)(KS0 > KS ? KS0 : KS) * RT * 1024 * (NW == 8 ? 2 : 1) + NW * kEncScratch;
+  // (RTXN_TRAIN_FWD_ALONE=1, diagnostic: 40 KiB of LDS nobody uses, so that only ONE block fits a CU -- what a block's phases cost
+  // without a partner on its SIMDs: profiles/r04/fwd_stamps.txt)
+  static const bool alone = getenv("RTXN_TRAIN_FWD_ALONE") && atoi(getenv("RTXN_TRAIN_FWD_ALONE")) == 1;
+  const size_t lds = (size_t)(KS0 > KS ? KS0 : KS) * RT * 1024 * (NW == 8 ? 2 : 1) + NW * kEncScratch + (alone ? 40 * 1024 : 0);
   hipStream_t s = rtxn::as_stream(stream);
   const dim3 grid((unsigned)((Sp + 64 * NW - 1) / (64 * NW))), block(64 * NW);
 #define RTXN_FWD_LAUNCH(WW, SAVE, NWV)                                                                        \

@@ -42,6 +42,7 @@ print(f"mode {mode}: block lifetime {d(0, 2 + 3 * (L - 1) + 1).mean():.0f} cycle
 print(f"  layer 0 (fetch + transpose + 7 k-steps) {d(0, 1).mean():.0f}")
 print(f"    entry -> first chunk's loads issued {d(0, 26).mean():.0f}; -> layer 0's weights landed (and that chunk) {d(26, 27).mean():.0f}; chunk 0 {d(27, 28).mean():.0f}; "
       f"chunk 1 {d(28, 29).mean():.0f}; chunk 2 {d(29, 30).mean():.0f}; pack {d(30, 1).mean():.0f}")
+print(f"    chunk 0 in parts: scratch written {d(27, 25).mean():.0f}; its 48 two-byte reads back and permuted {d(25, 31).mean():.0f}; 12 fragment reads + 24 MFMAs {d(31, 28).mean():.0f}")
 prev = 1
 for l in range(1, L):
     b = 2 + 3 * (l - 1)
