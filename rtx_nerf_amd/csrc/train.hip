@@ -651,6 +651,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_train_fwd_kernel(TrainArgs a) 
     };
     rtxn::int4v piece[6], ahead[6];                      // two chunks in flight, taking turns (no copies: a copy would wait for the load)
     load_chunk(0, piece);
+    __builtin_amdgcn_sched_barrier(0);
     RTXN_FWD_STAMP(26);
     const uint8_t* w0 = weights_ready(0);
     RTXN_FWD_STAMP(27);
@@ -695,14 +696,30 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_train_fwd_kernel(TrainArgs a) 
         }
       }
     };
-    for (int c0 = 0; c0 < a.E; c0 += 96) {               // E is a multiple of 16: a chunk is 1-3 whole k-steps
-      if (c0 + 48 < a.E) load_chunk(c0 + 48, ahead);
-      chunk(c0, piece);
-      RTXN_FWD_STAMP(28 + (c0 ? 2 : 0));
-      if (c0 + 48 < a.E) {
-        if (c0 + 96 < a.E) load_chunk(c0 + 96, piece);
-        chunk(c0 + 48, ahead);
-        RTXN_FWD_STAMP(29);
+    if (a.E == 112) {
+      // the reference's encoding, straight-line: in the loop below hipcc waits `vmcnt(0)` in front of every chunk's LDS writes --
+      // for the chunk it has just asked for as well (the registers are loop-carried) -- so a chunk's fetch never ran under the
+      // previous chunk's work (3,400 cycles of round trip per chunk: stamps); without the back edge its counts are exact
+      // (sched_barrier: left alone, hipcc's scheduler sinks each chunk's loads down to their first use -- behind the previous
+      // chunk's MFMAs -- to save registers)
+      load_chunk(48, ahead);
+      __builtin_amdgcn_sched_barrier(0);
+      chunk(0, piece);
+      RTXN_FWD_STAMP(28);
+      load_chunk(96, piece);
+      __builtin_amdgcn_sched_barrier(0);
+      chunk(48, ahead);
+      RTXN_FWD_STAMP(29);
+      chunk(96, piece);
+      RTXN_FWD_STAMP(30);
+    } else {
+      for (int c0 = 0; c0 < a.E; c0 += 96) {             // E is a multiple of 16: a chunk is 1-3 whole k-steps
+        if (c0 + 48 < a.E) load_chunk(c0 + 48, ahead);
+        chunk(c0, piece);
+        if (c0 + 48 < a.E) {
+          if (c0 + 96 < a.E) load_chunk(c0 + 96, piece);
+          chunk(c0 + 48, ahead);
+        }
       }
     }
     // (layer 0 reads LDS with compiler-generated loads, in front of which hipcc waits for every LDS-DMA in flight: layer 1's

@@ -501,13 +501,19 @@ def test_deterministic_mode_makes_two_trainers_bit_identical(gpu, encoding, mode
         for k, (x, y) in enumerate(zip(_state(a), _state(b))):
             assert torch.equal(x, y), f"eager vs eager: step {i}, tensor {k}: {int((x != y).sum())} of {x.numel()} differ"
         assert abs(float(la) - float(lb)) <= 1e-6 * abs(float(la))      # (the reported loss sum stays a float atomic)
+        if i == 0:
+            # one step: the same gradients bit for bit, Adam's beta^t from the device counter (v_exp_f32) against the host's: measured
+            # 0 to 7e-8 (tools/probe/det_gap.py); the default mode's bar for this comparison is 3e-2 / 0.2
+            for k, (x, y) in enumerate(zip(_state(a), _state(c))):
+                if x.dtype in (torch.float32, torch.float16):
+                    assert float((x.float() - y.float()).norm()) <= 1e-6 * float(x.float().norm()) + 1e-12, f"eager vs rtxn_train_step after ONE step: tensor {k}"
     moved = float((a.master - _small_trainer(torch, encoding, mode, neurons, layers).master).abs().max())
     assert moved > 1e-3 and bool(torch.isfinite(a.master).all())
     # the one-call step: the same gradient kernels, but its Adam takes beta^t from the device step counter (v_exp_f32, 1e-6 relative on
-    # the learning rate) and a saved-activation model's eager step saves activations in a second pass: close, not bit-identical
+    # the learning rate): equal to 1e-6 after one step (above), and what is left of that after six
     for k, (x, y) in enumerate(zip(_state(a), _state(c))):
         if x.dtype in (torch.float32, torch.float16):
-            assert float((x.float() - y.float()).norm()) <= 3e-2 * float(x.float().norm()) + 1e-12, f"eager vs rtxn_train_step: tensor {k}"   # the bar of test_train_step_entry_matches_the_eager_step
+            assert float((x.float() - y.float()).norm()) <= 8e-3 * float(x.float().norm()) + 1e-12, f"eager vs rtxn_train_step: tensor {k}"   # measured <= 2.5e-3 after six steps at lr 1e-2 (the 1e-7 of step one, amplified); default mode: 3e-2
     # the shadows are left clean, and the default mode is untouched by a deterministic trainer living in the same process
     assert int(a._det_mlp.abs().max()) == 0 and (a._det_table is None or int(a._det_table.abs().max()) == 0)
     plain = _small_trainer(torch, encoding, mode, neurons, layers)
