@@ -399,6 +399,16 @@ def train_ref_record(batch_rays, grid_res, steps, warmup, dense_grid=True, mode=
         flop_exec = 262144 * (1.0 + 2.0 * live_frac + (live_frac if tr.two_pass else 0.0))
         bytes_exec = ((256 + live_frac * 2400) if tr.two_pass else 2432) + live_frac * (2248 + 4352)
     tf = flop_exec * S / (ms * 1e-3) / 1e12
+    # HBM bytes of the three lean kernels from the committed counter passes (tools/pmc_lean_bytes.py: FETCH_SIZE doubled + WRITE_SIZE per
+    # sample of the 22,528-ray batch, 88 % of its segments live), quoted only for the dense batches they were measured on and only while
+    # all three kernels still carry the measured machine code
+    traffic = None
+    if getattr(tr, "lean", False) and dense_grid and all(pmc_kernel(k) for k in ("mlp_train_fwd_128_masks", "mlp_bwd_128", "wgrad_recompute_all")):
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04", "lean_pmc_bytes_per_sample.json")) as f:
+                traffic = int(json.load(f)["lean path, three kernels"]["bytes_per_sample_fetch_doubled"] * S)
+        except (OSError, KeyError, ValueError):
+            traffic = None
     rec = {
         "workload": f"{B} rays/batch, 8x128 ReLU MLP + Composite-Frequency(10, 12), REGULAR sampler, "
                     f"{'the reference compositor fwd/bwd (RTXN_VR_COMPAT)' if mode == 'compat' else 'NeRF compositor'}, L2, Adam 1e-3; "
@@ -411,7 +421,7 @@ def train_ref_record(batch_rays, grid_res, steps, warmup, dense_grid=True, mode=
                                  else "mlp_train_fwd_kernel<128> + mlp_bwd_kernel<128> + wgrad_lds_kernel"),
                      "bound": "mfma", "achieved": round(tf, 1),
                      "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_F16_DENSE_PEAK_TFLOPS, 4),
-                     "flop_executed_per_sample": int(flop_exec), "flop_nominal_per_sample": nominal, "samples_per_launch": int(S), "traffic": None,
+                     "flop_executed_per_sample": int(flop_exec), "flop_nominal_per_sample": nominal, "samples_per_launch": int(S), "traffic": traffic,
                      "live_fraction": round(live_frac, 4),
                      "note": "whole step; achieved / frac count the matrix work EXECUTED (forward for every sample; dgrad, weight gradient and "
                              "its recomputed forward layers for the segments that carry a loss gradient); frac_nominal = the asked "

@@ -72,5 +72,46 @@ for it in range(a.iters):
     if errs:
         bad += 1
         print(f"MISMATCH it={it} W={W} L={L} E={E} act={act} n={n}: {errs}", flush=True)
-print(f"fuzz_train: {a.iters} cases, {bad} mismatches")
+# the lean 8 x 128 path (sign masks + dZ only, weight gradient recomputes the activations): random batch sizes around its 256-sample
+# tiles, random spans of zero loss gradient (dead tiles are stepped over), both output activations -- against the oracle's backward
+n_lean = max(a.iters // 3, 4)
+for it in range(n_lean):
+    W, L, E = 128, 8, 112
+    act = int(rng.integers(0, 2))
+    n = int(rng.choice([1, 31, 255, 256, 257, 511, 513, 1025, int(rng.integers(1, 9000)), int(rng.integers(15000, 22000))]))
+    params = scenes.xavier_params_fp16(W, L, E, seed=1000 + it)
+    enc = rng.uniform(-1, 1, (n, E)).astype(np.float16)
+    Sp = api.padded_samples(n)
+    encT = np.zeros((E, Sp), np.float16)
+    encT[:, :n] = enc.T
+    net = api.Network(n_neurons=W, n_hidden_layers=L, n_encoded_features=E, output_activation=act)
+    net.set_params(dev(params))
+    assert net.lean_supported()
+    encT_d = dev(encT)
+    ws = net.train_lean_workspace(n)
+    out = torch.empty((n, 16), dtype=torch.float16, device="cuda")
+    net.train_forward_lean(encT_d, n, ws, out)
+    dout = (rng.standard_normal((n, 4)) * 0.05).astype(np.float16)
+    for _ in range(int(rng.integers(0, 4))):                 # dead spans: whole tiles and ragged pieces
+        lo = int(rng.integers(0, n)); dout[lo:lo + int(rng.integers(1, 1500))] = 0
+    dparams = torch.zeros(net.n_params(), device="cuda")
+    net.train_backward_lean(encT_d, out, dev(dout), n, ws, dparams)
+    torch.cuda.synchronize()
+    o_acts, o_out = O.mlpe_forward(W, L, act, params, enc)
+    errs = []
+    got = out.cpu().numpy().astype(np.float32)
+    if not (np.isfinite(got).all() and np.abs(got[:, :4] - o_out.astype(np.float32)[:, :4]).max() <= (1e-2 if act else 3e-2)):
+        errs.append("forward output")
+    acts_sm = np.ascontiguousarray(o_acts)
+    want_dp, _ = O.mlpe_backward(W, L, act, params, enc, acts_sm, out.cpu().numpy(), dout)
+    got_dp = dparams.cpu().numpy()
+    scale = np.abs(want_dp).max()
+    if scale > 0 and not (np.abs(got_dp - want_dp).max() < 3e-2 * scale and np.linalg.norm(got_dp - want_dp) < 2e-2 * np.linalg.norm(want_dp)):
+        errs.append(f"weight gradient: max err {np.abs(got_dp - want_dp).max() / max(scale, 1e-30):.3g} of scale")
+    if scale == 0 and np.abs(got_dp).max() != 0:
+        errs.append("non-zero gradient for an all-zero loss gradient")
+    if errs:
+        bad += 1
+        print(f"MISMATCH lean it={it} act={act} n={n}: {errs}", flush=True)
+print(f"fuzz_train: {a.iters} + {n_lean} lean cases, {bad} mismatches")
 sys.exit(1 if bad else 0)
