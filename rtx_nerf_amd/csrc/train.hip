@@ -1992,7 +1992,7 @@ __device__ __forceinline__ void wgrad_recompute_pass(LeanArgs a, const int sub_b
 
   while (tile < a.n_tiles) {
     const int nxt_tile = next_live(tile + sub_grid);
-    const int look = nxt_tile < a.n_tiles ? nxt_tile : tile;       // no further tile: the look-ahead stages re-read this one (unused)
+    const int look = nxt_tile < a.n_tiles ? nxt_tile : tile;       // no further tile: the encoding prefetch touches this one again (harmless; the wait counts stay static)
     RTXN_LN_STAMP(0);
     const long tile0 = (long)tile * kTile + wave * 64;
     // where the wave's two 32-sample column tiles sit in encT: consecutive, or with the live list two listed segments
@@ -2236,7 +2236,7 @@ __device__ __forceinline__ void wgrad_recompute_pass(LeanArgs a, const int sub_b
 #endif
     tile = nxt_tile;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the last look-ahead stages land in LDS this block still owns
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the last prefetch instructions land in LDS this block still owns
   __syncthreads();
   // The accumulators were last written by asm MFMAs, which hipcc's hazard recogniser does not see: the MFMA-result -> read wait
   // states are spent here, with the accumulators going THROUGH the statement (rtxn::mfma_results_settle, for AGPRs;
