@@ -394,6 +394,11 @@ def train_ref_record(batch_rays, grid_res, steps, warmup, dense_grid=True, mode=
         path = "lean: sign masks only, weight gradient recomputes the activations (three passes)"
         flop_exec = 262144 * (1.0 + live_frac * (1.0 + 1.0 + 15.0 / 8.0))
         bytes_exec = 384 + live_frac * (2248 + 2080 + 3 * 224)
+        if getattr(tr, "lean_fused", False):
+            # sampler + encoder folded into the forward and into the weight gradient: no encT (forward: 1 B of segment constants in, 32 B out,
+            # 128 B of masks, 4 B of t_vals; weight gradient: dZ only)
+            path = "lean, encoder folded in: sign masks only, weight gradient recomputes encoding and activations (three passes)"
+            bytes_exec = 165 + live_frac * (2248 + 2080)
     else:
         path = "saved activations" + (" (outputs-only forward + saving pass over the live segments)" if tr.two_pass else "")
         flop_exec = 262144 * (1.0 + 2.0 * live_frac + (live_frac if tr.two_pass else 0.0))

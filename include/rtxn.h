@@ -504,6 +504,20 @@ int rtxn_mlp_train_lean_supported(const rtxn_mlp* m);
 size_t rtxn_mlp_train_lean_workspace_bytes(const rtxn_mlp* m, long n_samples);
 int rtxn_mlp_train_forward_lean(const rtxn_mlp* m, const void* encT, long n_samples, void* workspace_lean, void* output_half,
                                 float* radiance, rtxn_stream_t stream);
+/* The same forward with the encoder folded in (the reference's model only: Composite-Frequency with 3 x 10 position and 2 x 12
+ * direction frequencies, main.cu:35-69; _fused_supported says so): the samples are formed from the packed segments as
+ * rtxn_encode_frequency_segments forms them and encoded straight into the first layer's operands -- bit for bit the values
+ * _forward_lean reads out of encT; t_vals (may be NULL) as rtxn_encode_frequency_segments writes them.  _backward_lean_segments is the
+ * matching backward: its weight gradient recomputes the encoding with the activations, a column tile's segment constants through
+ * the scalar cache.  With the pair no encT exists at all (main.cu:721,781 are tcnn calls that encode and multiply in one):
+ * 3.7 instead of 4.8 KB per sample through device memory, and no encoder launch. */
+int rtxn_mlp_train_forward_lean_fused_supported(const rtxn_mlp* m);
+int rtxn_mlp_train_forward_lean_segments(const rtxn_mlp* m, const float* start_points, const float* end_points, const float* seg_view,
+                                         long n_segments, int sample_type, float t_scale, float* t_vals, void* workspace_lean,
+                                         void* output_half, float* radiance, rtxn_stream_t stream);
+int rtxn_mlp_train_backward_lean_segments(const rtxn_mlp* m, const float* start_points, const float* end_points, const float* seg_view,
+                                          long n_segments, int sample_type, const void* output_half, const void* dout_half4,
+                                          void* workspace_lean, const void* live_ws, float* dparams, rtxn_stream_t stream);
 int rtxn_mlp_train_backward_lean(const rtxn_mlp* m, const void* encT, const void* output_half, const void* dout_half4,
                                  long n_samples, void* workspace_lean, const void* live_ws, float* dparams, rtxn_stream_t stream);
 

@@ -208,6 +208,9 @@ SYMBOLS = {
     "rtxn_mlp_train_lean_workspace_bytes": (C.c_size_t, [_P, _L]),
     "rtxn_mlp_train_forward_lean": (_I, [_P, _P, _L, _P, _P, _P, _P]),
     "rtxn_mlp_train_backward_lean": (_I, [_P, _P, _P, _P, _L, _P, _P, _P, _P]),
+    "rtxn_mlp_train_forward_lean_fused_supported": (_I, [_P]),
+    "rtxn_mlp_train_forward_lean_segments": (_I, [_P, _P, _P, _P, _L, _I, _F, _P, _P, _P, _P, _P]),
+    "rtxn_mlp_train_backward_lean_segments": (_I, [_P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P]),
     "rtxn_train_gradients": (_I, [C.POINTER(TrainBatch), _P]),
     "rtxn_train_step": (_I, [C.POINTER(TrainStepArgs), _P]),
     "rtxn_live_segments_workspace_bytes": (C.c_size_t, [_L]),

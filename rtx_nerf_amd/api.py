@@ -549,6 +549,36 @@ def _net_train_forward_lean(self, encT, n, workspace, output=None, radiance=None
     return output
 
 
+def _net_lean_fused_supported(self):
+    """True where the lean forward can encode for itself (the reference's Composite-Frequency(3 x 10, 2 x 12) model)."""
+    return bool(_lib.lib().rtxn_mlp_train_forward_lean_fused_supported(self._h))
+
+
+def _net_train_forward_lean_segments(self, start_points, end_points, seg_view, n_segments, sample_type, workspace, output, radiance=None,
+                                     t_vals=None, t_scale=1.0):
+    """The lean forward with sampler and encoder folded in (rtxn_mlp_train_forward_lean_segments): encT is not read; t_vals as the
+    standalone encoder writes them."""
+    check(_lib.lib().rtxn_mlp_train_forward_lean_segments(self._h, _ptr(start_points, torch.float32, "start_points"),
+                                                          _ptr(end_points, torch.float32, "end_points"), _ptr(seg_view, torch.float32, "seg_view"),
+                                                          n_segments, sample_type, t_scale, _ptr(t_vals, torch.float32, "t_vals"),
+                                                          _ptr(workspace, torch.float16, "workspace"), _ptr(output, torch.float16),
+                                                          _ptr(radiance, torch.float32, "radiance"), _stream()),
+          "rtxn_mlp_train_forward_lean_segments")
+    return output
+
+
+def _net_train_backward_lean_segments(self, start_points, end_points, seg_view, n_segments, sample_type, output, dout, workspace, dparams,
+                                      live_ws=None):
+    """The lean backward whose weight gradient recomputes the encoding as well (rtxn_mlp_train_backward_lean_segments): no encT."""
+    check(_lib.lib().rtxn_mlp_train_backward_lean_segments(self._h, _ptr(start_points, torch.float32, "start_points"),
+                                                           _ptr(end_points, torch.float32, "end_points"), _ptr(seg_view, torch.float32, "seg_view"),
+                                                           n_segments, sample_type, _ptr(output, torch.float16), _ptr(dout, torch.float16),
+                                                           _ptr(workspace, torch.float16, "workspace"), _ptr(live_ws, None, "live_ws"),
+                                                           _ptr(dparams, torch.float32), _stream()),
+          "rtxn_mlp_train_backward_lean_segments")
+    return dparams
+
+
 def _net_train_backward_lean(self, encT, output, dout, n, workspace, dparams, live_ws=None):
     """network->backward on the lean workspace: dgrad chain + weight gradient with recomputed activations."""
     check(_lib.lib().rtxn_mlp_train_backward_lean(self._h, _ptr(encT, torch.float16, "encT"), _ptr(output, torch.float16, "output"),
@@ -561,6 +591,9 @@ def _net_train_backward_lean(self, encT, output, dout, n, workspace, dparams, li
 Network.lean_supported = _net_lean_supported
 Network.train_lean_workspace = _net_train_lean_workspace
 Network.train_forward_lean = _net_train_forward_lean
+Network.lean_fused_supported = _net_lean_fused_supported
+Network.train_forward_lean_segments = _net_train_forward_lean_segments
+Network.train_backward_lean_segments = _net_train_backward_lean_segments
 Network.train_backward_lean = _net_train_backward_lean
 Network.train_forward_live = _net_train_forward_live
 Network.train_backward_recompute_live = _net_train_backward_recompute_live

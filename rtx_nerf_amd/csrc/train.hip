@@ -139,6 +139,42 @@ __device__ __forceinline__ void sample_dir(const SampleSrc& src, long s, bool ok
     v[1] = ok ? src.seg_view[g + 1] : 0.0f;
   }
 }
+__device__ __forceinline__ void sample_dir_unmasked(const SampleSrc& src, long s, float (&v)[2]) {
+  const float* p = src.in ? src.in + 5 * s + 3 : src.seg_view + (s >> 5) * 2;
+  v[0] = p[0];
+  v[1] = p[1];
+}
+
+// Feature f of the reference's Composite-Frequency(3 dims x 10, 2 dims x 12) encoding in encode_freq_kernel's order
+// (dimension-major, frequency, (sin, cos)), padded to 112 with ones: main.cu:35-69.
+struct FreqFeat { int dim, freq, ph, pad; };
+__host__ __device__ constexpr FreqFeat freq_feat_3_10_2_12(int f) {
+  return f < 60 ? FreqFeat{f / 20, (f % 20) / 2, f & 1, 0} : f < 108 ? FreqFeat{3 + (f - 60) / 24, ((f - 60) % 24) / 2, f & 1, 0} : FreqFeat{0, 0, 0, 1};
+}
+// The encoded sample AS the training kernels' layer-0 B fragments: lane-half h of k-step kk holds the features
+// perm_feature(kk, h, j) = b + 4 h, b a compile-time number -- so per value one select between two dimensions (where b and b + 4
+// straddle one), one between two frequencies, and encode_freq_kernel's own arithmetic (sin_turns, one rounding to fp16): the
+// fragments are bit for bit what the forward reads back out of encT.  x: the sample's (x, y, z, theta, phi); !ok: zeros.
+template <int KS0>
+__device__ __forceinline__ void encode_freq_fragments_3_10_2_12(const float (&x)[5], int h, bool ok, half8 (&dst)[KS0]) {
+  static_assert(KS0 == 7, "112 features");
+#pragma unroll
+  for (int kk = 0; kk < KS0; ++kk) {
+    half8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int b = 16 * kk + 8 * (j >> 2) + (j & 3);
+      const FreqFeat f0 = freq_feat_3_10_2_12(b), f1 = freq_feat_3_10_2_12(b + 4);
+      const float xv = (f1.pad || f0.dim == f1.dim) ? x[f0.dim] : (h ? x[f1.dim] : x[f0.dim]);
+      const int e = f1.pad ? f0.freq : (h ? f1.freq : f0.freq);
+      float y = sin_turns(xv, e, f0.ph);                 // b and b + 4 have the same parity: the same phase
+      if (f1.pad) y = h ? 1.0f : y;
+      v[j] = ok ? (_Float16)y : (_Float16)0.0f;
+    }
+    dst[kk] = v;
+  }
+}
+
 // the sampler's t_vals of sample s (segments only): REGULAR (i + 1)/32; MIDPOINT_WORLD |end - start|/32, times t_scale
 __device__ __forceinline__ float sample_tval(const SampleSrc& src, long s, float t_scale) {
   if (!src.midpoint) return (float)((int)(s & 31) + 1) * (1.0f / 32);
@@ -496,6 +532,9 @@ struct TrainArgs {
   uint8_t* live_tiles;      // [Sp / 256]: backward: 1 where the tile carries a non-zero loss gradient (weight-gradient kernels skip the others)
   const int* live_list;     // segments that carry a loss gradient (rtxn_live_segments), or NULL.  Backward: the chain then visits
   const int* live_count;    // only those, and dz / dzL are written COMPACT (slot * 32 + sample) for the weight-gradient kernels
+  SampleSrc src;            // forward with the encoder fused (ENC = 1): where the samples come from; encT is not read
+  float* t_vals;            //   ... and the sampler's t_vals, if asked for (as rtxn_encode_frequency_segments writes them)
+  float t_scale;
 };
 
 // Element (feature row f0 + 4h, sample s) of a feature-major tensor X[feature][Sp]: the address is split into a wave-uniform
@@ -559,7 +598,10 @@ constexpr int kEncScratch = 6 * 1024;                    // per wave: 48 feature
 // rounds 1-3.  8 (512 samples, ONE block per CU, the weights double-buffered, the next layer's fetched under this layer's MFMAs;
 // 128 wide only): a layer's 32 KiB of A fragments then feed twice the samples -- an experiment (RTXN_TRAIN_FWD_WAVES=8): half the
 // LDS-DMA weight stream per sample bought nothing (train_forward_impl has the A/B), so this kernel is not paced by it.
-template <int W, int SAVE = kSaveAll, int NW = 4>
+// ENC = 1 (lean forward of the reference's model): the Composite-Frequency(3 x 10, 2 x 12) encoding is computed in the kernel, straight
+// into layer 0's fragments (encode_freq_fragments_3_10_2_12): no encT read, no LDS transposition -- and the standalone encoder, whose
+// output only the weight-gradient kernel still needs, can run beside this kernel instead of in front of it.
+template <int W, int SAVE = kSaveAll, int NW = 4, int ENC = 0>
 __global__ __launch_bounds__(64 * NW, 2) void mlp_train_fwd_kernel(TrainArgs a) {
   constexpr int RT = W / 32, KS = W / 16, TILE = 64 * NW;
   constexpr bool DB = NW == 8;                             // double-buffered weights
@@ -630,7 +672,49 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_train_fwd_kernel(TrainArgs a) 
   // picks its fragments out with two-byte LDS reads.  The two 64-byte halves of a row are swapped in rows 4-7 of every eight so
   // that lane-half h = 1 (rows + 4) reads the other half of the banks than h = 0.
   half8 bf[KS][2], bg[KS][2];
-  {
+  if constexpr (ENC == 1) {
+    static_assert(W == 128 && NW == 4, "the fused encoder is built into the four-wave 128-wide forward");
+    constexpr int KSE = 7;
+    stage_w(a.packed, wbuf(0), KSE * RT * 1024);          // layer 0's weights travel while the encoding is computed
+    half8 b[2][KSE];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const long sc = ok_s[ct] ? samp[ct] : 0;
+      float p3[3], v2[2];
+      sample_pos_unmasked(a.src, sc, p3);
+      sample_dir_unmasked(a.src, sc, v2);
+      const float x[5] = {p3[0], p3[1], p3[2], v2[0], v2[1]};
+      encode_freq_fragments_3_10_2_12<KSE>(x, h, ok_s[ct], b[ct]);
+      if (a.t_vals && ok_s[ct] && h == 0) a.t_vals[samp[ct]] = sample_tval(a.src, samp[ct], a.t_scale);
+    }
+    RTXN_FWD_STAMP(26);
+    rtxn::staged_barrier();
+    RTXN_FWD_STAMP(27);
+    const uint8_t* w0 = wbuf(0);
+    floatx16 acc[RT][2];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[rt][ct][e] = 0.0f;
+#pragma unroll
+    for (int kk = 0; kk < KSE; ++kk)                       // k-step outer, as the chunked form: the same sums in the same order
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const half8 af = *reinterpret_cast<const half8*>(w0 + ((rt * KSE + kk) * 64 + lane) * 16);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, b[ct][kk], acc[rt][ct], 0, 0, 0);
+      }
+    RTXN_FWD_STAMP(30);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) bf[2 * rt + s2][ct] = pack8<true>(acc[rt][ct], s2);
+    off += (long)KSE * RT * 1024;
+  } else {
     if (DB) stage_w(a.packed, wbuf(0), layer_bytes(0));
     uint8_t* scratch = smem + (DB ? 2 : 1) * WB + wave * kEncScratch;
     const int r8 = lane >> 3, jg = lane & 7;              // row of a piece; 16-byte sample group of the wave's 64 samples
@@ -642,12 +726,16 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_train_fwd_kernel(TrainArgs a) 
     // a chunk's six loads are issued a chunk ahead -- the first in front of the wait for layer 0's weights -- so that the kernel
     // stands still for ONE memory round trip per tile, not one per chunk plus the weights' (19,000 of the tile's 73,000 cycles)
     auto load_chunk = [&](int c0, rtxn::int4v (&pc)[6]) {
+#ifdef RTXN_FWD_NO_ENC_FETCH      // timing-only (results wrong): what layer 0 costs when its input is free
+      for (int p = 0; p < 6; ++p) pc[p] = rtxn::int4v{0x3c003c00, 0x3c003c00, 0x3c003c00, 0x3c003c00};
+#else
 #pragma unroll
       for (int p = 0; p < 6; ++p)
         // rows past the encoding are clamped, not skipped: their k-steps are never multiplied, and a conditional load here came out
         // of hipcc as six branches with `s_waitcnt vmcnt(0)` behind every single load -- six memory round trips in a row per chunk
         // (6,900 cycles from the block's entry to its first chunk's last load: phase stamps)
         pc[p] = *reinterpret_cast<const rtxn::int4v*>(src + (long)min(c0 + 8 * p, a.E - 8) * a.Sp);
+#endif
     };
     rtxn::int4v piece[6], ahead[6];                      // two chunks in flight, taking turns (no copies: a copy would wait for the load)
     load_chunk(0, piece);
@@ -663,14 +751,22 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_train_fwd_kernel(TrainArgs a) 
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[rt][ct][e] = 0.0f;
     auto chunk = [&](int c0, const rtxn::int4v (&pc)[6]) {
+#ifndef RTXN_FWD_NO_ENC_FETCH
 #pragma unroll
       for (int p = 0; p < 6; ++p) *reinterpret_cast<rtxn::int4v*>(scratch + p * 1024 + wr_off) = pc[p];
+#endif
 #ifdef RTXN_FWD_STAMPS
       if (c0 == 0) RTXN_FWD_STAMP(25);
 #endif
       // all of the chunk's fragment reads first, then its MFMAs: k-step by k-step (reads, wait, permute, multiply) every k-step
       // was two or three LDS round trips in a row with the partner block's layer on the same pipe (1,700-2,000 cycles each: stamps)
       half8 b[3][2];
+#ifdef RTXN_FWD_NO_ENC_FETCH
+#pragma unroll
+      for (int k3 = 0; k3 < 3; ++k3)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) b[k3][ct] = __builtin_bit_cast(half8, pc[(k3 + ct) % 6]);
+#else
 #pragma unroll
       for (int k3 = 0; k3 < 3; ++k3)
 #pragma unroll
@@ -678,6 +774,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_train_fwd_kernel(TrainArgs a) 
 #pragma unroll
           for (int j = 0; j < 8; ++j)
             b[k3][ct][j] = *reinterpret_cast<const _Float16*>(scratch + (perm_feature(k3, 0, j)) * 128 + (rd_off ^ (ct * 64)));
+#endif
 #ifdef RTXN_FWD_STAMPS
       if (c0 == 0) {
         asm volatile("" : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[2][0]), "+v"(b[2][1]));
@@ -1754,6 +1851,7 @@ struct LeanArgs {
   const int* live_list;
   const int* live_count;
   DetCtx det;
+  SampleSrc src;               // ENC passes: the packed segments the encoding is recomputed from (encT is not read)
 };
 
 // (timing-only ablations, results wrong: -DRTXN_LN_NO_WAIT no wait for the dZ stages / weights, -DRTXN_LN_NO_CONTRACT no contraction,
@@ -1810,7 +1908,10 @@ __device__ unsigned long long g_ln_clock[3 * 8];   // per pass, first block: s_m
 
 // L0 <= l < L1: the layers whose gradient this pass accumulates (at most 4); OUT: also the output layer (then L1 == LTOT)
 // sub_block of sub_grid: this block's place among the blocks that run THIS pass (see wgrad_recompute_kernel)
-template <int KS0, int L0, int L1, bool OUT, int LTOT>
+// ENC: the tile's encoded input is COMPUTED (the reference's Composite-Frequency(3 x 10, 2 x 12), encode_freq_fragments_3_10_2_12)
+// from the packed segments instead of fetched: a column tile is one segment, so its start / end / view direction come through the
+// scalar cache and the tile's dZ stages are in flight while the vector ALU encodes.
+template <int KS0, int L0, int L1, bool OUT, int LTOT, bool ENC = false>
 __device__ __forceinline__ void wgrad_recompute_pass(LeanArgs a, const int sub_block, const int sub_grid) {
   constexpr int W = 128, RT = 4, KS = 8, NL = L1 - L0;
   constexpr int FWD_END = OUT ? LTOT : L1 - 1;            // forward layers 0 .. FWD_END-1 are recomputed
@@ -2019,9 +2120,52 @@ __device__ __forceinline__ void wgrad_recompute_pass(LeanArgs a, const int sub_b
     // round trip (phase stamps, profiles/r04/lean_stamps.txt: 5,000-10,000 cycles per tile with the lines coming from HBM), so the
     // previous tile's last step has touched every line once (prefetch_enc below: they come from the L2 now), and the tile's four
     // dZ stages are issued behind the wait, not in front of it, so that it does not wait for them as well.
+    half8 act[2][KS][2];                                // ping-pong: layer l reads act[l & 1], its forward writes act[(l + 1) & 1]
+    if constexpr (ENC) {
+      ln_barrier();                                     // everyone has left the previous tile's last contraction: the ring is free
+      // the two segments' constants through the scalar cache (col0 is wave-uniform): nothing of this enters the vector-memory queue
+      float seg[2][8];
+      const long n_seg = (a.S + 31) >> 5;
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        long g = col0[ct] >> 5;
+        g = g < n_seg ? g : n_seg - 1;                  // tiles past the batch (the last one's padding): any real segment, their dZ is zero
+        const float* ps = a.src.start + 3 * g;
+        const float* pe = a.src.end + 3 * g;
+        const float* pv = a.src.seg_view + 2 * g;
+        unsigned long long s01, e01, v01;
+        unsigned s2, e2;
+        asm volatile("s_nop 4\n\ts_load_dwordx2 %0, %5, 0x0\n\ts_load_dword %1, %5, 0x8\n\ts_load_dwordx2 %2, %6, 0x0\n\ts_load_dword %3, %6, 0x8\n\t"
+                     "s_load_dwordx2 %4, %7, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(s01), "=&s"(s2), "=&s"(e01), "=&s"(e2), "=&s"(v01) : "s"(ps), "s"(pe), "s"(pv) : "memory");
+        seg[ct][0] = __builtin_bit_cast(float, (unsigned)s01);
+        seg[ct][1] = __builtin_bit_cast(float, (unsigned)(s01 >> 32));
+        seg[ct][2] = __builtin_bit_cast(float, s2);
+        seg[ct][3] = __builtin_bit_cast(float, (unsigned)e01);
+        seg[ct][4] = __builtin_bit_cast(float, (unsigned)(e01 >> 32));
+        seg[ct][5] = __builtin_bit_cast(float, e2);
+        seg[ct][6] = __builtin_bit_cast(float, (unsigned)v01);
+        seg[ct][7] = __builtin_bit_cast(float, (unsigned)(v01 >> 32));
+      }
+      // the four dZ stages of the tile's first gradient layer: the whole ring is free, and they travel while the encoding is computed
+#pragma unroll
+      for (int v = 0; v < 4; ++v) issue_stage(v, L0, (long)tile * kTile + 64 * v);
+      const float tpar = ((float)col + (a.src.midpoint ? 0.5f : 0.0f)) * (1.0f / 32);      // as sample_pos: sample i of its segment
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        float x[5];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) x[c] = fmaf(tpar, seg[ct][3 + c] - seg[ct][c], seg[ct][c]);
+        x[3] = seg[ct][6];
+        x[4] = seg[ct][7];
+        half8 frag[KS0];
+        encode_freq_fragments_3_10_2_12<KS0>(x, h, true, frag);
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) act[0][kk][ct] = kk < KS0 ? frag[kk] : half8{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+    } else {
     long Sp_t = a.Sp;
     asm volatile("" : "+s"(Sp_t));
-    half8 act[2][KS][2];                                // ping-pong: layer l reads act[l & 1], its forward writes act[(l + 1) & 1]
     {
       ln_barrier();                                     // everyone has left the previous tile's last contraction: the X images are free
       uint8_t* scratch = smem + kLnOffX + wave * kLnEncScratch;
@@ -2057,6 +2201,7 @@ __device__ __forceinline__ void wgrad_recompute_pass(LeanArgs a, const int sub_b
       // the four dZ stages of the tile's first gradient layer: the whole ring is free
 #pragma unroll
       for (int v = 0; v < 4; ++v) issue_stage(v, L0, (long)tile * kTile + 64 * v);
+    }
     }
     RTXN_LN_STAMP(1);
     // One layer, l a compile-time constant: [forward: nxt = relu(W_l cur)] THEN [weight gradient of layer l from A_{l-1} = cur],
@@ -2193,11 +2338,11 @@ __device__ __forceinline__ void wgrad_recompute_pass(LeanArgs a, const int sub_b
             if constexpr (next_w_same_tile) {
               issue_stage(0, next_w, (long)tile * kTile);
               issue_stage(1, next_w, (long)tile * kTile + 64);
-            } else {
+            } else if constexpr (!ENC) {
               prefetch_enc(look);
             }
           };
-          constexpr int ahead_ops = next_w_same_tile ? 8 : 4;
+          constexpr int ahead_ops = next_w_same_tile ? 8 : (ENC ? 0 : 4);
           if (wave < 2) write_image(ximg + wave * kLnImg, cur);
           ln_wait_vm<8>();                                // stages 0, 1: behind them stages 2, 3
           ln_barrier();                                   // + the images of waves 0, 1; everyone has left the forward
@@ -2283,9 +2428,9 @@ __device__ __forceinline__ void wgrad_recompute_pass(LeanArgs a, const int sub_b
 }
 
 // One pass as a launch of its own (small batches: fewer tiles than CUs).
-template <int KS0, int L0, int L1, bool OUT, int LTOT>
+template <int KS0, int L0, int L1, bool OUT, int LTOT, bool ENC = false>
 __global__ __launch_bounds__(kThreads, 1) void wgrad_recompute_kernel(LeanArgs a) {
-  wgrad_recompute_pass<KS0, L0, L1, OUT, LTOT>(a, (int)blockIdx.x, (int)gridDim.x);
+  wgrad_recompute_pass<KS0, L0, L1, OUT, LTOT, ENC>(a, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // All three passes of the 8-layer model in ONE launch, side by side on disjoint CUs.  Run one after the other they alternate
@@ -2295,12 +2440,12 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_recompute_kernel(LeanArgs a
 // Side by side the chip's memory pipe serves fewer blocks at a time and is not idle while others recompute.
 // Workgroups are dealt round-robin to the 8 XCDs, so block b sits in slot b / 8 of XCD b % 8: slots [0, s1) run layers 0-2,
 // [s1, s2) layers 3-5, the rest 6-7 + output -- every XCD gets the same mix.  gridDim.x is a multiple of 8.
-template <int KS0>
+template <int KS0, bool ENC = false>
 __global__ __launch_bounds__(kThreads, 1) void wgrad_recompute_all_kernel(LeanArgs a, int s1, int s2) {
   const int b = (int)blockIdx.x, slot = b >> 3, xcd = b & 7, slots = (int)gridDim.x >> 3;
-  if (slot < s1) wgrad_recompute_pass<KS0, 0, 3, false, 8>(a, slot * 8 + xcd, s1 * 8);
-  else if (slot < s2) wgrad_recompute_pass<KS0, 3, 6, false, 8>(a, (slot - s1) * 8 + xcd, (s2 - s1) * 8);
-  else wgrad_recompute_pass<KS0, 6, 8, true, 8>(a, (slot - s2) * 8 + xcd, (slots - s2) * 8);
+  if (slot < s1) wgrad_recompute_pass<KS0, 0, 3, false, 8, ENC>(a, slot * 8 + xcd, s1 * 8);
+  else if (slot < s2) wgrad_recompute_pass<KS0, 3, 6, false, 8, ENC>(a, (slot - s1) * 8 + xcd, (s2 - s1) * 8);
+  else wgrad_recompute_pass<KS0, 6, 8, true, 8, ENC>(a, (slot - s2) * 8 + xcd, (slots - s2) * 8);
 }
 
 // ------------------------------------------------------------------------- segments that carry a loss gradient
@@ -2671,9 +2816,11 @@ static hipError_t set_lds_once(const void* fn, int bytes) {
 
 // workspace == NULL: outputs only (the forward half of the recompute path)
 // lean: `workspace` is the lean workspace (rtxn_mlp_train_lean_workspace_bytes): outputs + sign masks, no activations
+// src != NULL (lean only): the encoder fused into the kernel (the reference's Composite-Frequency(3 x 10, 2 x 12)); encT is not read
 static int train_forward_impl(const rtxn_mlp* m, const void* encT, long n_samples, void* workspace, void* output_half,
                               float* radiance, DevCount dc, rtxn_stream_t stream, const int* live_list = nullptr,
-                              const int* live_count = nullptr, bool lean = false) {
+                              const int* live_count = nullptr, bool lean = false, const SampleSrc* src = nullptr, float* t_vals = nullptr,
+                              float t_scale = 1.0f) {
   const int W = m->cfg.n_neurons;
   const long Sp = padded(n_samples);
   // outputs only, 64 wide: the all-asm 16x16x32 kernel with the weights resident in LDS (hashmlp.hip) -- the same layer stack
@@ -2702,12 +2849,17 @@ static int train_forward_impl(const rtxn_mlp* m, const void* encT, long n_sample
   a.radiance = reinterpret_cast<float4*>(radiance);
   a.live_list = live_list;
   a.live_count = live_count;
+  if (src) {
+    a.src = *src;
+    a.t_vals = t_vals;
+    a.t_scale = t_scale;
+  }
   const int RT = W / 32, KS = W / 16, KS0 = a.E / 16;
   // 128 wide, RTXN_TRAIN_FWD_WAVES=8: 8-wave blocks of 512 samples with double-buffered weights.  Built on the guess that the kernel
   // is paced by its weight stream; the same-box A/B says it is not (outputs only 1.050 against 1.068 ms per 4.7 M samples, with the
   // sign masks 1.43 against 1.35: the double buffer's vmcnt(0) also waits for the mask stores), so the 4-wave form stays the default.
   static const bool waves8 = getenv("RTXN_TRAIN_FWD_WAVES") && atoi(getenv("RTXN_TRAIN_FWD_WAVES")) == 8;
-  const int NW = W == 128 && waves8 ? 8 : 4;
+  const int NW = W == 128 && waves8 && !src ? 8 : 4;
   // (RTXN_TRAIN_FWD_ALONE=1, diagnostic: 40 KiB of LDS nobody uses, so that only ONE block fits a CU -- what a block's phases cost
   // without a partner on its SIMDs: profiles/r04/fwd_stamps.txt)
   static const bool alone = getenv("RTXN_TRAIN_FWD_ALONE") && atoi(getenv("RTXN_TRAIN_FWD_ALONE")) == 1;
@@ -2719,7 +2871,10 @@ static int train_forward_impl(const rtxn_mlp* m, const void* encT, long n_sample
     RTXN_HIP(set_lds_once(reinterpret_cast<const void*>(mlp_train_fwd_kernel<WW, SAVE, NWV>), (int)lds));      \
     hipLaunchKernelGGL((mlp_train_fwd_kernel<WW, SAVE, NWV>), grid, block, lds, s, a);                         \
   } while (0)
-  if (W == 64) { if (workspace) RTXN_FWD_LAUNCH(64, kSaveAll, 4); else RTXN_FWD_LAUNCH(64, kSaveNone, 4); }
+  if (src) {
+    RTXN_HIP(set_lds_once(reinterpret_cast<const void*>(mlp_train_fwd_kernel<128, kSaveMasks, 4, 1>), (int)lds));
+    hipLaunchKernelGGL((mlp_train_fwd_kernel<128, kSaveMasks, 4, 1>), grid, block, lds, s, a);
+  } else if (W == 64) { if (workspace) RTXN_FWD_LAUNCH(64, kSaveAll, 4); else RTXN_FWD_LAUNCH(64, kSaveNone, 4); }
   else if (NW == 8) {
     if (lean) RTXN_FWD_LAUNCH(128, kSaveMasks, 8);
     else if (workspace) RTXN_FWD_LAUNCH(128, kSaveAll, 8);
@@ -2859,9 +3014,10 @@ extern "C" size_t rtxn_mlp_train_lean_workspace_bytes(const rtxn_mlp* m, long n_
   return (size_t)((L * W + 16 + 8 * L) * Sp) * sizeof(_Float16) + (size_t)((Sp / kTile + 15) / 16 * 16);
 }
 
+// src != NULL: the weight gradient recomputes the ENCODING too (the reference's Composite-Frequency model); encT is not read
 static int train_backward_lean_impl(const rtxn_mlp* m, const void* encT, const void* output_half, const void* dout_half4,
                                     long n_samples, void* workspace, float* dparams, DevCount dc, rtxn_stream_t stream,
-                                    const int* live_list = nullptr, const int* live_count = nullptr) {
+                                    const int* live_list = nullptr, const int* live_count = nullptr, const SampleSrc* src = nullptr) {
   const int W = 128, L = m->cfg.n_hidden_layers, E = m->enc_padded;
   const long Sp = padded(n_samples);
   _Float16* ws = static_cast<_Float16*>(workspace);
@@ -2905,6 +3061,7 @@ static int train_backward_lean_impl(const rtxn_mlp* m, const void* encT, const v
   la.live_list = live_list;
   la.live_count = live_count;
   la.det = det_ctx(dparams, g_det_mlp);
+  if (src) la.src = *src;
   int dev = 0, n_cu = 0;
   RTXN_HIP(hipGetDevice(&dev));
   RTXN_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
@@ -2916,8 +3073,11 @@ static int train_backward_lean_impl(const rtxn_mlp* m, const void* encT, const v
   // round 4 -- hipcc spilled accumulator tiles to scratch around the tile loop's back edge -- and gone since the output layer's
   // gradient lives in AGPRs too.)
   constexpr int n_pass = 3;
-  static const lean_fn pass[3] = {wgrad_recompute_kernel<7, 0, 3, false, 8>, wgrad_recompute_kernel<7, 3, 6, false, 8>,
-                                  wgrad_recompute_kernel<7, 6, 8, true, 8>};
+  static const lean_fn pass_enc[2][3] = {{wgrad_recompute_kernel<7, 0, 3, false, 8>, wgrad_recompute_kernel<7, 3, 6, false, 8>,
+                                          wgrad_recompute_kernel<7, 6, 8, true, 8>},
+                                         {wgrad_recompute_kernel<7, 0, 3, false, 8, true>, wgrad_recompute_kernel<7, 3, 6, false, 8, true>,
+                                          wgrad_recompute_kernel<7, 6, 8, true, 8, true>}};
+  const lean_fn* pass = pass_enc[src ? 1 : 0];
   // large batches: the three passes side by side in one launch (wgrad_recompute_all_kernel); the CU split follows the passes'
   // measured cost (RTXN_LEAN_SPLIT="s1,s2" of 32 slots per XCD for experiments; RTXN_LEAN_SPLIT=0: one launch per pass)
   int split[2] = {9, 20};
@@ -2926,8 +3086,13 @@ static int train_backward_lean_impl(const rtxn_mlp* m, const void* encT, const v
   }
   const int slots = n_cu / 8;
   if (split[0] > 0 && split[0] < split[1] && split[1] < slots && la.n_tiles >= 4 * n_cu) {
-    RTXN_HIP(set_lds_once(reinterpret_cast<const void*>(wgrad_recompute_all_kernel<7>), kLnLdsLaunch));
-    hipLaunchKernelGGL(wgrad_recompute_all_kernel<7>, dim3((unsigned)(slots * 8)), dim3(kThreads), kLnLdsLaunch, s, la, split[0] * slots / 32, split[1] * slots / 32);
+    if (src) {
+      RTXN_HIP(set_lds_once(reinterpret_cast<const void*>(wgrad_recompute_all_kernel<7, true>), kLnLdsLaunch));
+      hipLaunchKernelGGL((wgrad_recompute_all_kernel<7, true>), dim3((unsigned)(slots * 8)), dim3(kThreads), kLnLdsLaunch, s, la, split[0] * slots / 32, split[1] * slots / 32);
+    } else {
+      RTXN_HIP(set_lds_once(reinterpret_cast<const void*>(wgrad_recompute_all_kernel<7>), kLnLdsLaunch));
+      hipLaunchKernelGGL(wgrad_recompute_all_kernel<7>, dim3((unsigned)(slots * 8)), dim3(kThreads), kLnLdsLaunch, s, la, split[0] * slots / 32, split[1] * slots / 32);
+    }
     RTXN_LAUNCH_CHECK("wgrad_recompute_all_kernel");
     return det_fold(la.det.q, m->n_params, dparams, nullptr, 0, s);
   }
@@ -2963,6 +3128,32 @@ extern "C" int rtxn_mlp_train_forward_lean(const rtxn_mlp* m, const void* encT, 
   return train_forward_impl(m, encT, n_samples, workspace_lean, output_half, radiance, DevCount{nullptr, 0}, stream, nullptr, nullptr, true);
 }
 
+extern "C" int rtxn_mlp_train_forward_lean_fused_supported(const rtxn_mlp* m) {
+  return m && rtxn_mlp_train_lean_supported(m) && m->cfg.encoding == RTXN_ENC_FREQUENCY && m->cfg.n_pos_dims == 3 && m->cfg.n_pos_freqs == 10 &&
+         m->cfg.n_dir_dims == 2 && m->cfg.n_dir_freqs == 12;
+}
+
+extern "C" int rtxn_mlp_train_forward_lean_segments(const rtxn_mlp* m, const float* start_points, const float* end_points,
+                                                    const float* seg_view, long n_segments, int sample_type, float t_scale, float* t_vals,
+                                                    void* workspace_lean, void* output_half, float* radiance, rtxn_stream_t stream) {
+  int rc = check_lean(m, "rtxn_mlp_train_forward_lean_segments", n_segments * 32, true);
+  if (rc != RTXN_OK) return rc;
+  if (!rtxn_mlp_train_forward_lean_fused_supported(m)) {
+    rtxn::set_error("rtxn_mlp_train_forward_lean_segments: the fused encoder is the reference's Composite-Frequency(3 x 10, 2 x 12); this model: "
+                    "%d x %d, %d x %d -- use rtxn_encode_frequency_segments + rtxn_mlp_train_forward_lean", m->cfg.n_pos_dims, m->cfg.n_pos_freqs,
+                    m->cfg.n_dir_dims, m->cfg.n_dir_freqs);
+    return RTXN_ERR_UNSUPPORTED;
+  }
+  rc = check_segments("rtxn_mlp_train_forward_lean_segments", start_points, end_points, seg_view, n_segments, sample_type);
+  if (rc != RTXN_OK) return rc;
+  RTXN_DEVICE_OR_FAIL();
+  if (n_segments == 0) return RTXN_OK;
+  RTXN_REQUIRE(workspace_lean && output_half, "rtxn_mlp_train_forward_lean_segments: NULL buffer");
+  const SampleSrc src{nullptr, start_points, end_points, seg_view, sample_type == RTXN_SAMPLING_MIDPOINT_WORLD};
+  return train_forward_impl(m, nullptr, n_segments * 32, workspace_lean, output_half, radiance, DevCount{nullptr, 0}, stream, nullptr, nullptr, true, &src,
+                            t_vals, t_scale);
+}
+
 #ifdef RTXN_LN_STAMPS
 // diagnostic builds only: the stamps of the last lean weight-gradient launch (3 passes x 4 waves x 2 tiles x 92 slots)
 extern "C" int rtxn_debug_read_lean_stamps(unsigned* dst) {
@@ -2983,6 +3174,27 @@ extern "C" int rtxn_mlp_train_backward_lean(const rtxn_mlp* m, const void* encT,
   RTXN_REQUIRE(encT && output_half && dout_half4 && workspace_lean && dparams, "rtxn_mlp_train_backward_lean: NULL buffer");
   return train_backward_lean_impl(m, encT, output_half, dout_half4, n_samples, workspace_lean, dparams, DevCount{nullptr, 0}, stream,
                                   live_ws ? live_list_of(live_ws) : nullptr, live_ws ? live_count_of(live_ws) : nullptr);
+}
+
+extern "C" int rtxn_mlp_train_backward_lean_segments(const rtxn_mlp* m, const float* start_points, const float* end_points,
+                                                     const float* seg_view, long n_segments, int sample_type, const void* output_half,
+                                                     const void* dout_half4, void* workspace_lean, const void* live_ws, float* dparams,
+                                                     rtxn_stream_t stream) {
+  int rc = check_lean(m, "rtxn_mlp_train_backward_lean_segments", n_segments * 32, true);
+  if (rc != RTXN_OK) return rc;
+  if (!rtxn_mlp_train_forward_lean_fused_supported(m)) {
+    rtxn::set_error("rtxn_mlp_train_backward_lean_segments: the fused encoder is the reference's Composite-Frequency(3 x 10, 2 x 12); use "
+                    "rtxn_mlp_train_backward_lean with encT");
+    return RTXN_ERR_UNSUPPORTED;
+  }
+  rc = check_segments("rtxn_mlp_train_backward_lean_segments", start_points, end_points, seg_view, n_segments, sample_type);
+  if (rc != RTXN_OK) return rc;
+  RTXN_DEVICE_OR_FAIL();
+  if (n_segments == 0) return RTXN_OK;
+  RTXN_REQUIRE(output_half && dout_half4 && workspace_lean && dparams, "rtxn_mlp_train_backward_lean_segments: NULL buffer");
+  const SampleSrc src{nullptr, start_points, end_points, seg_view, sample_type == RTXN_SAMPLING_MIDPOINT_WORLD};
+  return train_backward_lean_impl(m, nullptr, output_half, dout_half4, n_segments * 32, workspace_lean, dparams, DevCount{nullptr, 0}, stream,
+                                  live_ws ? live_list_of(live_ws) : nullptr, live_ws ? live_count_of(live_ws) : nullptr, &src);
 }
 
 // ---- recompute path (64-wide models): forward without saved activations + fused backward ----
@@ -3658,15 +3870,23 @@ extern "C" int rtxn_train_gradients(const rtxn_train_batch* b, rtxn_stream_t str
   const DevCount dc{b->total_segments, (int)b->segment_capacity};
   const long cap_samples = b->segment_capacity * 32;
   const SampleSrc src{nullptr, b->start_points, b->end_points, b->seg_view, b->sample_type == RTXN_SAMPLING_MIDPOINT_WORLD};
+  // The reference's own model on the lean path: sampler AND encoder folded into the forward and into the weight gradient (encT is
+  // never written; RTXN_TRAIN_LEAN_FUSED=0: the staged encoder, for the A/B -- the same values bit for bit)
+  const char* fused_env = getenv("RTXN_TRAIN_LEAN_FUSED");       // (read per call: a test switches it between trainers)
+  const bool fused_off = fused_env && atoi(fused_env) == 0;
+  const bool fused = lean && !fused_off && rtxn_mlp_train_forward_lean_fused_supported(m);
   // launchSampler + encoding (main.cu:703,721)
-  rc = hash ? hashgrid_encode_impl(b->grid, b->n_dir_freqs, b->table_fp16, src, b->encT, b->t_vals, b->t_scale, cap_samples, dc, stream)
-            : encode_frequency_impl(m, src, b->encT, b->t_vals, b->t_scale, cap_samples, dc, stream);
-  if (rc != RTXN_OK) return rc;
+  if (!fused) {
+    rc = hash ? hashgrid_encode_impl(b->grid, b->n_dir_freqs, b->table_fp16, src, b->encT, b->t_vals, b->t_scale, cap_samples, dc, stream)
+              : encode_frequency_impl(m, src, b->encT, b->t_vals, b->t_scale, cap_samples, dc, stream);
+    if (rc != RTXN_OK) return rc;
+  }
   // network->forward (main.cu:721).  Saved-activation models with a live list and the NeRF compositor (whose gradient vanishes
   // behind the first surface): outputs only here, the activations of the live segments are saved after the compositor.
   // (lean: the forward saves 16 bytes of sign masks per sample and layer for EVERY sample -- cheap enough that no second pass is needed)
   const bool two_pass = !recompute && !lean && b->live_ws != nullptr && b->vr_mode == RTXN_VR_NERF;
-  rc = train_forward_impl(m, b->encT, cap_samples, two_pass ? nullptr : b->workspace, b->output_half, b->radiance, dc, stream, nullptr, nullptr, lean);
+  rc = fused ? train_forward_impl(m, nullptr, cap_samples, b->workspace, b->output_half, b->radiance, dc, stream, nullptr, nullptr, true, &src, b->t_vals, b->t_scale)
+             : train_forward_impl(m, b->encT, cap_samples, two_pass ? nullptr : b->workspace, b->output_half, b->radiance, dc, stream, nullptr, nullptr, lean);
   if (rc != RTXN_OK) return rc;
   // launch_volrender_cuda, loss->evaluate, launch_volrender_backward_cuda (main.cu:737-767): per ray, no sample count needed
   if (b->vr_mode == RTXN_VR_NERF) {
@@ -3695,7 +3915,8 @@ extern "C" int rtxn_train_gradients(const rtxn_train_batch* b, rtxn_stream_t str
     rc = train_forward_impl(m, b->encT, cap_samples, b->workspace, nullptr, nullptr, dc, stream, ll, lc);
     if (rc != RTXN_OK) return rc;
   }
-  rc = lean      ? train_backward_lean_impl(m, b->encT, b->output_half, b->radiance_gradients, cap_samples, b->workspace, b->dparams, dc, stream, ll, lc)
+  rc = lean      ? train_backward_lean_impl(m, b->encT, b->output_half, b->radiance_gradients, cap_samples, b->workspace, b->dparams, dc, stream, ll, lc,
+                                            fused ? &src : nullptr)
      : recompute ? train_backward_recompute_impl(m, b->encT, b->output_half, b->radiance_gradients, cap_samples, b->dparams, b->dencT, dc, stream, ll, lc)
                  : train_backward_impl(m, b->encT, b->output_half, b->radiance_gradients, cap_samples, b->workspace, b->dparams,
                                        hash ? b->dencT : nullptr, dc, stream, ll, lc);

@@ -131,6 +131,11 @@ class Trainer:
         # encoding: 5.1 instead of 8.8 KB moved per sample and half the workspace.  RTXN_TRAIN_LEAN=0: the saved-activation path (A/B).
         self.lean = (not self.recompute and encoding != "hash" and self.net.lean_supported()
                      and os.environ.get("RTXN_TRAIN_LEAN", "1") != "0")
+        # ... and with the reference's Composite-Frequency(3 x 10, 2 x 12) encoding the sampler and the encoder are folded into both lean
+        # kernels (rtxn_mlp_train_forward_lean_segments / _backward_lean_segments): no encoder launch, encT never written -- the same
+        # values bit for bit.  RTXN_TRAIN_LEAN_FUSED=0: the staged encoder (A/B; librtxn's one-call step reads the same switch).
+        self.lean_fused = (self.lean and self.fold_sampler and self.net.lean_fused_supported()
+                           and os.environ.get("RTXN_TRAIN_LEAN_FUSED", "1") != "0")
         self.two_pass = (not self.recompute and not self.lean and self.live_segments and mode == "nerf"
                          and os.environ.get("RTXN_TRAIN_TWO_PASS", "1") != "0")
         # ---- per-step buffers at capacity ---------------------------------------------------------
@@ -232,6 +237,13 @@ class Trainer:
         two-pass step)."""
         P = S // api.NUM_SAMPLES_PER_SEGMENT
         t_scale = self.density_scale if self.mode == "nerf" else 1.0
+        if self.lean_fused and not from_samples and save:
+            with _Stage(self, "mlp_fwd"):       # sampler + encoder + forward: one kernel, t_vals beside the outputs
+                self.net.train_forward_lean_segments(self.start, self.end, self.seg_view, P, self._stype(), self.ws, self.out, self.radiance,
+                                                     t_vals=self.t_vals, t_scale=t_scale)
+            self._fused_batch = True
+            return
+        self._fused_batch = False
         with _Stage(self, "encode"):
             if self.fold_sampler and not from_samples:      # sampler + encoder in one pass over the segments; writes t_vals too
                 if self.encoding == "hash":
@@ -343,7 +355,10 @@ class Trainer:
             with _Stage(self, "mlp_fwd_live"):       # the activations of the segments the backward is about to visit
                 self.net.train_forward_live(self.encT, S, self.ws, self.live_ws)
         with _Stage(self, "mlp_bwd+wgrad"):
-            if self.lean:
+            if self.lean and getattr(self, "_fused_batch", False):
+                self.net.train_backward_lean_segments(self.start, self.end, self.seg_view, P, self._stype(), self.out, self.dout, self.ws,
+                                                      self.dparams, live_ws=self.live_ws if self.live_segments else None)
+            elif self.lean:
                 self.net.train_backward_lean(self.encT, self.out, self.dout, S, self.ws, self.dparams,
                                              live_ws=self.live_ws if self.live_segments else None)
             elif self.live_segments and self.recompute:

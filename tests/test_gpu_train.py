@@ -902,3 +902,89 @@ def test_lean_path_is_refused_for_other_models(gpu):
     encT = torch.zeros((48, 1024), dtype=torch.float16, device="cuda")
     with pytest.raises(_lib.RtxnError, match="lean path"):
         net.train_forward_lean(encT, 1000, torch.zeros(16, dtype=torch.float16, device="cuda"))
+
+
+@pytest.mark.parametrize("P,stype", [(1, 0), (7, 3), (8, 0), (9, 3), (300, 0), (5000, 3)])   # 0: REGULAR, 3: MIDPOINT_WORLD
+def test_lean_forward_with_the_encoder_folded_in_equals_the_staged_pair(gpu, P, stype):
+    """rtxn_mlp_train_forward_lean_segments (round 4: sampler + Composite-Frequency(3 x 10, 2 x 12) encoder inside the forward kernel,
+    straight into layer 0's operands) against rtxn_encode_frequency_segments + rtxn_mlp_train_forward_lean on the same packed
+    segments: outputs, radiance and the sign masks BIT FOR BIT (the same sin_turns arithmetic, one rounding to fp16, the same sums in
+    the same order), for both deterministic sample types, ragged tiles included; a model with another encoding is refused."""
+    torch = gpu
+    from rtx_nerf_amd import api
+    rng = np.random.default_rng(100 + P)
+    W, L = 128, 8
+    net = api.Network(n_neurons=W, n_hidden_layers=L)
+    assert net.encoded_width() == 112 and net.lean_supported() and net.lean_fused_supported()
+    net.set_params(_dev(torch, scenes.xavier_params_fp16(W, L, 112, seed=5)))
+    start = _dev(torch, rng.uniform(-1, 1, (P, 3)).astype(np.float32))
+    end = _dev(torch, (start.cpu().numpy() + rng.uniform(-0.2, 0.2, (P, 3))).astype(np.float32))
+    view = _dev(torch, rng.uniform(0, 3.0, (P, 2)).astype(np.float32))
+    n = P * 32
+    Sp = api.padded_samples(n)
+    encT = torch.full((112, Sp), 9.0, dtype=torch.float16, device="cuda")
+    net.encode_frequency_segments(start, end, view, P, stype, encT)
+    wa, wb = net.train_lean_workspace(n), net.train_lean_workspace(n)
+    wa.zero_(); wb.zero_()
+    oa = torch.zeros((n, 16), dtype=torch.float16, device="cuda")
+    ob = torch.zeros((n, 16), dtype=torch.float16, device="cuda")
+    ra = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+    rb = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+    net.train_forward_lean(encT, n, wa, oa, ra)
+    net.train_forward_lean_segments(start, end, view, P, stype, wb, ob, rb)
+    torch.cuda.synchronize()
+    assert torch.equal(oa[:, :4], ob[:, :4]) and torch.equal(ra, rb)
+    lo = (L * W + 16) * Sp                                  # the masks: u64[L][Sp][2] behind dZ and dZ_L
+    ma, mb = wa[lo:lo + 8 * L * Sp].view(torch.int16), wb[lo:lo + 8 * L * Sp].view(torch.int16)     # bit patterns, not halves (NaNs)
+    assert torch.equal(ma, mb) and bool((ma != 0).any())
+    other = api.Network(n_neurons=W, n_hidden_layers=L, n_encoded_features=112)
+    assert other.lean_supported() and not other.lean_fused_supported()
+    with pytest.raises(api._lib.RtxnError):
+        other.train_forward_lean_segments(start, end, view, P, stype, wb, ob)
+
+
+@pytest.mark.parametrize("P,stype,live", [(9, 0, False), (300, 3, False), (2500, 0, True), (9000, 3, False), (9000, 0, True)])
+def test_lean_backward_recomputing_the_encoding_equals_the_one_reading_it(gpu, P, stype, live):
+    """rtxn_mlp_train_backward_lean_segments (the weight gradient recomputes the ENCODING with the activations: a column tile's
+    segment constants through the scalar cache, encode_freq_fragments_3_10_2_12) against rtxn_mlp_train_backward_lean on the encT
+    the standalone encoder wrote for the same segments: the same operands bit for bit, so the gradients agree to the order of the fp32
+    atomic adds (2e-5 of the norm).  One launch per pass (small batches) and the three passes side by side (9,000 segments); with
+    spans of zero loss gradient and the live list."""
+    torch = gpu
+    from rtx_nerf_amd import api
+    rng = np.random.default_rng(300 + P)
+    W, L = 128, 8
+    net = api.Network(n_neurons=W, n_hidden_layers=L)
+    net.set_params(_dev(torch, scenes.xavier_params_fp16(W, L, 112, seed=6)))
+    start = _dev(torch, rng.uniform(-1, 1, (P, 3)).astype(np.float32))
+    end = _dev(torch, (start.cpu().numpy() + rng.uniform(-0.2, 0.2, (P, 3))).astype(np.float32))
+    view = _dev(torch, rng.uniform(0, 3.0, (P, 2)).astype(np.float32))
+    n = P * 32
+    Sp = api.padded_samples(n)
+    encT = torch.zeros((112, Sp), dtype=torch.float16, device="cuda")
+    net.encode_frequency_segments(start, end, view, P, stype, encT)
+    dout = (rng.standard_normal((n, 4)) * 0.05).astype(np.float16)
+    lws = None
+    if live:
+        seg_dead = rng.random(P) < 0.6
+        dout.reshape(P, 32, 4)[seg_dead] = 0
+        lws = api.live_segments_workspace(P)
+    dout_d = _dev(torch, dout)
+    if live:
+        api.live_segments(dout_d, P, P, lws)
+    res = []
+    for fused in (False, True):
+        ws = net.train_lean_workspace(n)
+        out = torch.zeros((n, 16), dtype=torch.float16, device="cuda")
+        dp = torch.zeros(net.n_params(), dtype=torch.float32, device="cuda")
+        if fused:
+            net.train_forward_lean_segments(start, end, view, P, stype, ws, out)
+            net.train_backward_lean_segments(start, end, view, P, stype, out, dout_d, ws, dp, live_ws=lws)
+        else:
+            net.train_forward_lean(encT, n, ws, out)
+            net.train_backward_lean(encT, out, dout_d, n, ws, dp, live_ws=lws)
+        torch.cuda.synchronize()
+        res.append(dp.double().cpu().numpy())
+    a, b = res
+    assert np.isfinite(b).all() and np.linalg.norm(a) > 0
+    assert np.linalg.norm(a - b) <= 2e-5 * np.linalg.norm(a) and np.abs(a - b).max() <= 1e-4 * np.abs(a).max()

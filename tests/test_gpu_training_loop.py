@@ -561,3 +561,57 @@ def test_deterministic_captured_step_and_checkpoint_resume(gpu, tmp_path):
     torch.cuda.synchronize()
     for k, (x, y) in enumerate(zip(_state(full), _state(resumed))):
         assert torch.equal(x, y), f"resumed vs uninterrupted: tensor {k}"
+
+
+def _reference_model_trainer(torch, **kw):
+    """The reference's own model (8 x 128, Composite-Frequency(3 x 10, 2 x 12): 112 encoded features) on a small scene"""
+    import numpy as np
+    from rtx_nerf_amd import scenes
+    from rtx_nerf_amd.train import Trainer
+    R, B = 16, 900
+    occ = torch.from_numpy(scenes.pack_occupancy(scenes.sphere_density(R, 0.75)).view(np.int32).copy()).cuda()
+    return Trainer(R, occ, encoding="freq", n_neurons=128, n_hidden_layers=8, n_dir_freqs=12, batch_rays=B, max_segments=B * 30, lr=1e-3,
+                   loss_scale=128.0, mode="compat", seed=3, **kw)
+
+
+def test_reference_model_fused_staged_and_saved_paths_agree(gpu, monkeypatch):
+    """The reference's 8 x 128 model through the Trainer, three eager steps of its own iteration (compat compositor) on the same
+    batches: (a) lean with sampler + encoder folded into the forward and the weight gradient (default), (b) lean with the staged
+    encoder (RTXN_TRAIN_LEAN_FUSED=0), (c) saved activations (RTXN_TRAIN_LEAN=0), (d) one C call per step (rtxn_train_step, which
+    folds the encoder in too).  In deterministic mode (a) and (b) are BIT-IDENTICAL -- the folded encoder produces the staged one's
+    operands bit for bit and the gradient sums are order-free -- and (d) matches to the device-side beta^t of its Adam; the saved
+    path differs by the rounding points of its weight-gradient sums."""
+    torch = gpu
+    batches = _det_batches(torch, n=3)
+    B = batches[0][0].shape[0]
+
+    def run(env, entry=False):
+        for k in ("RTXN_TRAIN_LEAN_FUSED", "RTXN_TRAIN_LEAN"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        tr = _reference_model_trainer(torch, deterministic=True)
+        if entry:
+            tr.entry_args(B, launch_segments=B * 30)
+        for o, d, t in batches:
+            if entry:
+                tr.graph_rays_o.copy_(o); tr.graph_rays_d.copy_(d); tr.graph_targets.copy_(t)
+                tr.step_entry()
+            else:
+                tr.step(o, d, t)
+        torch.cuda.synchronize()
+        return tr
+
+    fused = run({})
+    staged = run({"RTXN_TRAIN_LEAN_FUSED": "0"})
+    saved = run({"RTXN_TRAIN_LEAN": "0"})
+    entry = run({}, entry=True)
+    assert fused.lean and fused.lean_fused and staged.lean and not staged.lean_fused and not saved.lean and entry.lean_fused
+    assert int(fused.total.item()) * 32 > 50_000
+    moved = float((fused.master - _reference_model_trainer(torch).master).abs().max())
+    assert moved > 1e-3
+    for k, (x, y) in enumerate(zip(_state(fused), _state(staged))):
+        assert torch.equal(x, y), f"folded vs staged encoder: tensor {k}: {int((x != y).sum())} of {x.numel()} differ"
+    rel = lambda x, y: float((x.float() - y.float()).norm()) / float(x.float().norm())
+    assert rel(fused.master, entry.master) <= 1e-5 and rel(fused.master, saved.master) <= 1e-4
+    assert torch.equal(fused.t_vals[:1000], staged.t_vals[:1000])
