@@ -32,10 +32,11 @@ KERNELS = {
     "mlp_bwd_fused64_4_3": ("mlp_bwd_fused64_kernel<4, 3>", ["mlp_bwd_fused64_kernelILi4ELi3E"]),
     "volrender_l2_fused_multi": ("volrender_l2_fused_multi_kernel<4>", ["volrender_l2_fused_multi_kernelILi4E"]),
     "volrender_fwd_pair_nerf_compact": ("volrender_fwd_pair_kernel<1, true>", ["volrender_fwd_pair_kernelILi1ELb1E"]),
-    "mlp_train_fwd_128_save": ("mlp_train_fwd_kernel<128, 1, 4>", ["mlp_train_fwd_kernelILi128ELi1ELi4E"]),
-    "mlp_train_fwd_128_out": ("mlp_train_fwd_kernel<128, 0, 4>", ["mlp_train_fwd_kernelILi128ELi0ELi4E"]),
-    "mlp_train_fwd_128_masks": ("mlp_train_fwd_kernel<128, 2, 4>", ["mlp_train_fwd_kernelILi128ELi2ELi4E"]),
-    "wgrad_recompute_all": ("wgrad_recompute_all_kernel<7>", ["wgrad_recompute_all_kernelILi7E"]),
+    "mlp_train_fwd_128_save": ("mlp_train_fwd_kernel<128, 1, 4, 0>", ["mlp_train_fwd_kernelILi128ELi1ELi4ELi0E"]),
+    "mlp_train_fwd_128_out": ("mlp_train_fwd_kernel<128, 0, 4, 0>", ["mlp_train_fwd_kernelILi128ELi0ELi4ELi0E"]),
+    # the lean pair as the trainer runs it for the reference's model: sampler + encoder folded in (ENC = 1 / true)
+    "mlp_train_fwd_128_masks": ("mlp_train_fwd_kernel<128, 2, 4, 1>", ["mlp_train_fwd_kernelILi128ELi2ELi4ELi1E"]),
+    "wgrad_recompute_all": ("wgrad_recompute_all_kernel<7, true>", ["wgrad_recompute_all_kernelILi7ELb1E"]),
     "wgrad_recompute_0_3": ("wgrad_recompute_kernel<7, 0, 3, false, 8>", ["wgrad_recompute_kernelILi7ELi0ELi3ELb0ELi8E"]),
     "wgrad_recompute_3_6": ("wgrad_recompute_kernel<7, 3, 6, false, 8>", ["wgrad_recompute_kernelILi7ELi3ELi6ELb0ELi8E"]),
     "wgrad_recompute_6_8": ("wgrad_recompute_kernel<7, 6, 8, true, 8>", ["wgrad_recompute_kernelILi7ELi6ELi8ELb1ELi8E"]),

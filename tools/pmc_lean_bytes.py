@@ -11,8 +11,8 @@ from collections import defaultdict
 
 fetch, write = sys.argv[1], sys.argv[2]
 S = float(sys.argv[3]) if len(sys.argv) > 3 else 4_695_827.0
-KERN = {"forward (outputs + sign masks)": "mlp_train_fwd_kernel<128, 2,", "dgrad chain": "mlp_bwd_kernel<128>",
-        "weight gradient, recomputed activations": "wgrad_recompute_all_kernel<7>",
+KERN = {"forward (outputs + sign masks)": "mlp_train_fwd_kernel<128, 2, 4, 1>", "dgrad chain": "mlp_bwd_kernel<128>",
+        "weight gradient, recomputed activations": "wgrad_recompute_all_kernel<7, true>",
         "forward (saved activations)": "mlp_train_fwd_kernel<128, 1,", "weight gradient (saved activations)": "wgrad_lds_kernel"}
 
 
