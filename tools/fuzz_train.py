@@ -113,5 +113,48 @@ for it in range(n_lean):
     if errs:
         bad += 1
         print(f"MISMATCH lean it={it} act={act} n={n}: {errs}", flush=True)
-print(f"fuzz_train: {a.iters} + {n_lean} lean cases, {bad} mismatches")
+# ... and the same path with sampler + encoder folded into both kernels (rtxn_mlp_train_forward_lean_segments / _backward_lean_segments)
+# against the staged encoder + encT kernels on random segments: outputs and t_vals bit for bit, gradients to the order of the atomics
+n_fused = max(a.iters // 6, 3)
+for it in range(n_fused):
+    P = int(rng.choice([1, 7, 9, 63, int(rng.integers(1, 400)), int(rng.integers(8200, 9000))]))
+    stype = int(rng.choice([0, 3]))
+    net = api.Network(n_neurons=128, n_hidden_layers=8, output_activation=int(rng.integers(0, 2)))
+    net.set_params(dev(scenes.xavier_params_fp16(128, 8, 112, seed=2000 + it)))
+    start = rng.uniform(-1, 1, (P, 3)).astype(np.float32)
+    end = (start + rng.uniform(-0.3, 0.3, (P, 3))).astype(np.float32)
+    view = rng.uniform(0, 3.1, (P, 2)).astype(np.float32)
+    n, Sp = P * 32, api.padded_samples(P * 32)
+    sd, ed, vd = dev(start), dev(end), dev(view)
+    encT = torch.zeros((112, Sp), dtype=torch.float16, device="cuda")
+    tv_a, tv_b = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    net.encode_frequency_segments(sd, ed, vd, P, stype, encT, tv_a, 1.7)
+    dout = (rng.standard_normal((n, 4)) * 0.05).astype(np.float16)
+    dout.reshape(P, 32, 4)[rng.random(P) < 0.3] = 0
+    dd = dev(dout)
+    got = []
+    for fused in (False, True):
+        ws = net.train_lean_workspace(n)
+        out = torch.zeros((n, 16), dtype=torch.float16, device="cuda")
+        dp = torch.zeros(net.n_params(), device="cuda")
+        if fused:
+            net.train_forward_lean_segments(sd, ed, vd, P, stype, ws, out, t_vals=tv_b, t_scale=1.7)
+            net.train_backward_lean_segments(sd, ed, vd, P, stype, out, dd, ws, dp)
+        else:
+            net.train_forward_lean(encT, n, ws, out)
+            net.train_backward_lean(encT, out, dd, n, ws, dp)
+        torch.cuda.synchronize()
+        got.append((out[:, :4].clone(), dp.double().cpu().numpy()))
+    errs = []
+    if not torch.equal(got[0][0], got[1][0]):
+        errs.append("outputs differ")
+    if not torch.equal(tv_a, tv_b):
+        errs.append("t_vals differ")
+    ga, gb = got[0][1], got[1][1]
+    if np.linalg.norm(ga) > 0 and not np.linalg.norm(ga - gb) <= 2e-5 * np.linalg.norm(ga):
+        errs.append(f"weight gradient: {np.linalg.norm(ga - gb) / np.linalg.norm(ga):.3g} of the norm")
+    if errs:
+        bad += 1
+        print(f"MISMATCH folded it={it} P={P} sample_type={stype}: {errs}", flush=True)
+print(f"fuzz_train: {a.iters} + {n_lean} lean + {n_fused} folded-encoder cases, {bad} mismatches")
 sys.exit(1 if bad else 0)
