@@ -3080,7 +3080,7 @@ static int train_backward_lean_impl(const rtxn_mlp* m, const void* encT, const v
   const lean_fn* pass = pass_enc[src ? 1 : 0];
   // large batches: the three passes side by side in one launch (wgrad_recompute_all_kernel); the CU split follows the passes'
   // measured cost (RTXN_LEAN_SPLIT="s1,s2" of 32 slots per XCD for experiments; RTXN_LEAN_SPLIT=0: one launch per pass)
-  int split[2] = {9, 20};
+  int split[2] = {src ? 8 : 9, src ? 19 : 20};   // 9:11:12 reading encT, 8:11:13 with the encoder folded in (tools/probe/lean_split.py, same-process sweeps)
   if (const char* e = getenv("RTXN_LEAN_SPLIT")) {
     if (sscanf(e, "%d,%d", &split[0], &split[1]) != 2) split[0] = split[1] = 0;
   }

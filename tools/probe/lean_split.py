@@ -21,14 +21,26 @@ out = torch.empty((S, 16), dtype=torch.float16, device="cuda")
 dout = ((torch.rand((S, 4), device="cuda", generator=g) - 0.5) * 1e-3).half()
 dparams = torch.zeros(net.n_params(), dtype=torch.float32, device="cuda")
 ws = net.train_lean_workspace(S)
-net.train_forward_lean(encT, S, ws, out)
+FOLDED = bool(os.environ.get("LEAN_FOLDED"))      # the kernels with sampler + encoder folded in, on random segments
+if FOLDED:
+    P = S // 32
+    S = P * 32
+    start = torch.rand((P, 3), device="cuda", generator=g) * 2 - 1
+    end = start + (torch.rand((P, 3), device="cuda", generator=g) - 0.5) * 0.3
+    view = torch.rand((P, 2), device="cuda", generator=g) * 3
+    net.train_forward_lean_segments(start, end, view, P, 0, ws, out)
+else:
+    net.train_forward_lean(encT, S, ws, out)
 times = {s: [] for s in splits}
 for rep in range(10):
     for s in splits:
         os.environ["RTXN_LEAN_SPLIT"] = s
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        net.train_backward_lean(encT, out, dout, S, ws, dparams)
+        if FOLDED:
+            net.train_backward_lean_segments(start, end, view, P, 0, out, dout[:S], ws, dparams)
+        else:
+            net.train_backward_lean(encT, out, dout, S, ws, dparams)
         e1.record()
         torch.cuda.synchronize()
         if rep:
