@@ -167,7 +167,11 @@ __device__ __forceinline__ void encode_freq_fragments_3_10_2_12(const float (&x)
       const FreqFeat f0 = freq_feat_3_10_2_12(b), f1 = freq_feat_3_10_2_12(b + 4);
       const float xv = (f1.pad || f0.dim == f1.dim) ? x[f0.dim] : (h ? x[f1.dim] : x[f0.dim]);
       const int e = f1.pad ? f0.freq : (h ? f1.freq : f0.freq);
+#ifdef RTXN_ENC_FAKE      // timing-only (results wrong): what the folded encoder's sines and range reductions cost end to end
+      float y = xv * (float)(e + 1) * 0.03125f + 0.25f * (float)f0.ph;
+#else
       float y = sin_turns(xv, e, f0.ph);                 // b and b + 4 have the same parity: the same phase
+#endif
       if (f1.pad) y = h ? 1.0f : y;
       v[j] = ok ? (_Float16)y : (_Float16)0.0f;
     }
