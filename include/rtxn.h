@@ -495,7 +495,7 @@ int rtxn_mlp_train_backward_recompute(const rtxn_mlp* m, const void* encT, const
  * workspace of 4.3 KB per sample -- 40 GB at the reference's batch (main.cu:186).  Here the forward keeps only the 16-byte
  * sign masks per sample and layer (all the backward chain needs of the activations), the chain writes dZ as before, and the
  * weight gradient RECOMPUTES the activations from the encoded input in three passes (layers 0-2, 3-5, 6-7 + output) with the
- * gradients accumulated on chip: 5.4 KB moved and 2.2 KB of workspace per sample.  Same results as the pair above up to the
+ * gradients accumulated on chip: 5.4 KB moved (4.4 with the _segments pair below, which needs no encT) and 2.2 KB of workspace per sample.  Same results as the pair above up to the
  * summation order of the fp32 atomics.
  *   rtxn_mlp_train_lean_supported: 1 if the model has this path;
  *   workspace_lean: rtxn_mlp_train_lean_workspace_bytes(m, n_samples) bytes, written by _forward_lean, read by _backward_lean;
