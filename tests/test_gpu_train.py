@@ -988,3 +988,72 @@ def test_lean_backward_recomputing_the_encoding_equals_the_one_reading_it(gpu, P
     a, b = res
     assert np.isfinite(b).all() and np.linalg.norm(a) > 0
     assert np.linalg.norm(a - b) <= 2e-5 * np.linalg.norm(a) and np.abs(a - b).max() <= 1e-4 * np.abs(a).max()
+
+
+@pytest.mark.parametrize("act", [0, 1])
+def test_lean_gradients_match_torch_autograd(gpu, act):
+    """A reference that is neither this repository's oracle nor its kernels: the 8 x 128 model rebuilt as float64 torch modules on the
+    CPU (weights = the fp16 parameters exactly, tcnn layout: layer l is [out][in] row-major, the output layer 16 x 128), the same
+    encoded inputs, loss = sum(output[:, :4] * g), gradients by torch.autograd -- against the lean path (encT form and the form with
+    sampler + encoder folded in) fed g as dL/d(output).  fp16 activations against float64: 3e-3 of the gradient's norm for the output
+    layer, 6e-2 for the hidden ones (measured 7e-4 and 1.5e-2 ... 4.5e-2, growing with depth); outputs 2e-2 absolute."""
+    torch = gpu
+    from rtx_nerf_amd import api
+    rng = np.random.default_rng(77 + act)
+    W, L, E, P = 128, 8, 112, 96
+    n = P * 32
+    net = api.Network(n_neurons=W, n_hidden_layers=L, output_activation=act)
+    params = scenes.xavier_params_fp16(W, L, E, seed=9)
+    net.set_params(_dev(torch, params))
+    start = _dev(torch, rng.uniform(-1, 1, (P, 3)).astype(np.float32))
+    end = _dev(torch, (start.cpu().numpy() + rng.uniform(-0.2, 0.2, (P, 3))).astype(np.float32))
+    view = _dev(torch, rng.uniform(0, 3.0, (P, 2)).astype(np.float32))
+    Sp = api.padded_samples(n)
+    encT = torch.zeros((E, Sp), dtype=torch.float16, device="cuda")
+    net.encode_frequency_segments(start, end, view, P, 0, encT)
+    g = (rng.standard_normal((n, 4)) * 0.05).astype(np.float16)
+    g_d = _dev(torch, g)
+
+    # ---- torch, float64, CPU ----
+    x = encT[:, :n].t().contiguous().cpu().double()
+    sizes = [(W, E)] + [(W, W)] * (L - 1) + [(16, W)]
+    ws, off = [], 0
+    for o, i in sizes:
+        ws.append(torch.from_numpy(params[off:off + o * i].astype(np.float64).reshape(o, i)).requires_grad_(True))
+        off += o * i
+    assert off == params.size
+    h = x
+    for w in ws[:-1]:
+        h = torch.relu(h @ w.t())
+    z = h @ ws[-1].t()
+    y = torch.sigmoid(z) if act else z
+    (y[:, :4] * torch.from_numpy(g.astype(np.float64))).sum().backward()
+    want = np.concatenate([w.grad.numpy().reshape(-1) for w in ws])
+    want_out = y.detach().numpy()[:, :4]
+
+    for folded in (False, True):
+        wsp = net.train_lean_workspace(n)
+        out = torch.zeros((n, 16), dtype=torch.float16, device="cuda")
+        dp = torch.zeros(net.n_params(), dtype=torch.float32, device="cuda")
+        if folded:
+            net.train_forward_lean_segments(start, end, view, P, 0, wsp, out)
+            net.train_backward_lean_segments(start, end, view, P, 0, out, g_d, wsp, dp)
+        else:
+            net.train_forward_lean(encT, n, wsp, out)
+            net.train_backward_lean(encT, out, g_d, n, wsp, dp)
+        torch.cuda.synchronize()
+        assert np.abs(out[:, :4].float().cpu().numpy() - want_out).max() <= 2e-2
+        got = dp.double().cpu().numpy()
+        off = 0
+        errs = []
+        for k, (o, i) in enumerate(sizes):
+            a, b = got[off:off + o * i], want[off:off + o * i]
+            if k == len(sizes) - 1:                       # rows 4..15 of the output layer carry no loss
+                a, b = a[:4 * W], b[:4 * W]
+                assert np.abs(got[off + 4 * W:off + o * i]).max() == 0.0
+            errs.append(np.linalg.norm(a - b) / np.linalg.norm(b))
+            off += o * i
+        # measured: output layer 7e-4, layer 7 1.5e-2, ... layer 0 4.5e-2 of the norm -- half-precision activations and dZ (as tcnn keeps
+        # them) and the ReLU masks of activations within an fp16 rounding of zero, compounding layer by layer against a float64 chain;
+        # a wrong layout, transposition or sign would be O(1)
+        assert errs[-1] <= 3e-3 and max(errs[:-1]) <= 6e-2, (folded, ["%.2e" % e for e in errs])
