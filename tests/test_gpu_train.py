@@ -1057,3 +1057,42 @@ def test_lean_gradients_match_torch_autograd(gpu, act):
         # them) and the ReLU masks of activations within an fp16 rounding of zero, compounding layer by layer against a float64 chain;
         # a wrong layout, transposition or sign would be O(1)
         assert errs[-1] <= 3e-3 and max(errs[:-1]) <= 6e-2, (folded, ["%.2e" % e for e in errs])
+
+
+def test_hash_scatter_is_the_adjoint_of_the_encoder_at_the_bench_size(gpu):
+    """A size-independent property at BASELINE configs[2]'s own size (L = 16, F = 2, T = 2^19, base 16 x 1.5; 660 k samples), no oracle
+    involved: the encoding is linear in the table, so for any table t and any d, <encode(t), d> = <t, scatter(d)>.  The encoder is
+    held to tiny-cuda-nn's published formulas by tests/golden/kat_north_star.npz; this identity then pins the scatter -- every level,
+    the fp32 form and the mixed form (hashed levels through packed fp16 atomics).  fp16 rounding of the encoding and (mixed) of the
+    gradient entries: 2e-3 / 3e-3 relative."""
+    torch = gpu
+    from rtx_nerf_amd import api
+    rng = np.random.default_rng(2026)
+    n = 660_000
+    hg = api.HashGrid(16, 2, 19, 16, 1.5, n_dir_freqs=4)
+    nh = 32
+    x = _dev(torch, np.concatenate([rng.uniform(-1, 1, (n, 3)), rng.uniform(0, 3, (n, 2))], axis=1).astype(np.float32))
+    table = _dev(torch, (rng.standard_normal(hg.n_params()) * 0.5).astype(np.float16))
+    E, Sp = hg.encoded_width(), api.padded_samples(n)
+    enc = hg.encode(table, x)                                      # half[E][Sp]
+    d = torch.zeros((E, Sp), dtype=torch.float16, device="cuda")
+    d[:nh, :n] = _dev(torch, (rng.standard_normal((nh, n)) * 0.25).astype(np.float16))     # nothing on the direction features: not the table's
+    lhs = float((enc[:nh, :n].double() * d[:nh, :n].double()).sum())
+    g32 = torch.zeros(hg.n_params(), device="cuda")
+    hg.backward(x, d, g32)
+    rhs = float((table.double() * g32.double()).sum())
+    scale = float((enc[:nh, :n].double() * d[:nh, :n].double()).abs().sum())
+    assert abs(lhs) > 1e-6 * scale and abs(lhs - rhs) <= 2e-3 * scale ** 0.5 * abs(lhs) ** 0.5 + 2e-4 * abs(lhs), (lhs, rhs)
+    lo = hg.hashed_offset()
+    m32 = torch.zeros(hg.n_params(), device="cuda")
+    m16 = torch.zeros(hg.n_params() - lo, dtype=torch.float16, device="cuda")
+    hg.backward_mixed(x, d, m32, m16)
+    rhs_m = float((table[:lo].double() * m32[:lo].double()).sum() + (table[lo:].double() * m16.double()).sum())
+    assert abs(lhs - rhs_m) <= 3e-3 * scale ** 0.5 * abs(lhs) ** 0.5 + 3e-3 * abs(lhs), (lhs, rhs_m)
+    # level by level too (a level with its gradient in the wrong place would cancel nowhere)
+    offs = [hg.level_offset(l) for l in range(17)]                  # in parameters (entries x features)
+    for l in range(16):
+        a = float((enc[2 * l:2 * l + 2, :n].double() * d[2 * l:2 * l + 2, :n].double()).sum())
+        b = float((table[offs[l]:offs[l + 1]].double() * g32[offs[l]:offs[l + 1]].double()).sum())
+        s = float((enc[2 * l:2 * l + 2, :n].double() * d[2 * l:2 * l + 2, :n].double()).abs().sum())
+        assert abs(a - b) <= 5e-3 * s ** 0.5 * max(abs(a), 1.0) ** 0.5 + 1e-3 * abs(a), (l, a, b)
