@@ -6,7 +6,7 @@ SRCS := $(wildcard $(CSRC)/*.hip)
 OBJS := $(patsubst $(CSRC)/%.hip,build/%.o,$(SRCS)) build/loader.o
 HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -Iinclude -I$(CSRC) -Wall -Wno-unused-function
 
-all: rtx_nerf_amd/librtxn.so oracle examples/render_host examples/render_host_mgpu examples/train_host check-isa
+all: rtx_nerf_amd/librtxn.so oracle examples/render_host examples/render_host_mgpu examples/train_host examples/train_host_mgpu check-isa
 
 # train.hip: -amdgpu-mfma-vgpr-form.  Its one kernel above 256 registers (mlp_bwd_fused64_kernel, one wave per SIMD) keeps the
 # weight-gradient accumulators in AGPRs by hand (asm "+a"); left to its heuristic, hipcc put the destination of EVERY MFMA of
@@ -47,8 +47,11 @@ examples/render_host_mgpu: examples/render_host_mgpu.cpp rtx_nerf_amd/librtxn.so
 examples/train_host: examples/train_host.cpp rtx_nerf_amd/librtxn.so include/rtxn.h
 	$(HIPCC) -O2 -std=c++17 --offload-arch=$(ARCH) -Iinclude $< -o $@ -Lrtx_nerf_amd -lrtxn -Wl,-rpath,'$$ORIGIN/../rtx_nerf_amd'
 
+examples/train_host_mgpu: examples/train_host_mgpu.cpp rtx_nerf_amd/librtxn.so include/rtxn.h
+	$(HIPCC) -O2 -std=c++17 --offload-arch=$(ARCH) -Iinclude $< -o $@ -Lrtx_nerf_amd -lrtxn -Wl,-rpath,'$$ORIGIN/../rtx_nerf_amd'
+
 clean:
-	rm -rf build rtx_nerf_amd/librtxn.so examples/render_host examples/render_host_mgpu examples/train_host
+	rm -rf build rtx_nerf_amd/librtxn.so examples/render_host examples/render_host_mgpu examples/train_host examples/train_host_mgpu
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean check-isa

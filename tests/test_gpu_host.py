@@ -164,3 +164,32 @@ def test_cpp_multi_gpu_host_shards_rehearsed_on_one_gpu(gpu, tmp_path, W, H, R, 
     assert want.shape == got.shape == (W * H * 3,) and want.std() > 1e-3
     assert np.array_equal(got, want)
     assert open(out, "rb").read() == open(one, "rb").read()
+
+
+def test_cpp_data_parallel_training_host_rehearsed_on_one_gpu(gpu, tmp_path):
+    """examples/train_host_mgpu.cpp: ONE C++ process, the reference's 8 x 128 iteration with the ray batch split over N shards, each
+    with its own replica, stream and buffers; per step every shard computes its gradient (rtxn_trace_grid / rtxn_scan_hits /
+    rtxn_train_gradients), the gradients are summed on the root in shard order (peer copies + one add kernel of the host's own), the
+    sum is copied back and every replica takes the same Adam step (loss scale x N).  With the shards on device 0 ("0,0", "0,0,0,0":
+    the one-GPU rehearsal): the replicas end bit-identical to each other (the program checks and says so); the first step's summed
+    gradient is the one-shard gradient of the same batch (each shard scales its loss by 1 / N, so every ray's fp16 loss gradient is the
+    very number the one-shard step rounds to: what differs is the order of the fp32 sums, 1e-4 of the norm); and the parameters after
+    eight Adam steps agree to what Adam makes of that (its first steps are lr x sign(g): entries with a gradient at rounding level
+    can go either way).
+    Unmeasured on more than one GPU."""
+    exe = os.path.join(ROOT, "examples", "train_host_mgpu")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", ROOT, "examples/train_host_mgpu"])
+    outs, grads = {}, {}
+    for devices in ("0", "0,0", "0,0,0,0"):
+        n = devices.count(",") + 1
+        out, gout = str(tmp_path / f"dp_{n}.f32"), str(tmp_path / f"dpg_{n}.f32")
+        res = subprocess.run([exe, "8", "2048", "8", devices, out, gout], capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stdout + res.stderr
+        assert f"over {n} shard(s)" in res.stdout and "replicas bit-identical" in res.stdout, res.stdout
+        outs[n], grads[n] = np.fromfile(out, np.float32), np.fromfile(gout, np.float32)
+        assert np.isfinite(outs[n]).all() and np.isfinite(grads[n]).all()
+    assert np.linalg.norm(grads[1]) > 0
+    for n in (2, 4):
+        assert np.linalg.norm(grads[n] - grads[1]) <= 1e-4 * np.linalg.norm(grads[1]), (n, np.linalg.norm(grads[n] - grads[1]) / np.linalg.norm(grads[1]))
+        assert np.linalg.norm(outs[n] - outs[1]) <= 6e-3 * np.linalg.norm(outs[1])
