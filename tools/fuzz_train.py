@@ -106,10 +106,24 @@ for it in range(n_lean):
     want_dp, _ = O.mlpe_backward(W, L, act, params, enc, acts_sm, out.cpu().numpy(), dout)
     got_dp = dparams.cpu().numpy()
     scale = np.abs(want_dp).max()
-    if scale > 0 and not (np.abs(got_dp - want_dp).max() < 3e-2 * scale and np.linalg.norm(got_dp - want_dp) < 2e-2 * np.linalg.norm(want_dp)):
-        errs.append(f"weight gradient: max err {np.abs(got_dp - want_dp).max() / max(scale, 1e-30):.3g} of scale")
+    # (the oracle's backward runs on the ORACLE's activations here -- the lean path stores none to hand over -- so an activation within an
+    # fp16 rounding of zero can sit on the other side of its ReLU; with a few hundred samples, part of them dead, that is 2-2.5e-2 of the norm
+    # in one case of twenty (4e-2 allowed; the largest single element 8e-2).  The tight statement is the comparison with the
+    # saved-activation kernels below, which the first loop holds to the oracle on the GPU's own activations.)
+    if scale > 0 and not (np.abs(got_dp - want_dp).max() < 8e-2 * scale and np.linalg.norm(got_dp - want_dp) < 4e-2 * np.linalg.norm(want_dp)):
+        errs.append(f"weight gradient: max err {np.abs(got_dp - want_dp).max() / max(scale, 1e-30):.3g} of scale, "
+                    f"{np.linalg.norm(got_dp - want_dp) / np.linalg.norm(want_dp):.3g} of the norm")
     if scale == 0 and np.abs(got_dp).max() != 0:
         errs.append("non-zero gradient for an all-zero loss gradient")
+    ws_s = net.train_workspace(n)
+    out_s = net.train_forward(encT_d, n, ws_s)
+    dp_s = torch.zeros(net.n_params(), device="cuda")
+    net.train_backward(encT_d, out_s, dev(dout), n, ws_s, dp_s)
+    torch.cuda.synchronize()
+    ref = dp_s.double().cpu().numpy()
+    if np.linalg.norm(ref) > 0 and not np.linalg.norm(got_dp - ref) <= 5e-5 * np.linalg.norm(ref):
+        errs.append(f"lean vs saved-activation kernels: {np.linalg.norm(got_dp - ref) / np.linalg.norm(ref):.3g} of the norm")
+    del ws_s
     if errs:
         bad += 1
         print(f"MISMATCH lean it={it} act={act} n={n}: {errs}", flush=True)
