@@ -396,9 +396,10 @@ def train_ref_record(batch_rays, grid_res, steps, warmup, dense_grid=True, mode=
         bytes_exec = 384 + live_frac * (2248 + 2080 + 3 * 224)
         if getattr(tr, "lean_fused", False):
             # sampler + encoder folded into the forward and into the weight gradient: no encT (forward: 1 B of segment constants in, 32 B out,
-            # 128 B of masks, 4 B of t_vals; weight gradient: dZ only)
-            path = "lean, encoder folded in: sign masks only, weight gradient recomputes encoding and activations (three passes)"
-            bytes_exec = 165 + live_frac * (2248 + 2080)
+            # 128 B of masks, 4 B of t_vals); the last hidden layer's dZ is formed in the weight-gradient kernel, so the chain writes and the
+            # weight gradient reads 7 x 256 + 32 B of dZ
+            path = "lean, encoder folded in: sign masks only, weight gradient recomputes encoding, activations and the last layer's dZ (three passes)"
+            bytes_exec = 165 + live_frac * (168 + 1824 + 1824)
     else:
         path = "saved activations" + (" (outputs-only forward + saving pass over the live segments)" if tr.two_pass else "")
         flop_exec = 262144 * (1.0 + 2.0 * live_frac + (live_frac if tr.two_pass else 0.0))

@@ -539,6 +539,7 @@ struct TrainArgs {
   SampleSrc src;            // forward with the encoder fused (ENC = 1): where the samples come from; encT is not read
   float* t_vals;            //   ... and the sampler's t_vals, if asked for (as rtxn_encode_frequency_segments writes them)
   float t_scale;
+  int skip_last_dz;         // backward chain: dZ of the LAST hidden layer is not stored (the folded weight-gradient kernel forms it itself)
 };
 
 // Element (feature row f0 + 4h, sample s) of a feature-major tensor X[feature][Sp]: the address is split into a wave-uniform
@@ -1067,6 +1068,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_bwd_kernel(TrainArgs a) {
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) dst[2 * rt + s2][ct] = pack8<false>(m, s2);
     }
+    if (a.skip_last_dz && l == L - 1) return;
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) store_fragment_rows_pair(dzl, 2 * rt + s2, Sp_l, lane_dst[0], dst[2 * rt + s2][0], dst[2 * rt + s2][1]);
   };
@@ -1832,6 +1834,8 @@ constexpr int kLnOffOL = kLnOffX + 2 * kLnImg;   // dZ of the output layer, 16 r
 constexpr int kLnEncScratch = 112 * 128;           // one wave's encoded tile, [feature][64 samples]: 14 KiB, from kLnOffX on (the images, the
 constexpr int kLnOffJunk = kLnOffX + 4 * kLnEncScratch;   // output layer's dZ and 7 KiB more are all free at the top of a tile); 256 B nobody reads
 static_assert(kLnOffJunk >= kLnOffOL + 8192, "the scratch ends behind the output layer's dZ");
+constexpr int kLnOffWoT = kLnOffOL + 8192;         // ENC passes (no encoding scratch): the output layer's W^T, four 1-KiB fragments, resident for the kernel
+static_assert(kLnOffWoT + 4096 <= kLnOffJunk, "W_out^T sits in the tail of the (then unused) encoding scratch");
 constexpr int kLnLds = kLnOffJunk + 256;
 #ifdef RTXN_LN_STAMPS
 constexpr int kLnLdsLaunch = kLnLds + 4096;   // the stamps
@@ -1856,6 +1860,7 @@ struct LeanArgs {
   const int* live_count;
   DetCtx det;
   SampleSrc src;               // ENC passes: the packed segments the encoding is recomputed from (encT is not read)
+  const uint8_t* packed_bwd;   // ENC passes: packed_t, whose first four fragments are the output layer's W^T (dZ of the last hidden layer is formed here)
 };
 
 // (timing-only ablations, results wrong: -DRTXN_LN_NO_WAIT no wait for the dZ stages / weights, -DRTXN_LN_NO_CONTRACT no contraction,
@@ -2094,6 +2099,8 @@ __device__ __forceinline__ void wgrad_recompute_pass(LeanArgs a, const int sub_b
 
   // ---- prologue: layer 0's weights (from then on every forward fetches the next one's) and the first three stages of the first tile ----
   if (FWD_END > 0) stage_rt(a.packed_fwd, smem + kLnOffW, KS0 * RT * 1024, tid);
+  constexpr bool DZ_LAST = ENC && OUT;                    // dZ of the last hidden layer is computed here, not fetched (see the last layer's step)
+  if constexpr (DZ_LAST) stage_rt(a.packed_bwd, smem + kLnOffWoT, RT * 1024, tid);   // lands with layer 0's weights, in front of the first [W+T] barrier
 
   while (tile < a.n_tiles) {
     const int nxt_tile = next_live(tile + sub_grid);
@@ -2238,9 +2245,10 @@ __device__ __forceinline__ void wgrad_recompute_pass(LeanArgs a, const int sub_b
         constexpr bool next_w_same_tile = has_w && l + 1 < L1;
         RTXN_LN_STAMP(2 + 11 * l);
         // ---- [W+T] ----
-        if constexpr (has_f) ln_wait_vm<(prev_w ? 8 : 0)>();
+        constexpr bool dz_here = DZ_LAST && l == LTOT - 1;                       // this layer's dZ is formed in the kernel: nothing of it is in flight
+        if constexpr (has_f) ln_wait_vm<(dz_here ? 0 : prev_w ? 8 : 0)>();        // (dz_here: behind the weights only the output layer's dZ, needed as well)
         ln_barrier();
-        if constexpr (has_w && l > L0) {
+        if constexpr (has_w && l > L0 && !dz_here) {
           // slots 2, 3 (the previous step's second pair has just left them): stages 2, 3 of this layer, whose stages 0, 1 the
           // previous step looked ahead to
           issue_stage(2, l, (long)tile * kTile + 64 * 2);
@@ -2310,6 +2318,43 @@ __device__ __forceinline__ void wgrad_recompute_pass(LeanArgs a, const int sub_b
                 for (int rt = 0; rt < RT; ++rt)         // four different accumulators in a row: a dependent MFMA is four behind
                   asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(oq[rt]) : "v"(nxt[2 * rt + s][ct]), "v"(bz));
               }
+            if constexpr (DZ_LAST) {
+              // dZ of THIS layer, formed here instead of fetched (the dgrad chain does not store it: 256 B per sample less written and
+              // read): dZ^T[f][s] = relu'(A[f][s]) sum_o W_L[o][f] dZ_L[o][s] with the operands exchanged as above -- A operand dZ_L with
+              // the sample on the lane (eight two-byte reads per column tile from the wave's own sub-image), B operand the output
+              // layer's W^T fragment -- so the product comes out feature-on-lane exactly like nxt, whose zeros ARE the mask, and a lane
+              // holds four consecutive samples per accumulator quad: one ds_write_b64 each into the ring slot of the wave's 64 samples, in
+              // the layout the DMA stages have (row f, 16-byte sample group g in slot g ^ ((f >> 1) & 7)).  The same products, one
+              // rounding to fp16: the values the chain kernel would have stored.
+              const uint8_t* olw = smem + kLnOffOL + wave * 2048;
+              uint8_t* stage = ring + wave * kLnStage;
+#pragma unroll
+              for (int ct = 0; ct < 2; ++ct) {
+                half8 dza;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                  const int R = 8 * h + j, sl = 32 * ct + col;
+                  dza[j] = *reinterpret_cast<const _Float16*>(olw + R * 128 + ((((sl >> 3) ^ ((R >> 1) & 7))) << 4) + (sl & 7) * 2);
+                }
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                  const half8 wt = *reinterpret_cast<const half8*>(smem + kLnOffWoT + (rt * 64 + lane) * 16);
+                  floatx16 z;
+#pragma unroll
+                  for (int e = 0; e < 16; ++e) z[e] = 0.0f;
+                  const floatx16 gz = __builtin_amdgcn_mfma_f32_32x32x16_f16(dza, wt, z, 0, 0, 0);
+                  const int f = 32 * rt + col;
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) {
+                    const half8& tq = nxt[2 * rt + (q >> 1)][ct];
+                    half4v o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = tq[4 * (q & 1) + i] != (_Float16)0.0f ? (_Float16)gz[4 * q + i] : (_Float16)0.0f;
+                    *reinterpret_cast<half4v*>(stage + f * 128 + (((4 * ct + q) ^ ((f >> 1) & 7)) << 4) + 8 * h) = o;
+                  }
+                }
+              }
+            }
           } else {
             floatx16 acc2[2][2];
             rtxn::pipe_layer<RT, KS, KS>(wl, cur, nxt, acc2, lane);
@@ -2338,15 +2383,16 @@ __device__ __forceinline__ void wgrad_recompute_pass(LeanArgs a, const int sub_b
           // Issued when the first pair has left slots 0, 1: the next gradient layer's stages 0, 1.  The tile's last gradient layer
           // looks ahead to nothing (the next tile issues its four stages itself, behind its wait for the encoding): it warms the L2
           // with the next tile's encoding instead.
+          constexpr bool next_dz_here = DZ_LAST && l + 1 == LTOT - 1;            // the next layer's dZ will be formed in the kernel: no look-ahead
           auto look_ahead = [&]() {
-            if constexpr (next_w_same_tile) {
+            if constexpr (next_w_same_tile && !next_dz_here) {
               issue_stage(0, next_w, (long)tile * kTile);
               issue_stage(1, next_w, (long)tile * kTile + 64);
             } else if constexpr (!ENC) {
               prefetch_enc(look);
             }
           };
-          constexpr int ahead_ops = next_w_same_tile ? 8 : (ENC ? 0 : 4);
+          constexpr int ahead_ops = next_w_same_tile && !next_dz_here ? 8 : (ENC ? 0 : 4);
           if (wave < 2) write_image(ximg + wave * kLnImg, cur);
           ln_wait_vm<8>();                                // stages 0, 1: behind them stages 2, 3
           ln_barrier();                                   // + the images of waves 0, 1; everyone has left the forward
@@ -3039,6 +3085,7 @@ static int train_backward_lean_impl(const rtxn_mlp* m, const void* encT, const v
   a.dzL = ws + (long)L * W * Sp;
   a.masks = reinterpret_cast<unsigned long long*>(ws + ((long)L * W + 16) * Sp);
   a.live_tiles = reinterpret_cast<uint8_t*>(ws + ((long)L * W + 16 + 8L * L) * Sp);
+  a.skip_last_dz = src ? 1 : 0;     // the folded weight-gradient kernel forms the last hidden layer's dZ itself
   a.live_list = live_list;
   a.live_count = live_count;
   a.out_half = const_cast<_Float16*>(static_cast<const _Float16*>(output_half));
@@ -3066,6 +3113,7 @@ static int train_backward_lean_impl(const rtxn_mlp* m, const void* encT, const v
   la.live_count = live_count;
   la.det = det_ctx(dparams, g_det_mlp);
   if (src) la.src = *src;
+  la.packed_bwd = static_cast<const uint8_t*>(m->packed_t);
   int dev = 0, n_cu = 0;
   RTXN_HIP(hipGetDevice(&dev));
   RTXN_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
