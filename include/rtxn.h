@@ -510,7 +510,7 @@ int rtxn_mlp_train_forward_lean(const rtxn_mlp* m, const void* encT, long n_samp
  * _forward_lean reads out of encT; t_vals (may be NULL) as rtxn_encode_frequency_segments writes them.  _backward_lean_segments is the
  * matching backward: its weight gradient recomputes the encoding with the activations, a column tile's segment constants through
  * the scalar cache.  With the pair no encT exists at all (main.cu:721,781 are tcnn calls that encode and multiply in one):
- * 3.7 instead of 4.8 KB per sample through device memory, and no encoder launch. */
+ * 3.6 instead of 4.8 KB per sample through device memory (the pair also forms the last hidden layer's dZ on chip), and no encoder launch. */
 int rtxn_mlp_train_forward_lean_fused_supported(const rtxn_mlp* m);
 int rtxn_mlp_train_forward_lean_segments(const rtxn_mlp* m, const float* start_points, const float* end_points, const float* seg_view,
                                          long n_segments, int sample_type, float t_scale, float* t_vals, void* workspace_lean,
